@@ -1,0 +1,198 @@
+/*
+ * nbody_hip.h — C ABI of the MI355X (gfx950) n-body force + integration step.
+ *
+ * Drop-in boundary for the hot path of KristinnVikarJ/nbody-simulation.  The reference has no FFI of its
+ * own (no `extern`, `#[no_mangle]`, `repr(C)` anywhere); the seam this library replaces is the single call
+ *
+ *     world.update(STEP_SIZE, &mut counter)            src/main.rs:120  ->  World::update  src/main.rs:388-425
+ *
+ * and its three inner phases: tree build + upward pass (main.rs:400-401, bvh_tree.rs:56-158), force map
+ * (main.rs:406-416 -> bvh_sum_gravity :348-386 -> calculate_gravity :234-253) and the semi-implicit Euler
+ * loop (main.rs:419-423).  `Particle` (main.rs:193-198) is not repr(C), so the ABI takes separate flat
+ * arrays: pos_xy / vel_xy interleaved (x0,y0,x1,y1,...) and weight as u32, caller-owned, copied in/out.
+ *
+ * Conventions
+ *   - Every function returns 0 (NBODY_OK) or a negative nbody_status; nothing aborts or unwinds.
+ *     nbody_last_error() gives the message of the last failure on that context (or, with ctx == NULL,
+ *     of the last failed nbody_create on this thread).
+ *   - A context belongs to one host thread at a time (the reference calls update from one dedicated
+ *     thread only, main.rs:110-141).  Calls are synchronous unless the name ends in _dev (those enqueue
+ *     on the given hipStream_t and return).
+ *   - One context = one GPU = one process rank.  Multi-GPU runs shard targets over ranks; the only
+ *     exchange is an all-gather of positions per step, done by the host (RCCL) between *_dev calls.
+ *   - There is no CPU fallback: without a gfx950 device nbody_create fails with NBODY_ERR_NO_DEVICE.
+ */
+#ifndef NBODY_HIP_H
+#define NBODY_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NBODY_ABI_VERSION 1
+
+typedef struct nbody_ctx nbody_ctx;
+typedef struct nbody_timer nbody_timer;
+typedef struct nbody_host_tree nbody_host_tree;
+
+typedef enum nbody_status {
+  NBODY_OK = 0,
+  NBODY_ERR_INVALID = -1,    /* bad argument / call order */
+  NBODY_ERR_NO_DEVICE = -2,  /* no usable gfx950 device */
+  NBODY_ERR_HIP = -3,        /* a HIP runtime call failed (message has the hipError string) */
+  NBODY_ERR_DEGENERATE = -4, /* tree build hit the depth cap: > leaf_size coincident points (the
+                                reference recurses without bound there, bvh_tree.rs:78-88, quad_tree.rs:159-161) */
+  NBODY_ERR_NOMEM = -5
+} nbody_status;
+
+/* Arithmetic of the direct-sum kernel (the tree walkers always use the reference's operations). */
+typedef enum nbody_arith {
+  NBODY_ARITH_AUTO = 0,  /* FAST, switching per step on device to EXACT when a position is non-finite,
+                            >= 2^60 in magnitude, or non-zero below 2^-22 (the inputs on which FAST and the
+                            reference's is_normal() skip, main.rs:241-243, could disagree) */
+  NBODY_ARITH_FAST = 1,  /* one v_rcp_f32 per pair, fused multiply-adds, sources split over waves;
+                            matches the reference to the tolerance in DESIGN.md */
+  NBODY_ARITH_EXACT = 2  /* every operation as main.rs:236-252 writes it (IEEE divide, no contraction,
+                            is_normal skip), one sequential ascending-j chain per target: bit-identical
+                            to the CPU restatement */
+} nbody_arith;
+
+/* Which particle order the accelerations of a BVH step are applied in. */
+typedef enum nbody_order {
+  NBODY_ORDER_AS_WRITTEN = 0, /* reference behaviour: acceleration i is computed for the pre-build
+                                 snapshot's particle i and added to the post-build (permuted) particle i
+                                 (main.rs:398, :406-416, :419-423) */
+  NBODY_ORDER_CONSISTENT = 1  /* acceleration applied to the particle it was computed for */
+} nbody_order;
+
+typedef enum nbody_tree_kind {
+  NBODY_TREE_BVH = 0,  /* src/bvh_tree.rs (live in the reference) */
+  NBODY_TREE_QUAD = 1  /* src/quad_tree.rs build + upward pass (dead code upstream); walk by analogy */
+} nbody_tree_kind;
+
+/* Mirrors `struct Counting` (main.rs:74-79): cumulative seconds per phase. */
+typedef struct nbody_counting {
+  double build_bvh;
+  double sum_gravity;
+  double post_calculations;
+} nbody_counting;
+
+/* Runtime form of the reference's compile-time constants. */
+typedef struct nbody_params {
+  float theta;       /* THETA = 50.0            main.rs:35   (node accepted when s^2 < d^2*theta*theta) */
+  float clamp;       /* 0.001                   main.rs:247-248 */
+  int32_t leaf_size; /* TARGET_POINTS = 64      bvh_tree.rs:37 (BVH only; quad leaves hold 8, quad_tree.rs:54) */
+  int32_t order;     /* nbody_order, default NBODY_ORDER_AS_WRITTEN */
+  int32_t arith;     /* nbody_arith, default NBODY_ARITH_AUTO */
+  float quad_root_x; /* root cell of the quad tree: offset (0,0), side HEIGHT = 100000 (main.rs:31) */
+  float quad_root_y;
+  float quad_root_h;
+} nbody_params;
+
+/* ---- lifetime ------------------------------------------------------------------------------------- */
+int nbody_abi_version(void);
+int nbody_create(nbody_ctx** out, int device_id);
+void nbody_destroy(nbody_ctx* ctx);
+const char* nbody_last_error(const nbody_ctx* ctx);
+int nbody_default_params(nbody_params* out);
+int nbody_set_params(nbody_ctx* ctx, const nbody_params* p);
+int nbody_get_params(const nbody_ctx* ctx, nbody_params* out);
+
+/* ---- particle state: replaces `World.particles: Vec<Particle>` (main.rs:37-39) -------------------- */
+int nbody_upload_f32(nbody_ctx* ctx, int64_t n, const float* pos_xy, const float* vel_xy, const uint32_t* weight);
+int nbody_upload_f64(nbody_ctx* ctx, int64_t n, const double* pos_xy, const double* vel_xy, const uint32_t* weight);
+/* Any output pointer may be NULL.  `ids` receives, for each row, the index the particle was uploaded at
+ * (a BVH step permutes rows exactly as BVHTree::from permutes `self.particles`, bvh_tree.rs:73-77). */
+int nbody_download_f32(nbody_ctx* ctx, float* pos_xy, float* vel_xy, uint32_t* weight, uint32_t* ids);
+int nbody_download_f64(nbody_ctx* ctx, double* pos_xy, double* vel_xy, uint32_t* weight, uint32_t* ids);
+int64_t nbody_num_particles(const nbody_ctx* ctx);
+
+/* ---- World::update replacements (force + integrate, n_steps times) -------------------------------- */
+/* Direct O(N^2): a_i = sum_j calculate_gravity(p_i, p_j, w_j) for j ascending, then main.rs:419-423.
+ * (No reference function: this is what bvh_sum_gravity degenerates to at theta = 0) */
+int nbody_update_direct_f32(nbody_ctx* ctx, float delta, int n_steps, nbody_counting* counter);
+/* Barnes-Hut: host builds the linearised tree exactly as the reference does, device walks it. */
+int nbody_update_tree_f32(nbody_ctx* ctx, int tree_kind, float delta, int n_steps, nbody_counting* counter);
+int nbody_update_tree_f64(nbody_ctx* ctx, int tree_kind, double delta, int n_steps, nbody_counting* counter);
+
+/* ---- parity hooks: force only, state untouched ----------------------------------------------------- */
+/* acc_xy[2*n]: accelerations in current row order. */
+int nbody_accel_direct_f32(nbody_ctx* ctx, float* acc_xy);
+/* Builds the tree over the current positions (rows are permuted for the BVH, as a step would) and walks
+ * it for `n_targets` arbitrary target positions (NULL: the particles themselves, post-build order). */
+int nbody_accel_tree_f32(nbody_ctx* ctx, int tree_kind, int64_t n_targets, const float* target_xy, float* acc_xy);
+int nbody_accel_tree_f64(nbody_ctx* ctx, int tree_kind, int64_t n_targets, const double* target_xy, double* acc_xy);
+
+/* Linearised tree of the last build (pre-order; node i's first child is i+1; `skip` is the pre-order index
+ * following the subtree).  Any pointer may be NULL; call with all NULL to get the node count. */
+typedef struct nbody_tree_view {
+  int64_t n_nodes;
+  int32_t kind;       /* nbody_tree_kind */
+  int32_t max_depth;
+} nbody_tree_view;
+int nbody_tree_info(const nbody_ctx* ctx, nbody_tree_view* out);
+/* geom: BVH [n_nodes][6] = off_x off_y size_x size_y cog_x cog_y; quad [n_nodes][5] = off_x off_y height cog_x cog_y.
+ * leaf_first/leaf_count: slice of the tree-ordered particle list; order[n]: upload index of each tree-ordered particle. */
+int nbody_tree_export_f32(const nbody_ctx* ctx, float* geom, uint32_t* mass, int32_t* is_leaf, int64_t* leaf_first,
+                          int64_t* leaf_count, int64_t* skip, uint32_t* order);
+int nbody_tree_export_f64(const nbody_ctx* ctx, double* geom, uint32_t* mass, int32_t* is_leaf, int64_t* leaf_first,
+                          int64_t* leaf_count, int64_t* skip, uint32_t* order);
+
+/* Host-side tree build on caller arrays, without a device: the same builder the update calls run (the reference
+ * also builds on the host, bvh_tree.rs:56-96).  Returns NBODY_ERR_DEGENERATE (with *out still valid, for
+ * inspection) when the depth cap was hit.  `p` may be NULL for the defaults. */
+int nbody_host_tree_build_f32(int tree_kind, int64_t n, const float* pos_xy, const uint32_t* weight,
+                              const nbody_params* p, nbody_host_tree** out);
+int nbody_host_tree_build_f64(int tree_kind, int64_t n, const double* pos_xy, const uint32_t* weight,
+                              const nbody_params* p, nbody_host_tree** out);
+void nbody_host_tree_free(nbody_host_tree* t);
+int nbody_host_tree_info(const nbody_host_tree* t, nbody_tree_view* out);
+int nbody_host_tree_export_f32(const nbody_host_tree* t, float* geom, uint32_t* mass, int32_t* is_leaf,
+                               int64_t* leaf_first, int64_t* leaf_count, int64_t* skip, uint32_t* order);
+int nbody_host_tree_export_f64(const nbody_host_tree* t, double* geom, uint32_t* mass, int32_t* is_leaf,
+                               int64_t* leaf_first, int64_t* leaf_count, int64_t* skip, uint32_t* order);
+
+/* Walk statistics of the most recent tree walk made while collection was enabled (node visits, accepted nodes,
+ * leaf pairs, summed over targets).  `enable` != 0 turns collection on for later walks (it costs three atomics
+ * per target), 0 turns it off.  Used to price the walk's algorithmic bytes. */
+int nbody_tree_walk_stats(nbody_ctx* ctx, int enable, uint64_t* node_visits, uint64_t* accepted, uint64_t* leaf_pairs);
+/* Cumulative phase seconds of this context (the reference prints these once a second, main.rs:149-156). */
+int nbody_get_counting(const nbody_ctx* ctx, nbody_counting* out);
+
+/* ---- device-pointer level (caller owns device memory and the stream; used for multi-GPU sharding) -- */
+/* One direct step for targets [target_begin, target_begin + n_targets) against all n_sources bodies.
+ *   pos_all   float2[n_sources]   all positions (gathered), read only
+ *   mass_all  float [n_sources]   weights converted to f32 (u32 -> f32 as `weight as f32`, main.rs:360)
+ *   uniform_mass                  > 0 asserts that every entry of mass_all equals this value (the FAST kernel
+ *                                 then hoists the multiply out of the sum); 0 when masses differ or are unknown
+ *   vel       float2[n_targets]   this shard's velocities, updated in place
+ *   pos_out   float2[n_targets]   this shard's new positions (must not alias pos_all)
+ *   acc_out   float2[n_targets]   or NULL
+ *   workspace: nbody_direct_workspace_bytes(n_sources, n_targets) bytes, 256-B aligned, reusable across calls
+ * delta == 0 with vel == pos_out == NULL computes accelerations only.
+ * `stream` is a hipStream_t.  `arith` is an nbody_arith; AUTO/EXACT semantics as above. */
+size_t nbody_direct_workspace_bytes(int64_t n_sources, int64_t n_targets);
+int nbody_direct_step_dev(void* stream, int64_t n_sources, const void* pos_all, const void* mass_all,
+                          float uniform_mass, int64_t target_begin, int64_t n_targets, void* vel, void* pos_out, void* acc_out,
+                          float delta, float clamp, int arith, void* workspace, size_t workspace_bytes,
+                          nbody_timer* timer /* may be NULL */);
+/* u32 weights -> f32 masses on device (the `as f32` of main.rs:360). */
+int nbody_weights_to_mass_dev(void* stream, int64_t n, const void* weight_u32, void* mass_f32);
+
+/* ---- kernel timing (bench.py's roofline leg) -------------------------------------------------------- */
+/* A timer brackets every launch of the dominant kernel of a call (direct: direct_fast / direct_exact; tree:
+ * the walk kernel) with HIP events recorded on the stream the kernel is launched on. */
+int nbody_timer_create(nbody_timer** out);
+void nbody_timer_destroy(nbody_timer* t);
+/* Waits for the recorded events; average milliseconds per launch and launch count since the last reset. */
+int nbody_timer_read(nbody_timer* t, int reset, double* avg_ms, int64_t* launches);
+/* Context-level calls time their dominant kernel with `t` (NULL turns timing off). */
+int nbody_set_timer(nbody_ctx* ctx, nbody_timer* t);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NBODY_HIP_H */

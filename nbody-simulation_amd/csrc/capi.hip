@@ -1,0 +1,808 @@
+// libnbody_hip — context and extern "C" surface (include/nbody_hip.h).
+//
+// Host side of the drop-in for World::update (/root/reference src/main.rs:388-425).  The context owns the
+// device image of `World.particles` (main.rs:37-39) as SoA arrays; every entry point is one of the three
+// phases of update (build / force / integrate) or a copy in/out.  There is no CPU fallback anywhere in this
+// file: the only host computation is the tree build, which the reference also does on the host and in
+// sequence (bvh_tree.rs:56-96); forces and integration always run on the GPU.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "common.h"
+#include "direct_kernels.h"
+#include "tree_build.hpp"
+#include "tree_kernels.h"
+
+using namespace nbody;
+
+// ------------------------------------------------------------------------------------------------ timer
+hipError_t nbody_timer::begin(hipStream_t s, Pair* out) {
+  if (pool.size() >= 256) {
+    hipError_t e = drain();
+    if (e != hipSuccess) return e;
+  }
+  Pair p{};
+  if (!free_.empty()) {
+    p = free_.back();
+    free_.pop_back();
+  } else {
+    hipError_t e = hipEventCreate(&p.a);
+    if (e != hipSuccess) return e;
+    e = hipEventCreate(&p.b);
+    if (e != hipSuccess) return e;
+  }
+  *out = p;
+  return hipEventRecord(p.a, s);
+}
+hipError_t nbody_timer::end(hipStream_t s, const Pair& p) {
+  hipError_t e = hipEventRecord(p.b, s);
+  pool.push_back(p);
+  return e;
+}
+hipError_t nbody_timer::drain() {
+  for (auto& p : pool) {
+    hipError_t e = hipEventSynchronize(p.b);
+    if (e != hipSuccess) return e;
+    float ms = 0.f;
+    e = hipEventElapsedTime(&ms, p.a, p.b);
+    if (e != hipSuccess) return e;
+    total_ms += ms;
+    launches++;
+    free_.push_back(p);
+  }
+  pool.clear();
+  return hipSuccess;
+}
+nbody_timer::~nbody_timer() {
+  for (auto& p : pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+  for (auto& p : free_) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+}
+
+// ------------------------------------------------------------------------------------------------ context
+namespace {
+
+thread_local std::string g_create_error;
+
+double now_s() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+template <class T> struct State {
+  using T2 = typename Vec2T<T>::type;
+  struct Set {
+    T2* pos = nullptr;
+    T2* vel = nullptr;
+    uint32_t* weight = nullptr;
+    uint32_t* ids = nullptr;
+    T* mass = nullptr;
+  };
+  int64_t n = 0;
+  Set set[2];
+  int cur = 0;
+  T2* pos_next = nullptr;  // direct step output, swapped with set[cur].pos
+  float uniform_mass = 0.f;  // > 0 when every weight is the same value (checked on upload)
+  T2* acc = nullptr;
+  // tree
+  void* geom0 = nullptr;
+  void* geom1 = nullptr;
+  void* link = nullptr;
+  size_t node_cap = 0;
+  uint32_t* order_dev = nullptr;
+  TreeHost<T> tree;
+  bool tree_valid = false;
+  std::vector<T> h_pos;
+  std::vector<uint32_t> h_weight;  // current row order
+  std::vector<uint32_t> h_tmp;
+};
+
+}  // namespace
+
+struct nbody_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  nbody_params params{};
+  nbody_counting counting{};
+  nbody_timer* timer = nullptr;
+  bool has_f32 = false, has_f64 = false;
+  State<float> sf;
+  State<double> sd;
+  void* workspace = nullptr;
+  size_t workspace_bytes = 0;
+  unsigned long long* stats_dev = nullptr;
+  unsigned long long last_stats[3] = {0, 0, 0};
+  bool want_stats = false;
+};
+
+struct nbody_host_tree {
+  bool is_f64 = false;
+  TreeHost<float> tf;
+  TreeHost<double> td;
+};
+
+namespace {
+
+int fail(nbody_ctx* c, int code, const std::string& msg) {
+  if (c) c->err = msg; else g_create_error = msg;
+  return code;
+}
+int fail_hip(nbody_ctx* c, hipError_t e, const char* what) {
+  return fail(c, NBODY_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define HIPCHK(c, call)                                   \
+  do {                                                    \
+    hipError_t e__ = (call);                              \
+    if (e__ != hipSuccess) return fail_hip(c, e__, #call); \
+  } while (0)
+
+template <class P> void free_dev(P*& p) {
+  if (p) (void)hipFree((void*)p);
+  p = nullptr;
+}
+template <class T> void free_state(State<T>& s) {
+  for (auto& st : s.set) { free_dev(st.pos); free_dev(st.vel); free_dev(st.weight); free_dev(st.ids); free_dev(st.mass); }
+  free_dev(s.pos_next); free_dev(s.acc); free_dev(s.geom0); free_dev(s.geom1); free_dev(s.link); free_dev(s.order_dev);
+  s.node_cap = 0; s.n = 0; s.tree_valid = false; s.tree.clear();
+  s.h_pos.clear(); s.h_weight.clear();
+}
+
+template <class T> State<T>& state_of(nbody_ctx* c);
+template <> State<float>& state_of<float>(nbody_ctx* c) { return c->sf; }
+template <> State<double>& state_of<double>(nbody_ctx* c) { return c->sd; }
+template <class T> bool has_state(const nbody_ctx* c);
+template <> bool has_state<float>(const nbody_ctx* c) { return c->has_f32; }
+template <> bool has_state<double>(const nbody_ctx* c) { return c->has_f64; }
+
+// -------------------------------------------------------------------------------------------- direct config
+int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return (v && *v) ? atoi(v) : dflt;
+}
+
+// How the direct kernel covers (n_tgt x n_src): enough waves to fill 256 CUs x 4 SIMDs x 8 waves.
+DirectConfig choose_direct_config(int64_t n_src, int64_t n_tgt) {
+  (void)n_src;
+  DirectConfig c;
+  c.use_lds = env_int("NBODY_DIRECT_LDS", 1) != 0;  // measured: LDS tile beats SGPR broadcast
+  c.tpt = env_int("NBODY_DIRECT_TPT", 1);
+  if (c.tpt != 1 && c.tpt != 2 && c.tpt != 4) c.tpt = 1;
+  const int64_t want_waves = 8192;
+  int64_t groups = (n_tgt + 64 * c.tpt - 1) / (64 * c.tpt);
+  int wsplit = env_int("NBODY_DIRECT_WSPLIT", 4);  // measured faster than 1 at every size
+  if (wsplit != 1 && wsplit != 4) wsplit = 4;
+  c.wsplit = wsplit;
+  int64_t waves = groups * wsplit;
+  int64_t g = waves > 0 ? (want_waves + waves - 1) / waves : 1;
+  if (g < 1) g = 1;
+  if (g > 32) g = 32;
+  g = env_int("NBODY_DIRECT_GSPLIT", (int)g);
+  if (g < 1) g = 1;
+  if (g > 64) g = 64;
+  // a split must still hold a few unrolled iterations
+  while (g > 1 && n_src / (g * c.wsplit) < 64) g /= 2;
+  c.gsplit = (int)g;
+  return c;
+}
+
+constexpr size_t kFlagBytes = 256;
+
+size_t direct_ws_bytes(int64_t n_src, int64_t n_tgt) {
+  DirectConfig c = choose_direct_config(n_src, n_tgt);
+  size_t partial = c.gsplit > 1 ? (size_t)c.gsplit * (size_t)n_tgt * sizeof(float2) : 0;
+  return kFlagBytes + ((partial + 255) & ~(size_t)255);
+}
+
+int direct_step_dev(nbody_ctx* c, hipStream_t stream, int64_t n_src, const void* pos_all, const void* mass_all,
+                    float uniform_mass, int64_t tgt_begin, int64_t n_tgt, void* vel, void* pos_out, void* acc_out,
+                    float delta, float clamp, int arith, void* ws, size_t ws_bytes, nbody_timer* timer) {
+  if (n_src < 0 || n_tgt < 0 || tgt_begin < 0 || tgt_begin + n_tgt > n_src || n_src > 0x7fffffffLL)
+    return fail(c, NBODY_ERR_INVALID, "direct_step: bad target/source range");
+  if (n_tgt == 0) return NBODY_OK;
+  if (!pos_all || !mass_all) return fail(c, NBODY_ERR_INVALID, "direct_step: null pos_all/mass_all");
+  if ((vel == nullptr) != (pos_out == nullptr))
+    return fail(c, NBODY_ERR_INVALID, "direct_step: vel and pos_out must both be given or both be NULL");
+  if (!vel && !acc_out) return fail(c, NBODY_ERR_INVALID, "direct_step: nothing to compute");
+  if (arith < NBODY_ARITH_AUTO || arith > NBODY_ARITH_EXACT) return fail(c, NBODY_ERR_INVALID, "direct_step: bad arith");
+  if (!ws || ws_bytes < direct_ws_bytes(n_src, n_tgt)) return fail(c, NBODY_ERR_INVALID, "direct_step: workspace too small");
+  // FAST's zero-distance bias needs clamp >= 2^-19; smaller clamps always take EXACT.
+  if (arith != NBODY_ARITH_EXACT && !(clamp >= 1.9073486328125e-06f)) arith = NBODY_ARITH_EXACT;
+
+  DirectConfig cfg = choose_direct_config(n_src, n_tgt);
+  DirectArgs a{};
+  a.pos_all = (const float2*)pos_all;
+  a.mass_all = (const float*)mass_all;
+  a.n_src = (int)n_src;
+  a.tgt_begin = (int)tgt_begin;
+  a.n_tgt = (int)n_tgt;
+  a.vel = (float2*)vel;
+  a.pos_out = (float2*)pos_out;
+  a.acc_out = (float2*)acc_out;
+  a.partial = (float2*)((char*)ws + kFlagBytes);
+  a.delta = delta;
+  a.clamp = clamp;
+  a.uniform_mass = (uniform_mass > 0.f && env_int("NBODY_DIRECT_NO_UNIFORM", 0) == 0) ? uniform_mass : 0.f;
+  int* flag = (int*)ws;
+  if (arith == NBODY_ARITH_AUTO) {
+    HIPCHK(c, launch_hazard_scan(stream, (const float*)pos_all, 2 * n_src, flag));
+    a.gate = flag;
+  }
+  if (arith != NBODY_ARITH_EXACT) {
+    a.run_if = 0;
+    TimerScope ts(timer, stream);
+    HIPCHK(c, launch_direct_fast(stream, a, cfg));
+  }
+  if (arith != NBODY_ARITH_FAST) {
+    a.run_if = 1;
+    TimerScope ts(arith == NBODY_ARITH_EXACT ? timer : nullptr, stream);
+    HIPCHK(c, launch_direct_exact(stream, a));
+  }
+  return NBODY_OK;
+}
+
+int ensure_workspace(nbody_ctx* c, size_t bytes) {
+  if (c->workspace_bytes >= bytes) return NBODY_OK;
+  free_dev(c->workspace);
+  c->workspace_bytes = 0;
+  HIPCHK(c, hipMalloc(&c->workspace, bytes));
+  c->workspace_bytes = bytes;
+  return NBODY_OK;
+}
+
+// -------------------------------------------------------------------------------------------- upload / download
+template <class T> int upload(nbody_ctx* c, int64_t n, const T* pos, const T* vel, const uint32_t* w) {
+  if (!c) return NBODY_ERR_INVALID;
+  if (n < 0 || n > 0x7fffffffLL || (n > 0 && (!pos || !vel))) return fail(c, NBODY_ERR_INVALID, "upload: bad arguments");
+  HIPCHK(c, hipSetDevice(c->device));
+  free_state(c->sf);
+  free_state(c->sd);
+  c->has_f32 = c->has_f64 = false;
+  State<T>& s = state_of<T>(c);
+  using T2 = typename State<T>::T2;
+  s.n = n;
+  const size_t nn = (size_t)(n > 0 ? n : 1);
+  for (auto& st : s.set) {
+    HIPCHK(c, hipMalloc((void**)&st.pos, nn * sizeof(T2)));
+    HIPCHK(c, hipMalloc((void**)&st.vel, nn * sizeof(T2)));
+    HIPCHK(c, hipMalloc((void**)&st.weight, nn * sizeof(uint32_t)));
+    HIPCHK(c, hipMalloc((void**)&st.ids, nn * sizeof(uint32_t)));
+    HIPCHK(c, hipMalloc((void**)&st.mass, nn * sizeof(T)));
+  }
+  HIPCHK(c, hipMalloc((void**)&s.pos_next, nn * sizeof(T2)));
+  HIPCHK(c, hipMalloc((void**)&s.acc, nn * sizeof(T2)));
+  HIPCHK(c, hipMalloc((void**)&s.order_dev, nn * sizeof(uint32_t)));
+  s.cur = 0;
+  s.h_weight.resize((size_t)n);
+  std::vector<uint32_t> ids((size_t)n);
+  std::vector<T> mass((size_t)n);
+  bool uniform = n > 0;
+  for (int64_t i = 0; i < n; ++i) {
+    s.h_weight[(size_t)i] = w ? w[i] : 1u;
+    uniform = uniform && s.h_weight[(size_t)i] == s.h_weight[0];
+    ids[(size_t)i] = (uint32_t)i;
+    mass[(size_t)i] = (T)s.h_weight[(size_t)i];  // `weight as f32`
+  }
+  if (n > 0) {
+    auto& st = s.set[0];
+    HIPCHK(c, hipMemcpyAsync(st.pos, pos, (size_t)n * sizeof(T2), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(st.vel, vel, (size_t)n * sizeof(T2), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(st.weight, s.h_weight.data(), (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(st.ids, ids.data(), (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(st.mass, mass.data(), (size_t)n * sizeof(T), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  s.uniform_mass = (uniform && s.h_weight[0] > 0) ? (float)s.h_weight[0] : 0.f;
+  s.tree_valid = false;
+  if (sizeof(T) == 4) c->has_f32 = true; else c->has_f64 = true;
+  return NBODY_OK;
+}
+
+template <class T> int download(nbody_ctx* c, T* pos, T* vel, uint32_t* w, uint32_t* ids) {
+  if (!c) return NBODY_ERR_INVALID;
+  if (!has_state<T>(c)) return fail(c, NBODY_ERR_INVALID, "download: no particles of this precision uploaded");
+  State<T>& s = state_of<T>(c);
+  using T2 = typename State<T>::T2;
+  HIPCHK(c, hipSetDevice(c->device));
+  auto& st = s.set[s.cur];
+  const size_t n = (size_t)s.n;
+  if (n) {
+    if (pos) HIPCHK(c, hipMemcpyAsync(pos, st.pos, n * sizeof(T2), hipMemcpyDeviceToHost, c->stream));
+    if (vel) HIPCHK(c, hipMemcpyAsync(vel, st.vel, n * sizeof(T2), hipMemcpyDeviceToHost, c->stream));
+    if (w) HIPCHK(c, hipMemcpyAsync(w, st.weight, n * 4, hipMemcpyDeviceToHost, c->stream));
+    if (ids) HIPCHK(c, hipMemcpyAsync(ids, st.ids, n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  return NBODY_OK;
+}
+
+// -------------------------------------------------------------------------------------------- tree phases
+template <class T> int upload_tree(nbody_ctx* c, State<T>& s) {
+  const size_t m = s.tree.size();
+  using G4 = typename TreeHost<T>::G4;
+  using L4 = typename TreeHost<T>::L4;
+  if (m > s.node_cap) {
+    free_dev(s.geom0); free_dev(s.geom1); free_dev(s.link);
+    size_t cap = m + m / 4 + 64;
+    HIPCHK(c, hipMalloc(&s.geom0, cap * sizeof(G4)));
+    HIPCHK(c, hipMalloc(&s.geom1, cap * sizeof(G4)));
+    HIPCHK(c, hipMalloc(&s.link, cap * sizeof(L4)));
+    s.node_cap = cap;
+  }
+  HIPCHK(c, hipMemcpyAsync(s.geom0, s.tree.geom0.data(), m * sizeof(G4), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(s.geom1, s.tree.geom1.data(), m * sizeof(G4), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(s.link, s.tree.link.data(), m * sizeof(L4), hipMemcpyHostToDevice, c->stream));
+  if (s.n) HIPCHK(c, hipMemcpyAsync(s.order_dev, s.tree.order.data(), (size_t)s.n * 4, hipMemcpyHostToDevice, c->stream));
+  return NBODY_OK;
+}
+
+// Phase 1 of update (main.rs:398-401): snapshot + build + upward pass.  After it, for the BVH, set[cur] holds the
+// permuted particles and set[1-cur].pos the pre-build snapshot (`cloned`); for the quad tree set[1-cur].pos/.mass
+// hold the leaf-ordered copies the leaves own.
+template <class T> int tree_build_phase(nbody_ctx* c, State<T>& s, int kind) {
+  using T2 = typename State<T>::T2;
+  if (kind != NBODY_TREE_BVH && kind != NBODY_TREE_QUAD) return fail(c, NBODY_ERR_INVALID, "unknown tree kind");
+  const int64_t n = s.n;
+  s.tree_valid = false;
+  s.h_pos.resize((size_t)(2 * n));
+  if (n) {
+    HIPCHK(c, hipMemcpyAsync(s.h_pos.data(), s.set[s.cur].pos, (size_t)n * sizeof(T2), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  if (kind == NBODY_TREE_BVH) {
+    if (c->params.leaf_size < 1) return fail(c, NBODY_ERR_INVALID, "leaf_size must be >= 1");
+    build_bvh<T>(s.h_pos.data(), s.h_weight.data(), n, c->params.leaf_size, s.tree);
+  } else {
+    build_quad<T>(s.h_pos.data(), s.h_weight.data(), n, (T)c->params.quad_root_x, (T)c->params.quad_root_y,
+                  (T)c->params.quad_root_h, s.tree);
+  }
+  if (s.tree.overflow)
+    return fail(c, NBODY_ERR_DEGENERATE, "tree build exceeded the depth cap (more coincident points than a leaf holds)");
+  int rc = upload_tree(c, s);
+  if (rc) return rc;
+  auto& in = s.set[s.cur];
+  auto& out = s.set[1 - s.cur];
+  GatherArgs<T> g{};
+  g.perm = s.order_dev;
+  g.n = n;
+  g.pos_in = in.pos; g.pos_out = out.pos;
+  g.weight_in = in.weight;
+  g.mass_out = out.mass;
+  if (kind == NBODY_TREE_BVH) {
+    g.vel_in = in.vel; g.vel_out = out.vel;
+    g.weight_out = out.weight;
+    g.ids_in = in.ids; g.ids_out = out.ids;
+    HIPCHK(c, launch_gather<T>(c->stream, g));
+    s.cur = 1 - s.cur;
+    // host mirror of the row order
+    s.h_tmp.resize((size_t)n);
+    for (int64_t i = 0; i < n; ++i) s.h_tmp[(size_t)i] = s.h_weight[s.tree.order[(size_t)i]];
+    s.h_weight.swap(s.h_tmp);
+  } else {
+    HIPCHK(c, launch_gather<T>(c->stream, g));
+  }
+  s.tree_valid = true;
+  return NBODY_OK;
+}
+
+// Phase 2 (main.rs:406-416).  tgt_pos == nullptr: the particles themselves.
+template <class T>
+int tree_walk_phase(nbody_ctx* c, State<T>& s, int kind, const void* tgt_pos, int64_t n_tgt, void* acc) {
+  WalkArgs<T> w{};
+  w.geom0 = s.geom0; w.geom1 = s.geom1; w.link = s.link;
+  w.n_nodes = (int)s.tree.size();
+  w.theta = (T)c->params.theta;
+  w.clamp = (T)c->params.clamp;
+  w.acc = acc;
+  w.stats = c->want_stats ? c->stats_dev : nullptr;
+  if (w.stats) HIPCHK(c, hipMemsetAsync(c->stats_dev, 0, 3 * sizeof(unsigned long long), c->stream));
+  if (kind == NBODY_TREE_BVH) {
+    w.leaf_pos = s.set[s.cur].pos;
+    w.leaf_mass = s.set[s.cur].mass;
+    if (tgt_pos) { w.tgt_pos = tgt_pos; w.n_tgt = n_tgt; }
+    else {
+      // AS_WRITTEN: accelerations are computed for the snapshot's rows (main.rs:406-412 iterate `cloned`)
+      w.tgt_pos = (c->params.order == NBODY_ORDER_AS_WRITTEN) ? s.set[1 - s.cur].pos : s.set[s.cur].pos;
+      w.n_tgt = s.n;
+    }
+  } else {
+    w.leaf_pos = s.set[1 - s.cur].pos;
+    w.leaf_mass = s.set[1 - s.cur].mass;
+    if (tgt_pos) { w.tgt_pos = tgt_pos; w.n_tgt = n_tgt; }
+    else { w.tgt_pos = s.set[s.cur].pos; w.n_tgt = s.n; w.tgt_index = s.order_dev; }
+  }
+  {
+    TimerScope ts(c->timer, c->stream);
+    HIPCHK(c, launch_tree_walk<T>(c->stream, w));
+  }
+  if (w.stats) {
+    HIPCHK(c, hipMemcpyAsync(c->last_stats, c->stats_dev, sizeof(c->last_stats), hipMemcpyDeviceToHost, c->stream));
+  }
+  return NBODY_OK;
+}
+
+template <class T> int update_tree(nbody_ctx* c, int kind, T delta, int n_steps, nbody_counting* counter) {
+  if (!c) return NBODY_ERR_INVALID;
+  if (!has_state<T>(c)) return fail(c, NBODY_ERR_INVALID, "update_tree: no particles of this precision uploaded");
+  if (n_steps < 0) return fail(c, NBODY_ERR_INVALID, "update_tree: n_steps < 0");
+  HIPCHK(c, hipSetDevice(c->device));
+  State<T>& s = state_of<T>(c);
+  for (int step = 0; step < n_steps; ++step) {
+    double t0 = now_s();
+    int rc = tree_build_phase<T>(c, s, kind);
+    if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    double t1 = now_s();
+    rc = tree_walk_phase<T>(c, s, kind, nullptr, 0, s.acc);
+    if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    double t2 = now_s();
+    HIPCHK(c, launch_integrate<T>(c->stream, s.set[s.cur].pos, s.set[s.cur].vel, s.acc, s.n, delta));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    double t3 = now_s();
+    c->counting.build_bvh += t1 - t0;
+    c->counting.sum_gravity += t2 - t1;
+    c->counting.post_calculations += t3 - t2;
+    if (counter) { counter->build_bvh += t1 - t0; counter->sum_gravity += t2 - t1; counter->post_calculations += t3 - t2; }
+  }
+  return NBODY_OK;
+}
+
+template <class T> int accel_tree(nbody_ctx* c, int kind, int64_t n_targets, const T* target_xy, T* acc_xy) {
+  if (!c) return NBODY_ERR_INVALID;
+  if (!has_state<T>(c)) return fail(c, NBODY_ERR_INVALID, "accel_tree: no particles of this precision uploaded");
+  if (!acc_xy) return fail(c, NBODY_ERR_INVALID, "accel_tree: acc_xy is NULL");
+  using T2 = typename State<T>::T2;
+  HIPCHK(c, hipSetDevice(c->device));
+  State<T>& s = state_of<T>(c);
+  int rc = tree_build_phase<T>(c, s, kind);
+  if (rc) return rc;
+  if (!target_xy) {
+    // particles themselves, post-build row order, regardless of params.order
+    WalkArgs<T> dummy{};
+    (void)dummy;
+    const void* tp = s.set[s.cur].pos;
+    int saved = c->params.order;
+    c->params.order = NBODY_ORDER_CONSISTENT;
+    rc = tree_walk_phase<T>(c, s, kind, kind == NBODY_TREE_BVH ? tp : nullptr, s.n, s.acc);
+    c->params.order = saved;
+    if (rc) return rc;
+    if (s.n) HIPCHK(c, hipMemcpyAsync(acc_xy, s.acc, (size_t)s.n * sizeof(T2), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return NBODY_OK;
+  }
+  if (n_targets < 0) return fail(c, NBODY_ERR_INVALID, "accel_tree: n_targets < 0");
+  if (n_targets == 0) return NBODY_OK;
+  T2 *tp = nullptr, *ta = nullptr;
+  HIPCHK(c, hipMalloc((void**)&tp, (size_t)n_targets * sizeof(T2)));
+  hipError_t e = hipMalloc((void**)&ta, (size_t)n_targets * sizeof(T2));
+  if (e != hipSuccess) { (void)hipFree(tp); return fail_hip(c, e, "hipMalloc"); }
+  e = hipMemcpyAsync(tp, target_xy, (size_t)n_targets * sizeof(T2), hipMemcpyHostToDevice, c->stream);
+  rc = (e == hipSuccess) ? tree_walk_phase<T>(c, s, kind, tp, n_targets, ta) : fail_hip(c, e, "hipMemcpyAsync");
+  if (!rc) {
+    e = hipMemcpyAsync(acc_xy, ta, (size_t)n_targets * sizeof(T2), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) rc = fail_hip(c, e, "download acc");
+  }
+  (void)hipStreamSynchronize(c->stream);
+  (void)hipFree(tp);
+  (void)hipFree(ta);
+  return rc;
+}
+
+template <class T>
+void tree_export_host(const TreeHost<T>& t, T* geom, uint32_t* mass, int32_t* is_leaf, int64_t* first, int64_t* count,
+                      int64_t* skip, uint32_t* order) {
+  const size_t m = t.size();
+  for (size_t i = 0; i < m; ++i) {
+    if (geom) {
+      if (t.kind == NBODY_TREE_BVH) {
+        T* g = geom + 6 * i;
+        g[0] = t.geom0[i].a; g[1] = t.geom0[i].b; g[2] = t.size_x[i]; g[3] = t.size_y[i];
+        g[4] = t.geom1[i].a; g[5] = t.geom1[i].b;
+      } else {
+        T* g = geom + 5 * i;
+        g[0] = t.geom0[i].a; g[1] = t.geom0[i].b; g[2] = t.size_x[i]; g[3] = t.geom1[i].a; g[4] = t.geom1[i].b;
+      }
+    }
+    if (mass) mass[i] = t.mass_u32[i];
+    if (is_leaf) is_leaf[i] = t.link[i].is_leaf;
+    if (first) first[i] = t.link[i].first;
+    if (count) count[i] = t.link[i].count;
+    if (skip) skip[i] = t.link[i].skip;
+  }
+  if (order && !t.order.empty()) std::memcpy(order, t.order.data(), t.order.size() * sizeof(uint32_t));
+}
+
+template <class T>
+int tree_export(const nbody_ctx* cc, T* geom, uint32_t* mass, int32_t* is_leaf, int64_t* first, int64_t* count,
+                int64_t* skip, uint32_t* order) {
+  nbody_ctx* c = const_cast<nbody_ctx*>(cc);
+  if (!c) return NBODY_ERR_INVALID;
+  if (!has_state<T>(c)) return fail(c, NBODY_ERR_INVALID, "tree_export: no particles of this precision uploaded");
+  const State<T>& s = state_of<T>(c);
+  if (!s.tree_valid) return fail(c, NBODY_ERR_INVALID, "tree_export: no tree built yet");
+  tree_export_host<T>(s.tree, geom, mass, is_leaf, first, count, skip, order);
+  return NBODY_OK;
+}
+
+}  // namespace
+
+// ================================================================================================ C ABI
+#define NB_API extern "C" __attribute__((visibility("default")))
+
+NB_API int nbody_abi_version(void) { return NBODY_ABI_VERSION; }
+
+NB_API int nbody_default_params(nbody_params* p) {
+  if (!p) return NBODY_ERR_INVALID;
+  p->theta = 50.0f;          // main.rs:35
+  p->clamp = 0.001f;         // main.rs:247-248
+  p->leaf_size = 64;         // bvh_tree.rs:37
+  p->order = NBODY_ORDER_AS_WRITTEN;
+  p->arith = NBODY_ARITH_AUTO;
+  p->quad_root_x = 0.0f;
+  p->quad_root_y = 0.0f;
+  p->quad_root_h = 100000.0f;  // HEIGHT, main.rs:31
+  return NBODY_OK;
+}
+
+NB_API int nbody_create(nbody_ctx** out, int device_id) {
+  if (!out) return fail(nullptr, NBODY_ERR_INVALID, "nbody_create: out is NULL");
+  *out = nullptr;
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0)
+    return fail(nullptr, NBODY_ERR_NO_DEVICE,
+                std::string("nbody_create: no HIP device (") + (e != hipSuccess ? hipGetErrorString(e) : "count 0") +
+                    "); this library has no CPU path");
+  if (device_id < 0 || device_id >= count) return fail(nullptr, NBODY_ERR_INVALID, "nbody_create: device_id out of range");
+  hipDeviceProp_t prop;
+  e = hipGetDeviceProperties(&prop, device_id);
+  if (e != hipSuccess) return fail_hip(nullptr, e, "hipGetDeviceProperties");
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(nullptr, NBODY_ERR_NO_DEVICE, std::string("nbody_create: device is ") + prop.gcnArchName +
+                                                  ", kernels are built for gfx950 (MI355X) only");
+  nbody_ctx* c = new (std::nothrow) nbody_ctx();
+  if (!c) return fail(nullptr, NBODY_ERR_NOMEM, "nbody_create: out of host memory");
+  c->device = device_id;
+  nbody_default_params(&c->params);
+  e = hipSetDevice(device_id);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipMalloc((void**)&c->stats_dev, 3 * sizeof(unsigned long long));
+  if (e != hipSuccess) {
+    int rc = fail_hip(nullptr, e, "nbody_create");
+    delete c;
+    return rc;
+  }
+  *out = c;
+  return NBODY_OK;
+}
+
+NB_API void nbody_destroy(nbody_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  free_state(c->sf);
+  free_state(c->sd);
+  free_dev(c->workspace);
+  free_dev(c->stats_dev);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+NB_API const char* nbody_last_error(const nbody_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+NB_API int nbody_set_params(nbody_ctx* c, const nbody_params* p) {
+  if (!c || !p) return NBODY_ERR_INVALID;
+  if (p->leaf_size < 1) return fail(c, NBODY_ERR_INVALID, "set_params: leaf_size < 1");
+  if (p->order != NBODY_ORDER_AS_WRITTEN && p->order != NBODY_ORDER_CONSISTENT) return fail(c, NBODY_ERR_INVALID, "set_params: bad order");
+  if (p->arith < NBODY_ARITH_AUTO || p->arith > NBODY_ARITH_EXACT) return fail(c, NBODY_ERR_INVALID, "set_params: bad arith");
+  c->params = *p;
+  return NBODY_OK;
+}
+NB_API int nbody_get_params(const nbody_ctx* c, nbody_params* out) {
+  if (!c || !out) return NBODY_ERR_INVALID;
+  *out = c->params;
+  return NBODY_OK;
+}
+
+NB_API int nbody_upload_f32(nbody_ctx* c, int64_t n, const float* pos, const float* vel, const uint32_t* w) {
+  return upload<float>(c, n, pos, vel, w);
+}
+NB_API int nbody_upload_f64(nbody_ctx* c, int64_t n, const double* pos, const double* vel, const uint32_t* w) {
+  return upload<double>(c, n, pos, vel, w);
+}
+NB_API int nbody_download_f32(nbody_ctx* c, float* pos, float* vel, uint32_t* w, uint32_t* ids) {
+  return download<float>(c, pos, vel, w, ids);
+}
+NB_API int nbody_download_f64(nbody_ctx* c, double* pos, double* vel, uint32_t* w, uint32_t* ids) {
+  return download<double>(c, pos, vel, w, ids);
+}
+NB_API int64_t nbody_num_particles(const nbody_ctx* c) {
+  if (!c) return NBODY_ERR_INVALID;
+  return c->has_f32 ? c->sf.n : (c->has_f64 ? c->sd.n : 0);
+}
+
+NB_API int nbody_update_direct_f32(nbody_ctx* c, float delta, int n_steps, nbody_counting* counter) {
+  if (!c) return NBODY_ERR_INVALID;
+  if (!c->has_f32) return fail(c, NBODY_ERR_INVALID, "update_direct_f32: no f32 particles uploaded");
+  if (n_steps < 0) return fail(c, NBODY_ERR_INVALID, "update_direct_f32: n_steps < 0");
+  HIPCHK(c, hipSetDevice(c->device));
+  State<float>& s = c->sf;
+  int rc = ensure_workspace(c, direct_ws_bytes(s.n, s.n));
+  if (rc) return rc;
+  for (int step = 0; step < n_steps; ++step) {
+    double t0 = now_s();
+    auto& st = s.set[s.cur];
+    rc = direct_step_dev(c, c->stream, s.n, st.pos, st.mass, s.uniform_mass, 0, s.n, st.vel, s.pos_next, nullptr, delta,
+                         c->params.clamp, c->params.arith, c->workspace, c->workspace_bytes, c->timer);
+    if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::swap(st.pos, s.pos_next);
+    double t1 = now_s();
+    // force and integrate are one fused kernel: the whole step is booked under sum_gravity
+    c->counting.sum_gravity += t1 - t0;
+    if (counter) counter->sum_gravity += t1 - t0;
+  }
+  s.tree_valid = false;
+  return NBODY_OK;
+}
+
+NB_API int nbody_accel_direct_f32(nbody_ctx* c, float* acc_xy) {
+  if (!c) return NBODY_ERR_INVALID;
+  if (!c->has_f32) return fail(c, NBODY_ERR_INVALID, "accel_direct_f32: no f32 particles uploaded");
+  if (!acc_xy) return fail(c, NBODY_ERR_INVALID, "accel_direct_f32: acc_xy is NULL");
+  HIPCHK(c, hipSetDevice(c->device));
+  State<float>& s = c->sf;
+  int rc = ensure_workspace(c, direct_ws_bytes(s.n, s.n));
+  if (rc) return rc;
+  auto& st = s.set[s.cur];
+  rc = direct_step_dev(c, c->stream, s.n, st.pos, st.mass, s.uniform_mass, 0, s.n, nullptr, nullptr, s.acc, 0.f, c->params.clamp,
+                       c->params.arith, c->workspace, c->workspace_bytes, c->timer);
+  if (rc) return rc;
+  if (s.n) HIPCHK(c, hipMemcpyAsync(acc_xy, s.acc, (size_t)s.n * sizeof(float2), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return NBODY_OK;
+}
+
+NB_API int nbody_update_tree_f32(nbody_ctx* c, int kind, float delta, int n_steps, nbody_counting* counter) {
+  return update_tree<float>(c, kind, delta, n_steps, counter);
+}
+NB_API int nbody_update_tree_f64(nbody_ctx* c, int kind, double delta, int n_steps, nbody_counting* counter) {
+  return update_tree<double>(c, kind, delta, n_steps, counter);
+}
+NB_API int nbody_accel_tree_f32(nbody_ctx* c, int kind, int64_t n_targets, const float* target_xy, float* acc_xy) {
+  return accel_tree<float>(c, kind, n_targets, target_xy, acc_xy);
+}
+NB_API int nbody_accel_tree_f64(nbody_ctx* c, int kind, int64_t n_targets, const double* target_xy, double* acc_xy) {
+  return accel_tree<double>(c, kind, n_targets, target_xy, acc_xy);
+}
+
+NB_API int nbody_tree_info(const nbody_ctx* c, nbody_tree_view* out) {
+  if (!c || !out) return NBODY_ERR_INVALID;
+  nbody_ctx* mc = const_cast<nbody_ctx*>(c);
+  if (c->has_f32 && c->sf.tree_valid) {
+    out->n_nodes = (int64_t)c->sf.tree.size(); out->kind = c->sf.tree.kind; out->max_depth = c->sf.tree.max_depth;
+    return NBODY_OK;
+  }
+  if (c->has_f64 && c->sd.tree_valid) {
+    out->n_nodes = (int64_t)c->sd.tree.size(); out->kind = c->sd.tree.kind; out->max_depth = c->sd.tree.max_depth;
+    return NBODY_OK;
+  }
+  return fail(mc, NBODY_ERR_INVALID, "tree_info: no tree built yet");
+}
+NB_API int nbody_tree_export_f32(const nbody_ctx* c, float* geom, uint32_t* mass, int32_t* is_leaf, int64_t* first,
+                                 int64_t* count, int64_t* skip, uint32_t* order) {
+  return tree_export<float>(c, geom, mass, is_leaf, first, count, skip, order);
+}
+NB_API int nbody_tree_export_f64(const nbody_ctx* c, double* geom, uint32_t* mass, int32_t* is_leaf, int64_t* first,
+                                 int64_t* count, int64_t* skip, uint32_t* order) {
+  return tree_export<double>(c, geom, mass, is_leaf, first, count, skip, order);
+}
+template <class T>
+static int host_tree_build(int kind, int64_t n, const T* pos, const uint32_t* w, const nbody_params* p, nbody_host_tree** out) {
+  if (!out) return fail(nullptr, NBODY_ERR_INVALID, "host_tree_build: out is NULL");
+  *out = nullptr;
+  if (n < 0 || n > 0x7fffffffLL || (n > 0 && !pos)) return fail(nullptr, NBODY_ERR_INVALID, "host_tree_build: bad arguments");
+  nbody_params dflt;
+  nbody_default_params(&dflt);
+  if (!p) p = &dflt;
+  if (p->leaf_size < 1) return fail(nullptr, NBODY_ERR_INVALID, "host_tree_build: leaf_size < 1");
+  auto* h = new (std::nothrow) nbody_host_tree();
+  if (!h) return fail(nullptr, NBODY_ERR_NOMEM, "host_tree_build: out of memory");
+  TreeHost<T>* t;
+  if constexpr (sizeof(T) == 8) { h->is_f64 = true; t = &h->td; } else { t = &h->tf; }
+  if (kind == NBODY_TREE_BVH) build_bvh<T>(pos, w, n, p->leaf_size, *t);
+  else if (kind == NBODY_TREE_QUAD) build_quad<T>(pos, w, n, (T)p->quad_root_x, (T)p->quad_root_y, (T)p->quad_root_h, *t);
+  else { delete h; return fail(nullptr, NBODY_ERR_INVALID, "host_tree_build: unknown tree kind"); }
+  *out = h;
+  return t->overflow ? NBODY_ERR_DEGENERATE : NBODY_OK;
+}
+
+NB_API int nbody_host_tree_build_f32(int kind, int64_t n, const float* pos_xy, const uint32_t* weight,
+                                     const nbody_params* p, nbody_host_tree** out) {
+  return host_tree_build<float>(kind, n, pos_xy, weight, p, out);
+}
+NB_API int nbody_host_tree_build_f64(int kind, int64_t n, const double* pos_xy, const uint32_t* weight,
+                                     const nbody_params* p, nbody_host_tree** out) {
+  return host_tree_build<double>(kind, n, pos_xy, weight, p, out);
+}
+NB_API void nbody_host_tree_free(nbody_host_tree* t) { delete t; }
+NB_API int nbody_host_tree_info(const nbody_host_tree* t, nbody_tree_view* out) {
+  if (!t || !out) return NBODY_ERR_INVALID;
+  if (t->is_f64) { out->n_nodes = (int64_t)t->td.size(); out->kind = t->td.kind; out->max_depth = t->td.max_depth; }
+  else { out->n_nodes = (int64_t)t->tf.size(); out->kind = t->tf.kind; out->max_depth = t->tf.max_depth; }
+  return NBODY_OK;
+}
+NB_API int nbody_host_tree_export_f32(const nbody_host_tree* t, float* geom, uint32_t* mass, int32_t* is_leaf,
+                                      int64_t* first, int64_t* count, int64_t* skip, uint32_t* order) {
+  if (!t || t->is_f64) return fail(nullptr, NBODY_ERR_INVALID, "host_tree_export_f32: not an f32 tree");
+  tree_export_host<float>(t->tf, geom, mass, is_leaf, first, count, skip, order);
+  return NBODY_OK;
+}
+NB_API int nbody_host_tree_export_f64(const nbody_host_tree* t, double* geom, uint32_t* mass, int32_t* is_leaf,
+                                      int64_t* first, int64_t* count, int64_t* skip, uint32_t* order) {
+  if (!t || !t->is_f64) return fail(nullptr, NBODY_ERR_INVALID, "host_tree_export_f64: not an f64 tree");
+  tree_export_host<double>(t->td, geom, mass, is_leaf, first, count, skip, order);
+  return NBODY_OK;
+}
+
+NB_API int nbody_tree_walk_stats(nbody_ctx* c, int enable, uint64_t* node_visits, uint64_t* accepted, uint64_t* leaf_pairs) {
+  if (!c) return NBODY_ERR_INVALID;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (node_visits) *node_visits = c->last_stats[0];
+  if (accepted) *accepted = c->last_stats[1];
+  if (leaf_pairs) *leaf_pairs = c->last_stats[2];
+  c->want_stats = enable != 0;
+  return NBODY_OK;
+}
+
+NB_API int nbody_get_counting(const nbody_ctx* c, nbody_counting* out) {
+  if (!c || !out) return NBODY_ERR_INVALID;
+  *out = c->counting;
+  return NBODY_OK;
+}
+
+NB_API size_t nbody_direct_workspace_bytes(int64_t n_sources, int64_t n_targets) {
+  if (n_sources < 0 || n_targets < 0) return 0;
+  return direct_ws_bytes(n_sources, n_targets);
+}
+
+NB_API int nbody_direct_step_dev(void* stream, int64_t n_sources, const void* pos_all, const void* mass_all,
+                                 float uniform_mass, int64_t target_begin, int64_t n_targets, void* vel, void* pos_out, void* acc_out,
+                                 float delta, float clamp, int arith, void* workspace, size_t workspace_bytes,
+                                 nbody_timer* timer) {
+  return direct_step_dev(nullptr, (hipStream_t)stream, n_sources, pos_all, mass_all, uniform_mass, target_begin, n_targets, vel,
+                         pos_out, acc_out, delta, clamp, arith, workspace, workspace_bytes, timer);
+}
+
+NB_API int nbody_weights_to_mass_dev(void* stream, int64_t n, const void* weight_u32, void* mass_f32) {
+  if (n < 0 || (n > 0 && (!weight_u32 || !mass_f32))) return fail(nullptr, NBODY_ERR_INVALID, "weights_to_mass: bad arguments");
+  hipError_t e = launch_weights_to_mass((hipStream_t)stream, (const uint32_t*)weight_u32, (float*)mass_f32, n);
+  return e == hipSuccess ? NBODY_OK : fail_hip(nullptr, e, "weights_to_mass");
+}
+
+NB_API int nbody_timer_create(nbody_timer** out) {
+  if (!out) return NBODY_ERR_INVALID;
+  *out = new (std::nothrow) nbody_timer();
+  return *out ? NBODY_OK : NBODY_ERR_NOMEM;
+}
+NB_API void nbody_timer_destroy(nbody_timer* t) { delete t; }
+NB_API int nbody_timer_read(nbody_timer* t, int reset, double* avg_ms, int64_t* launches) {
+  if (!t) return NBODY_ERR_INVALID;
+  hipError_t e = t->drain();
+  if (e != hipSuccess) return fail_hip(nullptr, e, "timer drain");
+  if (avg_ms) *avg_ms = t->launches ? t->total_ms / (double)t->launches : 0.0;
+  if (launches) *launches = t->launches;
+  if (reset) { t->total_ms = 0.0; t->launches = 0; }
+  return NBODY_OK;
+}
+NB_API int nbody_set_timer(nbody_ctx* c, nbody_timer* t) {
+  if (!c) return NBODY_ERR_INVALID;
+  c->timer = t;
+  return NBODY_OK;
+}

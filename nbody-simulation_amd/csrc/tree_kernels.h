@@ -1,0 +1,37 @@
+// Launch interface of the tree kernels (tree_kernels.hip).  Internal to the library.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace nbody {
+
+template <class T> struct WalkArgs {
+  const void* geom0;      // T4[n_nodes]  lo.x lo.y hi.x hi.y
+  const void* geom1;      // T4[n_nodes]  cog.x cog.y mass s2
+  const void* link;       // int4[n_nodes] skip first count is_leaf
+  int n_nodes;
+  const void* leaf_pos;   // T2[n] tree-ordered particle positions
+  const T* leaf_mass;     // T[n]  tree-ordered masses
+  const void* tgt_pos;    // T2[*] target positions
+  const uint32_t* tgt_index;  // optional: thread t handles row tgt_index[t]
+  int64_t n_tgt;
+  void* acc;              // T2[*] indexed like tgt_pos
+  T theta, clamp;
+  unsigned long long* stats;  // optional [3]: node visits, accepted nodes, leaf pairs
+};
+
+template <class T> struct GatherArgs {
+  const uint32_t* perm;
+  int64_t n;
+  const void* pos_in; void* pos_out;
+  const void* vel_in; void* vel_out;
+  const uint32_t* weight_in; uint32_t* weight_out;
+  const uint32_t* ids_in; uint32_t* ids_out;
+  T* mass_out;
+};
+
+template <class T> hipError_t launch_tree_walk(hipStream_t s, const WalkArgs<T>& a);
+template <class T> hipError_t launch_gather(hipStream_t s, const GatherArgs<T>& a);
+template <class T> hipError_t launch_integrate(hipStream_t s, void* pos, void* vel, const void* acc, int64_t n, T delta);
+
+}  // namespace nbody

@@ -1,0 +1,161 @@
+// Barnes-Hut walk over a linearised (pre-order, skip-linked) BVH or quad tree, plus the gather and integrate
+// kernels of a tree step.  gfx950, wave64.  Compiled with -ffp-contract=off: every operation is the one the
+// reference writes, so a target's sum is bit-identical to the CPU recursion (same DFS order, same IEEE ops).
+//
+//   walk      World::bvh_sum_gravity            /root/reference src/main.rs:348-386
+//   pair      calculate_gravity                 src/main.rs:234-253
+//   integrate the Euler loop of World::update   src/main.rs:419-423
+//
+// The recursion "children[0] then children[1]" becomes a stackless pre-order scan: descending is i+1, leaving a
+// subtree (leaf done, or node accepted) is link.skip.  No per-thread stack is needed at all.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "tree_kernels.h"
+
+namespace nbody {
+
+template <class T> struct V2;
+template <> struct V2<float> { using type = float2; };
+template <> struct V2<double> { using type = double2; };
+template <class T> struct V4;
+template <> struct V4<float> { using type = float4; };
+template <> struct V4<double> { using type = double4; };
+
+template <class T> __device__ __forceinline__ bool is_normal_t(T v) { return __builtin_isnormal(v); }
+
+template <class T>
+__device__ __forceinline__ void pair_as_written(T px, T py, T qx, T qy, T force, T clamp, T& ax, T& ay) {
+  T dx = qx - px;                                        // main.rs:236
+  T dy = qy - py;
+  T sum = __builtin_fabs(dx) + __builtin_fabs(dy);       // :238
+  if (!is_normal_t(sum)) return;                         // :241-243
+  T distance = dx * dx + dy * dy;                        // :245
+  if (distance < clamp) distance = clamp;                // :247-249
+  T den = sum * distance;
+  ax = ax + (dx * force) / den;                          // :252
+  ay = ay + (dy * force) / den;
+}
+template <>
+__device__ __forceinline__ void pair_as_written<float>(float px, float py, float qx, float qy, float force,
+                                                       float clamp, float& ax, float& ay) {
+  float dx = qx - px;
+  float dy = qy - py;
+  float sum = __builtin_fabsf(dx) + __builtin_fabsf(dy);
+  if (!__builtin_isnormal(sum)) return;
+  float distance = dx * dx + dy * dy;
+  if (distance < clamp) distance = clamp;
+  float den = sum * distance;
+  ax = ax + (dx * force) / den;
+  ay = ay + (dy * force) / den;
+}
+
+// One thread per target.  tgt_index (optional) maps thread t to the target's row: targets are visited in tree
+// order so the lanes of a wave share most of their path, and results are scattered back to acc[row].
+template <class T>
+__global__ __launch_bounds__(256) void tree_walk(const WalkArgs<T> a) {
+  using T2 = typename V2<T>::type;
+  using T4 = typename V4<T>::type;
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= a.n_tgt) return;
+  const int64_t row = a.tgt_index ? (int64_t)a.tgt_index[t] : t;
+  const T2 p = reinterpret_cast<const T2*>(a.tgt_pos)[row];
+  const T4* __restrict__ g0 = reinterpret_cast<const T4*>(a.geom0);
+  const T4* __restrict__ g1 = reinterpret_cast<const T4*>(a.geom1);
+  const int4* __restrict__ lk = reinterpret_cast<const int4*>(a.link);
+  const T2* __restrict__ lpos = reinterpret_cast<const T2*>(a.leaf_pos);
+  const T* __restrict__ lmass = a.leaf_mass;
+  const T theta = a.theta, clamp = a.clamp;
+  T ax = 0, ay = 0;
+  unsigned long long visits = 0, accepted = 0, leaf_pairs = 0;
+  int i = 0;
+  const int n_nodes = a.n_nodes;
+  while (i < n_nodes) {
+    const int4 l = lk[i];
+    if (a.stats) visits++;
+    if (l.w) {  // Leaf arm, main.rs:351-363: every particle of the slice, in slice order
+      for (int k = l.y; k < l.y + l.z; ++k) {
+        const T2 q = lpos[k];
+        pair_as_written<T>(p.x, p.y, q.x, q.y, lmass[k], clamp, ax, ay);
+      }
+      if (a.stats) leaf_pairs += (unsigned long long)l.z;
+      i = l.x;
+      continue;
+    }
+    const T4 b = g0[i];  // lo.x lo.y hi.x hi.y
+    const T4 c = g1[i];  // cog.x cog.y mass s2
+    const bool contains = p.y > b.y && p.x > b.x && p.x < b.z && p.y < b.w;  // bvh_tree.rs:15-20 (all strict)
+    const T ddx = p.x - c.x, ddy = p.y - c.y;                                  // dist2(p, cog), main.rs:228-232
+    const T d2 = ddx * ddx + ddy * ddy;
+    if (!contains && c.w < d2 * theta * theta) {                               // main.rs:370-372
+      pair_as_written<T>(p.x, p.y, c.x, c.y, c.z, clamp, ax, ay);              // :374-379
+      if (a.stats) accepted++;
+      i = l.x;
+    } else {
+      i = i + 1;                                                               // :381-382
+    }
+  }
+  reinterpret_cast<T2*>(a.acc)[row] = T2{ax, ay};
+  if (a.stats) {
+    atomicAdd(&a.stats[0], visits);
+    atomicAdd(&a.stats[1], accepted);
+    atomicAdd(&a.stats[2], leaf_pairs);
+  }
+}
+
+// out[i] = in[perm[i]] for the particle arrays (the device-side image of the in-place partition permutation).
+template <class T>
+__global__ __launch_bounds__(256) void gather_particles(const GatherArgs<T> a) {
+  using T2 = typename V2<T>::type;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.n) return;
+  const int64_t s = (int64_t)a.perm[i];
+  if (a.pos_out) reinterpret_cast<T2*>(a.pos_out)[i] = reinterpret_cast<const T2*>(a.pos_in)[s];
+  if (a.vel_out) reinterpret_cast<T2*>(a.vel_out)[i] = reinterpret_cast<const T2*>(a.vel_in)[s];
+  if (a.weight_out) a.weight_out[i] = a.weight_in[s];
+  if (a.ids_out) a.ids_out[i] = a.ids_in[s];
+  if (a.mass_out) a.mass_out[i] = (T)a.weight_in[s];  // `weight as f32`, main.rs:360
+}
+
+// main.rs:419-423: v += a*dt ; x += v*dt, multiply then add, in place.
+template <class T>
+__global__ __launch_bounds__(256) void integrate_inplace(void* pos, void* vel, const void* acc, int64_t n, T delta) {
+  using T2 = typename V2<T>::type;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  T2 v = reinterpret_cast<T2*>(vel)[i];
+  T2 p = reinterpret_cast<T2*>(pos)[i];
+  const T2 ac = reinterpret_cast<const T2*>(acc)[i];
+  v.x = v.x + ac.x * delta;
+  v.y = v.y + ac.y * delta;
+  const T vx = v.x * delta, vy = v.y * delta;
+  p.x = p.x + vx;
+  p.y = p.y + vy;
+  reinterpret_cast<T2*>(vel)[i] = v;
+  reinterpret_cast<T2*>(pos)[i] = p;
+}
+
+template <class T> hipError_t launch_tree_walk(hipStream_t s, const WalkArgs<T>& a) {
+  if (a.n_tgt <= 0) return hipSuccess;
+  hipLaunchKernelGGL((tree_walk<T>), dim3((unsigned)((a.n_tgt + 255) / 256)), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+template <class T> hipError_t launch_gather(hipStream_t s, const GatherArgs<T>& a) {
+  if (a.n <= 0) return hipSuccess;
+  hipLaunchKernelGGL((gather_particles<T>), dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+template <class T> hipError_t launch_integrate(hipStream_t s, void* pos, void* vel, const void* acc, int64_t n, T delta) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL((integrate_inplace<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, pos, vel, acc, n, delta);
+  return hipGetLastError();
+}
+
+template hipError_t launch_tree_walk<float>(hipStream_t, const WalkArgs<float>&);
+template hipError_t launch_tree_walk<double>(hipStream_t, const WalkArgs<double>&);
+template hipError_t launch_gather<float>(hipStream_t, const GatherArgs<float>&);
+template hipError_t launch_gather<double>(hipStream_t, const GatherArgs<double>&);
+template hipError_t launch_integrate<float>(hipStream_t, void*, void*, const void*, int64_t, float);
+template hipError_t launch_integrate<double>(hipStream_t, void*, void*, const void*, int64_t, double);
+
+}  // namespace nbody

@@ -1,0 +1,56 @@
+"""Host-side mirror of the reference's step interface, above the C ABI.
+
+Reference (Rust, /root/reference src/main.rs):
+    struct World { particles: Vec<Particle> }                       :37-39
+    struct Counting { build_bvh, sum_gravity, post_calculations }   :74-79
+    impl World { fn update(&mut self, delta: f32, counter: &mut Counting) }   :388-425
+    called once per simulation step as `world.update(STEP_SIZE, &mut counter)`  :120
+
+Same names and argument meaning here; the particle arrays live on the GPU between calls and are read back
+with `particles()`.  `method` selects what the force phase is: "bvh" is the reference's own path, "quad" the
+quad_tree.rs tree (dead code upstream), "direct" the O(N^2) sum (theta = 0 limit).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _capi
+from ._capi import Counting  # noqa: F401  (re-exported: the reference's struct name)
+
+STEP_SIZE = 0.1   # main.rs:34
+THETA = 50.0      # main.rs:35
+HEIGHT = 100_000  # main.rs:31
+
+_METHODS = {"bvh": _capi.TREE_BVH, "quad": _capi.TREE_QUAD, "direct": None}
+
+
+class World:
+    def __init__(self, position, velocity, weight=None, *, method="bvh", device=0, theta=THETA, clamp=0.001,
+                 leaf_size=64, order="as_written", arith="auto", quad_root=(0.0, 0.0, float(HEIGHT))):
+        if method not in _METHODS:
+            raise ValueError(f"method must be one of {sorted(_METHODS)}")
+        self.method = method
+        self.ctx = _capi.Context(device)
+        self.ctx.set_params(theta=float(theta), clamp=float(clamp), leaf_size=int(leaf_size),
+                            order={"as_written": _capi.ORDER_AS_WRITTEN, "consistent": _capi.ORDER_CONSISTENT}[order],
+                            arith={"auto": _capi.ARITH_AUTO, "fast": _capi.ARITH_FAST, "exact": _capi.ARITH_EXACT}[arith],
+                            quad_root_x=float(quad_root[0]), quad_root_y=float(quad_root[1]),
+                            quad_root_h=float(quad_root[2]))
+        self.ctx.upload(position, velocity, weight)
+        if method == "direct" and self.ctx.dtype != np.float32:
+            raise ValueError("the direct path is f32 (the reference's precision)")
+
+    def update(self, delta: float, counter: Counting | None = None, n_steps: int = 1):
+        """World::update (main.rs:388-425): build, force, integrate; accumulates phase seconds into `counter`."""
+        if self.method == "direct":
+            self.ctx.update_direct(delta, n_steps, counter)
+        else:
+            self.ctx.update_tree(_METHODS[self.method], delta, n_steps, counter)
+
+    def particles(self):
+        """-> (position[n,2], velocity[n,2], weight[n], ids[n]); rows are in the order the reference's
+        `self.particles` would be in (permuted by every BVH build); ids give each row's original index."""
+        return self.ctx.download()
+
+    def close(self):
+        self.ctx.close()

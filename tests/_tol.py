@@ -1,0 +1,42 @@
+"""Tolerance of the FAST direct kernel against the oracle (stated once, used by every parity test).
+
+FAST replaces the reference's two IEEE divisions per pair by one v_rcp_f32 (1 ulp) and two multiplies, fuses
+dx*dx + dy*dy and the accumulation into FMAs, and sums the sources in 4 x gsplit partial chains instead of one.
+Each term carries a relative error of a few ulp (<= ~4 * 2^-24); the dominant error of BOTH the GPU and the
+reference is f32 summation: once a near neighbour has put a large term into the accumulator, every later
+addition rounds at that magnitude.  Measured on MI355X at N = 65 536 (tests/test_gpu_direct.py::test_config2):
+the reference's own single sequential f32 chain deviates from the exactly accumulated sum by up to 5.9e-4 of
+sum_j |term_j|, the GPU's shorter chains by up to 7.7e-5 (median 2e-7, 99th percentile 1.8e-6).
+
+With  a_ref64 = every term evaluated in f32 exactly as main.rs:252 writes it, accumulated in double,
+      a_cpu32 = the reference order: the same terms accumulated sequentially in f32 (ascending j),
+      norm(i) = sum_j | term_ij |_1,
+the checks are, per test:
+      p99_i  | a_gpu(i) - a_ref64(i) |_1 / norm(i)   <=  ACC_RTOL                       (typical accuracy)
+      max_i  | a_gpu(i) - a_ref64(i) |_1 / norm(i)   <=  max(ACC_RTOL, max_i | a_cpu32(i) - a_ref64(i) |_1 / norm(i))
+i.e. every target is within 2e-5, or else the GPU is still at least as close to the exact sum as the reference's
+own summation order is.  EXACT arithmetic is not subject to any tolerance: it is bit-identical.
+"""
+import numpy as np
+
+ACC_RTOL = 2e-5          # SURVEY §8d starting value
+TRAJ_ATOL_POS = 1e-3     # N=1024, 100 steps, box 1e5: max |x_gpu - x_oracle| (absolute)
+
+
+def fast_error(acc, ref64, norm):
+    err = np.abs(np.asarray(acc, np.float64) - ref64).sum(axis=1)
+    return err / np.maximum(norm, 1e-300)
+
+
+def check_fast(acc, ref64, norm, cpu32=None):
+    """Asserts the two inequalities above; returns (max ratio gpu, max ratio cpu32 or None)."""
+    r = fast_error(acc, ref64, norm)
+    assert np.all(np.isfinite(r)), "non-finite acceleration"
+    assert np.percentile(r, 99) <= ACC_RTOL, f"p99 {np.percentile(r, 99):.3e}"
+    rc = None
+    cap = ACC_RTOL
+    if cpu32 is not None:
+        rc = float(fast_error(cpu32, ref64, norm).max())
+        cap = max(cap, rc)
+    assert r.max() <= cap, f"max {r.max():.3e} > cap {cap:.3e}"
+    return float(r.max()), rc

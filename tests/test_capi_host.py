@@ -1,0 +1,116 @@
+"""CPU-side checks of the product: the C-ABI library loads, exports every declared symbol, refuses to run without
+a device, and its host-side tree builders reproduce the oracle's trees bit for bit.  No GPU, no compute calls."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+
+def test_library_exports_every_declared_symbol(nb):
+    C = nb._capi
+    lib = ctypes.CDLL(C.LIB_PATH)
+    declared = C.declared_symbols()
+    assert len(declared) >= 30
+    missing = [s for s in declared if not hasattr(lib, s)]
+    assert not missing, missing
+    # and the ctypes table binds exactly the declared set
+    assert sorted(C._SIGS) == declared
+
+
+def test_abi_version_and_defaults(nb):
+    C = nb._capi
+    assert C.load().nbody_abi_version() == 1
+    p = C.default_params()
+    # the reference's constants: THETA main.rs:35, clamp :247, TARGET_POINTS bvh_tree.rs:37, HEIGHT main.rs:31
+    assert (p.theta, p.leaf_size, p.quad_root_h) == (50.0, 64, 100000.0)
+    assert p.clamp == np.float32(0.001)
+    assert p.order == C.ORDER_AS_WRITTEN and p.arith == C.ARITH_AUTO
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="only meaningful without a GPU")
+def test_no_cpu_fallback(nb):
+    with pytest.raises(nb._capi.NBodyError) as e:
+        nb._capi.Context(0)
+    assert e.value.code == nb._capi.ERR_NO_DEVICE
+    assert "no CPU path" in str(e.value)
+
+
+def test_workspace_size_is_monotone_and_small(nb):
+    C = nb._capi
+    a = C.direct_workspace_bytes(1 << 20, 1 << 20)
+    b = C.direct_workspace_bytes(1 << 20, 1 << 17)
+    assert 256 <= a <= 64 << 20 and 256 <= b <= 64 << 20
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("n,leaf", [(0, 64), (1, 64), (40, 64), (64, 64), (65, 64), (1024, 64), (777, 16), (50000, 64)])
+def test_host_bvh_matches_oracle_bit_exact(nb, orc, dtype, n, leaf):
+    """Tree node indexing bit-exact: the product's iterative pre-order builder vs the oracle's recursive
+    restatement of bvh_tree.rs:56-158."""
+    C = nb._capi
+    pos, _, _ = nb.scenes.plummer(n, seed=31)
+    pos = pos.astype(dtype)
+    w = (np.arange(n) % 9 + 1).astype(np.uint32)
+    prm = C.default_params()
+    prm.leaf_size = leaf
+    t = C.host_tree(C.TREE_BVH, pos, w, prm)
+    o = orc.BVH(pos, w, leaf_size=leaf).flat()
+    assert not t["overflow"] and not o.overflow
+    for k in ("mass", "is_leaf", "first", "count", "skip"):
+        assert np.array_equal(t[k], getattr(o, k)), k
+    assert np.array_equal(t["geom"], o.geom, equal_nan=True)
+    assert np.array_equal(t["order"], o.ids)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("n", [0, 1, 8, 9, 100, 1024, 50000])
+def test_host_quad_matches_oracle_bit_exact(nb, orc, dtype, n):
+    """The product builds the quad tree top-down with a stable 4-way split; the oracle inserts point by point as
+    quad_tree.rs:153-227 does.  Cells, child codes, leaf orders, masses and centres of gravity must be identical."""
+    C = nb._capi
+    pos, _, _ = nb.scenes.plummer(n, seed=32)
+    pos = pos.astype(dtype)
+    w = (np.arange(n) % 4 + 1).astype(np.uint32)
+    t = C.host_tree(C.TREE_QUAD, pos, w)
+    o = orc.Quad(pos, w).flat()
+    for k in ("geom", "mass", "is_leaf", "first", "count", "skip", "order"):
+        assert np.array_equal(t[k], getattr(o, k)), k
+
+
+def test_host_trees_mixed_masses_and_heavy_bodies(nb, orc):
+    """The reference's own scene has masses 1, 750 000 and 75 000 000 (main.rs:282-291)."""
+    C = nb._capi
+    pos, _, w = nb.scenes.galaxy()
+    pos, w = pos[:30000], w[:30000]
+    t = C.host_tree(C.TREE_BVH, pos, w)
+    o = orc.BVH(pos, w).flat()
+    assert np.array_equal(t["geom"], o.geom) and np.array_equal(t["mass"], o.mass) and np.array_equal(t["order"], o.ids)
+    assert t["mass"][0] == (int(w.astype(np.uint64).sum()) & 0xFFFFFFFF)
+
+
+def test_host_tree_degenerate_inputs_report_not_hang(nb):
+    C = nb._capi
+    pos = np.tile(np.array([[5.0, 5.0]], np.float32), (100, 1))
+    assert C.host_tree(C.TREE_BVH, pos)["overflow"]
+    assert C.host_tree(C.TREE_QUAD, pos)["overflow"]
+    # > 8 points beyond the same corner of the root cell can never be separated either (no bounds check upstream)
+    far = np.tile(np.array([[2e5, 2e5]], np.float32), (9, 1)) + np.arange(9, dtype=np.float32)[:, None]
+    assert C.host_tree(C.TREE_QUAD, far)["overflow"]
+    # 64 coincident points still fit one BVH leaf; 8 fit one quad leaf
+    assert not C.host_tree(C.TREE_BVH, pos[:64])["overflow"]
+    assert not C.host_tree(C.TREE_QUAD, pos[:8])["overflow"]
+
+
+def test_host_quad_points_outside_root_cell(nb, orc):
+    """insert() has no bounds check (quad_tree.rs:153-207): outside points go to edge cells by comparison only."""
+    C = nb._capi
+    rng = np.random.default_rng(5)
+    inside = (rng.random((500, 2)) * 1e5).astype(np.float32)
+    outside = np.array([[-5e4, 2e4], [1.7e5, 3e4], [4e4, -1e3], [5e4, 2.5e5], [-1.0, -1.0], [1e5 + 1, 1e5 + 1]], np.float32)
+    pos = np.concatenate([inside[:250], outside, inside[250:]])
+    t = C.host_tree(C.TREE_QUAD, pos)
+    o = orc.Quad(pos).flat()
+    assert not t["overflow"] and not o.overflow
+    for k in ("geom", "mass", "is_leaf", "first", "count", "skip", "order"):
+        assert np.array_equal(t[k], getattr(o, k)), k

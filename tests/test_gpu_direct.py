@@ -1,0 +1,222 @@
+"""Parity of the direct O(N^2) HIP path (through the C ABI) against the CPU oracle.  Needs an MI355X."""
+import numpy as np
+import pytest
+
+from tests._tol import TRAJ_ATOL_POS, check_fast
+
+pytestmark = pytest.mark.gpu
+F32 = np.float32
+
+
+@pytest.fixture(scope="module")
+def ctx(nb):
+    c = nb._capi.Context(0)
+    yield c
+    c.close()
+
+
+def _refs(orc, pos, w, targets=None, nthreads=16):
+    ref64, norm = orc.direct_accel(pos, w, targets=targets, accum="f64", nthreads=nthreads)
+    cpu32, _ = orc.direct_accel(pos, w, targets=targets, nthreads=nthreads)
+    return ref64, norm, cpu32
+
+
+# ------------------------------------------------------------------ EXACT arithmetic: bit-identical
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 257, 1000, 4096])
+def test_exact_accel_bit_identical_to_oracle(nb, orc, ctx, n):
+    pos, vel, _ = nb.scenes.plummer(n, seed=41)
+    w = (np.arange(n) % 11 + 1).astype(np.uint32)
+    ctx.set_params(arith=nb._capi.ARITH_EXACT)
+    ctx.upload(pos, vel, w)
+    acc = ctx.accel_direct()
+    ref, _ = orc.direct_accel(pos, w, nthreads=8)
+    assert np.array_equal(acc, ref.astype(F32))
+
+
+def test_exact_update_bit_identical_over_steps(nb, orc, ctx):
+    pos, vel, w = nb.scenes.plummer(1024, seed=42)
+    ctx.set_params(arith=nb._capi.ARITH_EXACT)
+    ctx.upload(pos, vel, w)
+    ctx.update_direct(0.1, 10)
+    p, v, w2, ids = ctx.download()
+    rp, rv, _ = orc.update_direct(pos, vel, w, delta=0.1, nsteps=10, nthreads=8)
+    assert np.array_equal(p, rp) and np.array_equal(v, rv)
+    assert np.array_equal(ids, np.arange(1024)) and np.array_equal(w2, w)
+
+
+def test_exact_skip_semantics_edge_cases(nb, orc, ctx):
+    """main.rs:241-243: zero, subnormal, inf and NaN sums leave the accumulator untouched; the smallest normal sum
+    does not.  Checked on the device in EXACT arithmetic, bit for bit."""
+    tiny = np.finfo(F32).tiny
+    pos = np.array([[0, 0], [0, 0],                    # coincident pair
+                    [1e-39, 0], [0, -1e-40],           # subnormal separations from the origin
+                    [tiny, 0],                         # smallest normal separation
+                    [np.inf, 1], [np.nan, 2],          # non-finite
+                    [3e38, 3e38], [-3e38, -3e38],      # finite, but |dx|+|dy| overflows
+                    [3, 4], [0.01, 0.0], [100, -50]], F32)
+    vel = np.zeros_like(pos)
+    w = np.array([2, 3, 1, 1, 1, 5, 5, 7, 7, 2, 1, 750000], np.uint32)
+    ctx.set_params(arith=nb._capi.ARITH_EXACT)
+    ctx.upload(pos, vel, w)
+    acc = ctx.accel_direct()
+    ref, _ = orc.direct_accel(pos, w)
+    assert np.array_equal(acc, ref.astype(F32), equal_nan=True)
+    assert np.all(np.isfinite(acc[[0, 1, 2, 3, 4, 9, 10, 11]]))
+
+
+def test_auto_switches_to_exact_on_hazardous_positions(nb, orc, ctx):
+    """AUTO = FAST unless a coordinate is non-finite, >= 2^60, or non-zero below 2^-22; then EXACT (bit-exact)."""
+    pos, vel, w = nb.scenes.plummer(2048, seed=43)
+    for poison in (np.nan, np.inf, 2.0 ** 61, 1e-30, -1e-12):
+        p = pos.copy()
+        p[777, 1] = poison
+        ctx.set_params(arith=nb._capi.ARITH_AUTO)
+        ctx.upload(p, vel, w)
+        acc = ctx.accel_direct()
+        ref, _ = orc.direct_accel(p, w, nthreads=8)
+        assert np.array_equal(acc, ref.astype(F32), equal_nan=True), poison
+    # zero coordinates are not hazardous (differences are then 0 or >= 2^-46)
+    p = pos.copy()
+    p[5] = (0.0, 0.0)
+    p[6] = (0.0, 123.0)
+    ctx.upload(p, vel, w)
+    acc = ctx.accel_direct()
+    ref64, norm, cpu32 = _refs(orc, p, w)
+    check_fast(acc, ref64, norm, cpu32)
+    assert not np.array_equal(acc, cpu32.astype(F32))  # i.e. FAST really ran
+
+
+def test_tiny_clamp_forces_exact(nb, orc, ctx):
+    pos, vel, w = nb.scenes.plummer(512, seed=44)
+    ctx.set_params(arith=nb._capi.ARITH_FAST, clamp=1e-9)
+    ctx.upload(pos, vel, w)
+    acc = ctx.accel_direct()
+    ref, _ = orc.direct_accel(pos, w, clamp=1e-9)
+    assert np.array_equal(acc, ref.astype(F32))
+    ctx.set_params(clamp=0.001)
+
+
+# ------------------------------------------------------------------ FAST arithmetic: stated tolerance
+@pytest.mark.parametrize("n", [1, 7, 64, 100, 1000, 4097, 20000])
+def test_fast_accel_within_tolerance(nb, orc, ctx, n):
+    pos, vel, _ = nb.scenes.plummer(n, seed=45)
+    w = (np.arange(n) % 5 + 1).astype(np.uint32)
+    ctx.set_params(arith=nb._capi.ARITH_FAST)
+    ctx.upload(pos, vel, w)
+    acc = ctx.accel_direct()
+    check_fast(acc, *_refs(orc, pos, w))
+
+
+def test_fast_coincident_and_clamped_pairs(nb, orc, ctx):
+    """Coincident bodies contribute exactly nothing (the 2^-90 bias keeps 0 * rcp finite) and near pairs hit the
+    0.001 clamp, in FAST arithmetic."""
+    pos, vel, w = nb.scenes.plummer(3000, seed=46)
+    pos[100] = pos[200]                       # exact duplicate
+    pos[300] = pos[400] + F32(0.0078125)      # d^2 = 6.1e-5 < 0.001
+    w = (np.arange(3000) % 3 + 1).astype(np.uint32)
+    ctx.set_params(arith=nb._capi.ARITH_FAST)
+    ctx.upload(pos, vel, w)
+    acc = ctx.accel_direct()
+    assert np.all(np.isfinite(acc))
+    check_fast(acc, *_refs(orc, pos, w))
+
+
+def test_fast_mixed_masses_reference_scene(nb, orc, ctx):
+    """Masses 1 / 750 000 / 75 000 000 as in World::new (main.rs:282-291)."""
+    pos, vel, w = nb.scenes.galaxy()
+    pos, vel, w = pos[:20000], vel[:20000], w[:20000]
+    ctx.set_params(arith=nb._capi.ARITH_AUTO)
+    ctx.upload(pos, vel, w)
+    acc = ctx.accel_direct()
+    check_fast(acc, *_refs(orc, pos, w))
+
+
+def test_config2_65536_all_targets(nb, orc, ctx):
+    """BASELINE config 2: 65 536 bodies direct f32, every target compared with the CPU oracle."""
+    n = 65536
+    pos, vel, w = nb.scenes.plummer(n, seed=0x5EED0002)
+    ctx.set_params(arith=nb._capi.ARITH_AUTO)
+    ctx.upload(pos, vel, w)
+    acc = ctx.accel_direct()
+    rg, rc = check_fast(acc, *_refs(orc, pos, w))
+    # the f32 sequential reference order is itself further from the exactly accumulated sum than the GPU is
+    print(f"max err/norm: gpu {rg:.3e}, cpu f32 sequential {rc:.3e}")
+    assert rg <= rc
+
+
+def test_config3_1M_sampled_targets_and_properties(nb, orc, ctx):
+    """BASELINE config 3: 1 048 576 bodies; 4 096 sampled targets against the oracle, plus size-independent
+    properties of one full step: determinism, and total momentum change = sum of m*a*dt (equal masses here)."""
+    n = 1 << 20
+    pos, vel, w = nb.scenes.plummer(n, seed=0x5EED0003)
+    ctx.set_params(arith=nb._capi.ARITH_AUTO)
+    ctx.upload(pos, vel, w)
+    acc = ctx.accel_direct()
+    tg = np.arange(0, n, 256)
+    rg, rc = check_fast(acc[tg], *_refs(orc, pos, w, targets=tg))
+    print(f"1M sampled: max err/norm gpu {rg:.3e}, cpu f32 sequential {rc:.3e}")
+    acc2 = ctx.accel_direct()
+    assert np.array_equal(acc, acc2)                      # bitwise deterministic
+    # Newton's third law holds for this force law too (term_ij = -term_ji up to rounding): net force ~ 0
+    net = np.abs(acc.astype(np.float64).sum(axis=0))
+    assert np.all(net <= 1e-4 * np.abs(acc.astype(np.float64)).sum(axis=0))
+    ctx.update_direct(0.1, 1)
+    p1, v1, _, _ = ctx.download()
+    dt = F32(0.1)
+    v_exp = vel + acc * dt
+    assert np.array_equal(v1, v_exp)                      # integrate is the reference's mul-then-add, bit exact
+    assert np.array_equal(p1, pos + v_exp * dt)
+
+
+def test_fast_trajectory_1024x100(nb, orc, ctx):
+    pos, vel, w = nb.scenes.plummer(1024, seed=0x5EED0001)
+    ctx.set_params(arith=nb._capi.ARITH_FAST)
+    ctx.upload(pos, vel, w)
+    ctx.update_direct(0.1, 100)
+    p, v, _, _ = ctx.download()
+    rp, rv, _ = orc.update_direct(pos, vel, w, delta=0.1, nsteps=100, nthreads=8)
+    assert np.abs(p.astype(np.float64) - rp).max() <= TRAJ_ATOL_POS
+
+
+def test_direct_counter_and_timer(nb, ctx):
+    C = nb._capi
+    pos, vel, w = nb.scenes.plummer(8192, seed=47)
+    ctx.set_params(arith=C.ARITH_FAST)
+    ctx.upload(pos, vel, w)
+    t = C.Timer()
+    ctx.set_timer(t)
+    cnt = C.Counting()
+    ctx.update_direct(0.1, 3, cnt)
+    ms, launches = t.read()
+    ctx.set_timer(None)
+    assert launches == 3 and ms > 0
+    assert cnt.sum_gravity > 0 and cnt.build_bvh == 0
+
+
+def test_device_level_sharded_targets_equal_whole(nb, ctx):
+    """nbody_direct_step_dev on two target shards == one call over all targets (the multi-GPU decomposition)."""
+    import torch
+    C = nb._capi
+    n = 6000
+    pos, vel, w = nb.scenes.plummer(n, seed=48)
+    dev = torch.device("cuda:0")
+    tp = torch.from_numpy(pos).to(dev)
+    tm = torch.from_numpy(w.astype(np.float32)).to(dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def run(begin, cnt):
+        ws_bytes = C.direct_workspace_bytes(n, cnt)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        v = torch.from_numpy(vel[begin:begin + cnt].copy()).to(dev)
+        out = torch.empty((cnt, 2), dtype=torch.float32, device=dev)
+        acc = torch.empty((cnt, 2), dtype=torch.float32, device=dev)
+        C.direct_step_dev(stream, n, tp.data_ptr(), tm.data_ptr(), begin, cnt, v.data_ptr(), out.data_ptr(),
+                          acc.data_ptr(), 0.1, 0.001, C.ARITH_EXACT, ws.data_ptr(), ws_bytes)
+        torch.cuda.synchronize()
+        return out.cpu().numpy(), v.cpu().numpy(), acc.cpu().numpy()
+
+    whole = run(0, n)
+    a = run(0, 2500)
+    b = run(2500, n - 2500)
+    for k in range(3):
+        assert np.array_equal(np.concatenate([a[k], b[k]]), whole[k])

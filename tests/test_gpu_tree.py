@@ -1,0 +1,142 @@
+"""Parity of the Barnes-Hut HIP path (host build + device walk) against the CPU oracle.  Needs an MI355X.
+
+The walk uses the reference's operations in the reference's DFS order, so everything here is bit-exact."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+F32 = np.float32
+
+
+@pytest.fixture(scope="module")
+def ctx(nb):
+    c = nb._capi.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("n,theta", [(40, 50.0), (1024, 50.0), (1024, 0.5), (5000, 0.5), (5000, 0.0), (30000, 1.0)])
+def test_bvh_walk_bit_exact(nb, orc, ctx, dtype, n, theta):
+    C = nb._capi
+    pos, vel, _ = nb.scenes.plummer(n, seed=51)
+    pos, vel = pos.astype(dtype), vel.astype(dtype)
+    w = (np.arange(n) % 6 + 1).astype(np.uint32)
+    ctx.set_params(theta=theta, leaf_size=64)
+    ctx.upload(pos, vel, w)
+    # arbitrary targets (the snapshot positions, in upload order)
+    acc = ctx.accel_tree(C.TREE_BVH, pos)
+    bvh = orc.BVH(pos, w)
+    ref = bvh.walk(pos, theta=theta, nthreads=8)
+    assert np.array_equal(acc, ref)
+    # tree exported by the library == oracle tree; rows were permuted as BVHTree::from permutes self.particles
+    t, o = ctx.tree_export(), bvh.flat()
+    for k in ("mass", "is_leaf", "first", "count", "skip"):
+        assert np.array_equal(t[k], getattr(o, k)), k
+    assert np.array_equal(t["geom"], o.geom, equal_nan=True)
+    p, v, w2, ids = ctx.download()
+    assert np.array_equal(ids, o.ids) and np.array_equal(p, o.pos_perm) and np.array_equal(w2, w[o.ids])
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("n,theta", [(5, 0.5), (1024, 0.5), (6000, 0.5), (6000, 0.0), (20000, 50.0)])
+def test_quad_walk_bit_exact(nb, orc, ctx, dtype, n, theta):
+    C = nb._capi
+    pos, vel, _ = nb.scenes.plummer(n, seed=52)
+    pos, vel = pos.astype(dtype), vel.astype(dtype)
+    w = (np.arange(n) % 3 + 1).astype(np.uint32)
+    ctx.set_params(theta=theta)
+    ctx.upload(pos, vel, w)
+    acc = ctx.accel_tree(C.TREE_QUAD)          # the particles themselves
+    ref = orc.Quad(pos, w).walk(pos, theta=theta, nthreads=8)
+    assert np.array_equal(acc, ref)
+    acc2 = ctx.accel_tree(C.TREE_QUAD, pos[::7])
+    assert np.array_equal(acc2, ref[::7])
+    p, _, _, ids = ctx.download()
+    assert np.array_equal(ids, np.arange(n)) and np.array_equal(p, pos)   # the quad build does not permute rows
+
+
+@pytest.mark.parametrize("order", ["as_written", "consistent"])
+@pytest.mark.parametrize("theta", [50.0, 0.5])
+def test_update_bvh_trajectory_bit_exact(nb, orc, order, theta):
+    """World::update over 20 steps, both application orders, against the restatement."""
+    pos, vel, w = nb.scenes.plummer(1024, seed=0x5EED0001)
+    world = nb.World(pos, vel, w, method="bvh", theta=theta, order=order)
+    cnt = nb.Counting()
+    for _ in range(20):
+        world.update(0.1, cnt)
+    p, v, w2, ids = world.particles()
+    world.close()
+    mode = orc.AS_WRITTEN if order == "as_written" else orc.CONSISTENT
+    rp, rv, rw, rids, _ = orc.update_bvh(pos, vel, w, delta=0.1, theta=theta, mode=mode, nsteps=20, nthreads=8)
+    assert np.array_equal(ids, rids)
+    assert np.array_equal(p, rp) and np.array_equal(v, rv) and np.array_equal(w2, rw)
+    assert cnt.build_bvh > 0 and cnt.sum_gravity > 0 and cnt.post_calculations > 0
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_update_quad_trajectory_bit_exact(nb, orc, dtype):
+    pos, vel, w = nb.scenes.plummer(1024, seed=0x5EED0001)
+    pos, vel = pos.astype(dtype), vel.astype(dtype)
+    world = nb.World(pos, vel, w, method="quad", theta=0.5)
+    world.update(0.1, None, n_steps=20)
+    p, v, _, ids = world.particles()
+    world.close()
+    rp, rv, _ = orc.update_quad(pos, vel, w, delta=0.1, theta=0.5, nsteps=20, nthreads=8)
+    assert np.array_equal(p, rp) and np.array_equal(v, rv)
+
+
+def test_update_bvh_f64(nb, orc):
+    pos, vel, w = nb.scenes.plummer(4096, seed=53, dtype=np.float64)
+    world = nb.World(pos, vel, w, method="bvh", theta=0.5, order="consistent")
+    world.update(0.1, None, n_steps=5)
+    p, v, _, ids = world.particles()
+    world.close()
+    rp, rv, _, rids, _ = orc.update_bvh(pos, vel, w, delta=0.1, theta=0.5, mode=orc.CONSISTENT, nsteps=5, nthreads=8)
+    assert np.array_equal(ids, rids) and np.array_equal(p, rp) and np.array_equal(v, rv)
+
+
+def test_walk_statistics_match_oracle_counts(nb, orc, ctx):
+    """Node visits / accepted nodes / leaf pairs (the algorithmic-bytes basis of the walk's roofline)."""
+    C = nb._capi
+    n = 20000
+    pos, vel, w = nb.scenes.plummer(n, seed=54)
+    ctx.set_params(theta=0.5)
+    ctx.upload(pos, vel, w)
+    ctx.walk_stats(True)
+    ctx.accel_tree(C.TREE_BVH, pos[:3000])
+    got = ctx.walk_stats(False)
+    _, st = orc.BVH(pos, w).walk(pos[:3000], theta=0.5, stats=True)
+    assert tuple(int(x) for x in st) == got
+
+
+def test_degenerate_input_is_an_error_not_a_hang(nb, ctx):
+    C = nb._capi
+    pos = np.tile(np.array([[5.0, 5.0]], F32), (200, 1))
+    ctx.upload(pos, np.zeros_like(pos), None)
+    with pytest.raises(C.NBodyError) as e:
+        ctx.update_tree(C.TREE_BVH, 0.1, 1)
+    assert e.value.code == C.ERR_DEGENERATE
+
+
+def test_config4_4M_quad_f64_sampled(nb, orc):
+    """BASELINE config 4: 4 194 304 bodies, Barnes-Hut theta = 0.5 over the linearised quad tree, f64.
+    Sampled targets are compared bit for bit with the CPU restatement; one full step runs on the device."""
+    C = nb._capi
+    n = 1 << 22
+    pos, vel, w = nb.scenes.plummer(n, seed=0x5EED0004, dtype=np.float64)
+    c = C.Context(0)
+    try:
+        c.set_params(theta=0.5)
+        c.upload(pos, vel, w)
+        tg = pos[::1024]
+        acc = c.accel_tree(C.TREE_QUAD, tg)
+        ref = orc.Quad(pos, w).walk(tg, theta=0.5, nthreads=16)
+        assert np.array_equal(acc, ref)
+        cnt = C.Counting()
+        c.update_tree(C.TREE_QUAD, 0.1, 1, cnt)
+        p, v, _, _ = c.download()
+        assert np.all(np.isfinite(p)) and np.all(np.isfinite(v))
+        print(f"4M quad f64 step: build {cnt.build_bvh:.3f}s walk {cnt.sum_gravity:.3f}s integrate {cnt.post_calculations:.4f}s")
+    finally:
+        c.close()
