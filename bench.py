@@ -45,6 +45,12 @@ def cpu_baseline(pos, w, n_sample_targets):
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
+    try:  # a container's CPU share (cgroup v2 quota), when there is one
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            cores = max(1, min(cores, int(float(q) / float(per) + 0.5)))
+    except Exception:
+        pass
     n = pos.shape[0]
     tg = np.arange(0, n, n // n_sample_targets)[:n_sample_targets]
     orc.direct_accel(pos[:4096], w[:4096], targets=np.arange(64), nthreads=cores, native_lib=native)  # warm

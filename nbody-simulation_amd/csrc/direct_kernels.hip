@@ -98,6 +98,7 @@ __global__ __launch_bounds__(256) void direct_fast(const DirectArgs a) {
   constexpr int TGT_PER_BLOCK = GROUPS * TGT_PER_GROUP;
   constexpr int TILE = 1024;  // sources per LDS tile
   constexpr int UNR = 8;
+  constexpr int BLK = 256;    // inner block of the two-level summation (SGPR flavour)
 
   const int lane = threadIdx.x & 63;
   const int wave = wave_id_uniform();
@@ -130,24 +131,36 @@ __global__ __launch_bounds__(256) void direct_fast(const DirectArgs a) {
     const float2* __restrict__ ps = a.pos_all;
     const float* __restrict__ ms = a.mass_all;
     int j = j0;
-    for (; j + UNR <= j1; j += UNR) {
-      float2 p[UNR];
-      float m[UNR];
+    while (j < j1) {
+      // two-level summation: a block of BLK sources is summed on its own, then added to the running total
+      const int jb = (j + BLK < j1) ? j + BLK : j1;
+      float bx[TPT], by[TPT];
 #pragma unroll
-      for (int u = 0; u < UNR; ++u) {
-        p[u] = ps[j + u];
-        m[u] = UNIFORM ? 1.0f : ms[j + u];
+      for (int k = 0; k < TPT; ++k) bx[k] = by[k] = 0.f;
+      for (; j + UNR <= jb; j += UNR) {
+        float2 p[UNR];
+        float m[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+          p[u] = ps[j + u];
+          m[u] = UNIFORM ? 1.0f : ms[j + u];
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u)
+#pragma unroll
+          for (int k = 0; k < TPT; ++k) fast_pair<UNIFORM>(xi[k], yi[k], p[u].x, p[u].y, m[u], clamp, bx[k], by[k]);
+      }
+      for (; j < jb; ++j) {
+        float2 p = ps[j];
+        float m = UNIFORM ? 1.0f : ms[j];
+#pragma unroll
+        for (int k = 0; k < TPT; ++k) fast_pair<UNIFORM>(xi[k], yi[k], p.x, p.y, m, clamp, bx[k], by[k]);
       }
 #pragma unroll
-      for (int u = 0; u < UNR; ++u)
-#pragma unroll
-        for (int k = 0; k < TPT; ++k) fast_pair<UNIFORM>(xi[k], yi[k], p[u].x, p[u].y, m[u], clamp, ax[k], ay[k]);
-    }
-    for (; j < j1; ++j) {
-      float2 p = ps[j];
-      float m = UNIFORM ? 1.0f : ms[j];
-#pragma unroll
-      for (int k = 0; k < TPT; ++k) fast_pair<UNIFORM>(xi[k], yi[k], p.x, p.y, m, clamp, ax[k], ay[k]);
+      for (int k = 0; k < TPT; ++k) {
+        ax[k] += bx[k];
+        ay[k] += by[k];
+      }
     }
   } else {
     __shared__ __attribute__((aligned(16))) float2 tile_pos[TILE];
@@ -180,6 +193,10 @@ __global__ __launch_bounds__(256) void direct_fast(const DirectArgs a) {
       int hi = lo + SHARE;
       if (UNIFORM && hi > cnt) hi = cnt > lo ? cnt : lo;   // no zero-mass trick without masses: stop at cnt
       int u = lo;
+      // two-level summation: this wave's share of the tile is summed on its own, then added to the total
+      float bx[TPT], by[TPT];
+#pragma unroll
+      for (int k = 0; k < TPT; ++k) bx[k] = by[k] = 0.f;
       for (; u + UNR <= hi; u += UNR) {
         float4 pp[UNR / 2];
         float2 mm[UNR / 2];
@@ -193,15 +210,20 @@ __global__ __launch_bounds__(256) void direct_fast(const DirectArgs a) {
         for (int h = 0; h < UNR / 2; ++h)
 #pragma unroll
           for (int k = 0; k < TPT; ++k) {
-            fast_pair<UNIFORM>(xi[k], yi[k], pp[h].x, pp[h].y, mm[h].x, clamp, ax[k], ay[k]);
-            fast_pair<UNIFORM>(xi[k], yi[k], pp[h].z, pp[h].w, mm[h].y, clamp, ax[k], ay[k]);
+            fast_pair<UNIFORM>(xi[k], yi[k], pp[h].x, pp[h].y, mm[h].x, clamp, bx[k], by[k]);
+            fast_pair<UNIFORM>(xi[k], yi[k], pp[h].z, pp[h].w, mm[h].y, clamp, bx[k], by[k]);
           }
       }
       for (; u < hi; ++u) {
         float2 p = tile_pos[u];
         float m = UNIFORM ? 1.0f : tile_mass[u];
 #pragma unroll
-        for (int k = 0; k < TPT; ++k) fast_pair<UNIFORM>(xi[k], yi[k], p.x, p.y, m, clamp, ax[k], ay[k]);
+        for (int k = 0; k < TPT; ++k) fast_pair<UNIFORM>(xi[k], yi[k], p.x, p.y, m, clamp, bx[k], by[k]);
+      }
+#pragma unroll
+      for (int k = 0; k < TPT; ++k) {
+        ax[k] += bx[k];
+        ay[k] += by[k];
       }
       __syncthreads();
     }

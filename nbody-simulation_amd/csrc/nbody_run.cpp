@@ -1,0 +1,81 @@
+// Headless driver: the reference's scene (World::new, /root/reference src/main.rs:276-346, with a seeded
+// generator: the reference's own is unseeded) stepped through the C ABI, printing the reference's once-a-second
+// block (ups / step / Counting, main.rs:149-156).  The window, renderer and channel of the reference are out of scope.
+//   nbody_run [steps=100] [bvh|quad|direct] [seed]
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "world.hpp"
+
+using namespace nbody_host;
+
+static uint64_t splitmix64(uint64_t& s) {
+  uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+static float uni(uint64_t& s) { return (float)((splitmix64(s) >> 40) * (1.0 / 16777216.0)); }
+
+static std::vector<Particle> scene(uint64_t seed) {
+  const float TAU = 6.28318530717958647692f;
+  std::vector<Particle> p;
+  const Vec2 c1{35000.f, 35000.f}, c2{60000.f, 60000.f};
+  const float c1lenr2 = 15000000.f;
+  p.push_back({c1, {200.f, 250.f}, 75000000u});                       // main.rs:282-286
+  p.push_back({c2, {0.f, 0.f}, 750000u});                             // :287-291
+  const int m = 100000 / 14 - 1;                                      // :316
+  for (int x = 0; x < m; ++x)
+    for (int y = 0; y < m; ++y) {
+      Vec2 pos{x * 14.f, y * 14.f};
+      float dx = pos.x - c2.x, dy = pos.y - c2.y, d2 = dx * dx + dy * dy;
+      if (d2 < c1lenr2 && d2 > 500000.f && uni(seed) * ((c1lenr2 - d2) + 1.0f) > 6000000.f) {   // :319-321
+        float sc = std::sqrt(std::sqrt(750000.f) / d2);               // :323-324
+        p.push_back({pos, {dy * sc, -dx * sc}, 1u});                  // rotate_right :271-273
+      }
+    }
+  for (int i = 0; i < 100000; ++i) {                                  // :334, rand_body :260-269
+    float th = uni(seed) * TAU, r = uni(seed);
+    float tv = uni(seed) * TAU, rv = uni(seed);
+    p.push_back({{std::cos(th) * r * 25000.f + 50000.f, std::sin(th) * r * 25000.f + 50000.f},
+                 {std::cos(tv) * rv, std::sin(tv) * rv}, 1u});
+  }
+  return p;
+}
+
+int main(int argc, char** argv) {
+  int steps = argc > 1 ? std::atoi(argv[1]) : 100;
+  Method method = Method::Bvh;
+  if (argc > 2 && !std::strcmp(argv[2], "quad")) method = Method::Quad;
+  if (argc > 2 && !std::strcmp(argv[2], "direct")) method = Method::Direct;
+  uint64_t seed = argc > 3 ? std::strtoull(argv[3], nullptr, 0) : 0xC0FFEEull;
+  try {
+    World world(scene(seed), method);
+    std::printf("len: %zu\n", world.particles.size());                // main.rs:343
+    Counting counter{};
+    auto t0 = std::chrono::steady_clock::now();
+    long updates = 0, last = 0;
+    for (int s = 0; s < steps; ++s) {
+      world.update(0.1f, counter);                                    // main.rs:120 (STEP_SIZE)
+      ++updates;
+      auto now = std::chrono::steady_clock::now();
+      if (std::chrono::duration<double>(now - t0).count() >= 1.0 || s + 1 == steps) {
+        std::printf("ups: %ld\nstep: %ld\nCounting { build_bvh: %.6f, sum_gravity: %.6f, post_calculations: %.6f }\n",
+                    updates - last, updates, counter.build_bvh, counter.sum_gravity, counter.post_calculations);
+        last = updates;
+        t0 = now;
+      }
+    }
+    const auto& ps = world.snapshot();
+    double cx = 0, cy = 0;
+    for (auto& q : ps) { cx += q.position.x; cy += q.position.y; }
+    std::printf("centroid after %d steps: (%.3f, %.3f)\n", steps, cx / ps.size(), cy / ps.size());
+  } catch (const std::exception& e) {
+    std::fprintf(stderr, "nbody_run: %s\n", e.what());
+    return 1;
+  }
+  return 0;
+}

@@ -71,7 +71,13 @@ class ShardedDirectStepper:
             self.pos_all, self.out_shard = self.out_shard, self.pos_all
         else:
             import torch.distributed as dist
-            dist.all_gather_into_tensor(self.pos_next.view(-1), self.out_shard.view(-1), group=self.group)
+            if self.device.type == "cuda" and dist.get_backend(self.group) == "gloo":
+                # rehearsal mode (several ranks sharing one GPU, no RCCL between them): stage through the host
+                host = self.torch.empty((self.n, 2), dtype=self.torch.float32)
+                dist.all_gather_into_tensor(host.view(-1), self.out_shard.cpu().view(-1), group=self.group)
+                self.pos_next.copy_(host)
+            else:
+                dist.all_gather_into_tensor(self.pos_next.view(-1), self.out_shard.view(-1), group=self.group)
             self.pos_all, self.pos_next = self.pos_next, self.pos_all
 
     def local_state(self):

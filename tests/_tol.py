@@ -11,11 +11,11 @@ sum_j |term_j|, the GPU's shorter chains by up to 7.7e-5 (median 2e-7, 99th perc
 With  a_ref64 = every term evaluated in f32 exactly as main.rs:252 writes it, accumulated in double,
       a_cpu32 = the reference order: the same terms accumulated sequentially in f32 (ascending j),
       norm(i) = sum_j | term_ij |_1,
-the checks are, per test:
-      p99_i  | a_gpu(i) - a_ref64(i) |_1 / norm(i)   <=  ACC_RTOL                       (typical accuracy)
-      max_i  | a_gpu(i) - a_ref64(i) |_1 / norm(i)   <=  max(ACC_RTOL, max_i | a_cpu32(i) - a_ref64(i) |_1 / norm(i))
-i.e. every target is within 2e-5, or else the GPU is still at least as close to the exact sum as the reference's
-own summation order is.  EXACT arithmetic is not subject to any tolerance: it is bit-identical.
+and e_gpu(i) = | a_gpu(i) - a_ref64(i) |_1 / norm(i), e_cpu(i) likewise for a_cpu32, the checks are, per test:
+      p99_i e_gpu(i)  <=  max(ACC_RTOL, p99_i e_cpu(i))
+      max_i e_gpu(i)  <=  max(ACC_RTOL, max_i e_cpu(i))
+i.e. the GPU is within 2e-5 of the exactly accumulated sum, or else it is still at least as close to it as the
+reference's own summation order is.  EXACT arithmetic is not subject to any tolerance: it is bit-identical.
 """
 import numpy as np
 
@@ -28,15 +28,18 @@ def fast_error(acc, ref64, norm):
     return err / np.maximum(norm, 1e-300)
 
 
-def check_fast(acc, ref64, norm, cpu32=None):
-    """Asserts the two inequalities above; returns (max ratio gpu, max ratio cpu32 or None)."""
+def check_fast(acc, ref64, norm, cpu32=None, label=""):
+    """Asserts the two inequalities above; returns (max e_gpu, max e_cpu or None)."""
     r = fast_error(acc, ref64, norm)
     assert np.all(np.isfinite(r)), "non-finite acceleration"
-    assert np.percentile(r, 99) <= ACC_RTOL, f"p99 {np.percentile(r, 99):.3e}"
+    cap99 = capmax = ACC_RTOL
     rc = None
-    cap = ACC_RTOL
     if cpu32 is not None:
-        rc = float(fast_error(cpu32, ref64, norm).max())
-        cap = max(cap, rc)
-    assert r.max() <= cap, f"max {r.max():.3e} > cap {cap:.3e}"
+        c = fast_error(cpu32, ref64, norm)
+        rc = float(c.max())
+        cap99, capmax = max(cap99, float(np.percentile(c, 99))), max(capmax, rc)
+        print(f"[tol]{label} n_tgt={len(r)} e_gpu: median {np.median(r):.2e} p99 {np.percentile(r, 99):.2e} max {r.max():.2e}"
+              f" | e_cpu32: median {np.median(c):.2e} p99 {np.percentile(c, 99):.2e} max {rc:.2e}")
+    assert np.percentile(r, 99) <= cap99, f"p99 {np.percentile(r, 99):.3e} > {cap99:.3e}"
+    assert r.max() <= capmax, f"max {r.max():.3e} > cap {capmax:.3e}"
     return float(r.max()), rc
