@@ -94,12 +94,38 @@ def declared_symbols() -> list:
     return sorted(set(re.findall(r"\b(nbody_[a-z0-9_]+)\s*\(", txt)))
 
 
+def _share_hip_runtime_with_torch():
+    """PyTorch-ROCm wheels bundle their own libamdhip64 and load it by absolute path.  Two HIP runtimes in one
+    process do not coexist (whichever comes second sees no GPU), so when PyTorch is installed its copy is loaded
+    first and libnbody_hip's DT_NEEDED libamdhip64 resolves to it by SONAME.  Without PyTorch the system ROCm
+    runtime is used, as for any C/Rust host."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except Exception:
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    for d in spec.submodule_search_locations:
+        cand = os.path.join(d, "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            try:
+                C.CDLL(cand, mode=C.RTLD_GLOBAL)
+            except OSError:
+                pass
+            return
+
+
 def load() -> C.CDLL:
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise NBodyError(ERR_NO_DEVICE, f"{LIB_PATH} is not built (run __graft_entry__.build() or "
                                             f"`make -C nbody-simulation_amd/csrc`); there is no CPU fallback")
+        _share_hip_runtime_with_torch()
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGS.items():
             fn = getattr(lib, name)

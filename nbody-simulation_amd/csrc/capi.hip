@@ -166,11 +166,14 @@ int env_int(const char* name, int dflt) {
 }
 
 // How the direct kernel covers (n_tgt x n_src): enough waves to fill 256 CUs x 4 SIMDs x 8 waves.
-DirectConfig choose_direct_config(int64_t n_src, int64_t n_tgt) {
+DirectConfig choose_direct_config(int64_t n_src, int64_t n_tgt, bool uniform = true) {
   (void)n_src;
   DirectConfig c;
   c.use_lds = env_int("NBODY_DIRECT_LDS", 1) != 0;  // measured: LDS tile beats SGPR broadcast
-  c.tpt = env_int("NBODY_DIRECT_TPT", 1);
+  c.use_asm = env_int("NBODY_DIRECT_ASM", 1) != 0;
+  // measured at N = 1M (profiles/r01_direct_variant_sweep_*.txt): equal masses -> 1 target/thread with the
+  // hand-ordered block; per-body masses -> 2 targets/thread, compiler-scheduled
+  c.tpt = env_int("NBODY_DIRECT_TPT", uniform ? 1 : 2);
   if (c.tpt != 1 && c.tpt != 2 && c.tpt != 4) c.tpt = 1;
   const int64_t want_waves = 8192;
   int64_t groups = (n_tgt + 64 * c.tpt - 1) / (64 * c.tpt);
@@ -193,8 +196,12 @@ DirectConfig choose_direct_config(int64_t n_src, int64_t n_tgt) {
 constexpr size_t kFlagBytes = 256;
 
 size_t direct_ws_bytes(int64_t n_src, int64_t n_tgt) {
-  DirectConfig c = choose_direct_config(n_src, n_tgt);
-  size_t partial = c.gsplit > 1 ? (size_t)c.gsplit * (size_t)n_tgt * sizeof(float2) : 0;
+  size_t partial = 0;
+  for (bool uni : {false, true}) {
+    DirectConfig c = choose_direct_config(n_src, n_tgt, uni);
+    size_t p = c.gsplit > 1 ? (size_t)c.gsplit * (size_t)n_tgt * sizeof(float2) : 0;
+    if (p > partial) partial = p;
+  }
   return kFlagBytes + ((partial + 255) & ~(size_t)255);
 }
 
@@ -213,7 +220,8 @@ int direct_step_dev(nbody_ctx* c, hipStream_t stream, int64_t n_src, const void*
   // FAST's zero-distance bias needs clamp >= 2^-19; smaller clamps always take EXACT.
   if (arith != NBODY_ARITH_EXACT && !(clamp >= 1.9073486328125e-06f)) arith = NBODY_ARITH_EXACT;
 
-  DirectConfig cfg = choose_direct_config(n_src, n_tgt);
+  const bool uni = uniform_mass > 0.f && env_int("NBODY_DIRECT_NO_UNIFORM", 0) == 0;
+  DirectConfig cfg = choose_direct_config(n_src, n_tgt, uni);
   DirectArgs a{};
   a.pos_all = (const float2*)pos_all;
   a.mass_all = (const float*)mass_all;
@@ -226,7 +234,7 @@ int direct_step_dev(nbody_ctx* c, hipStream_t stream, int64_t n_src, const void*
   a.partial = (float2*)((char*)ws + kFlagBytes);
   a.delta = delta;
   a.clamp = clamp;
-  a.uniform_mass = (uniform_mass > 0.f && env_int("NBODY_DIRECT_NO_UNIFORM", 0) == 0) ? uniform_mass : 0.f;
+  a.uniform_mass = uni ? uniform_mass : 0.f;
   int* flag = (int*)ws;
   if (arith == NBODY_ARITH_AUTO) {
     HIPCHK(c, launch_hazard_scan(stream, (const float*)pos_all, 2 * n_src, flag));

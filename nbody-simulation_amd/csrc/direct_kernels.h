@@ -27,6 +27,7 @@ struct DirectConfig {
   int wsplit = 1;     // waves of a block sharing one target group and splitting the sources: 1 or 4
   int gsplit = 1;     // source split over blockIdx.y (partials + direct_finish)
   bool use_lds = false;
+  bool use_asm = true;  // hand-ordered 8-pair block (LDS flavour, tpt 1)
 };
 
 hipError_t launch_direct_fast(hipStream_t s, const DirectArgs& a, const DirectConfig& c);

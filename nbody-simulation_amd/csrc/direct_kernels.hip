@@ -61,6 +61,54 @@ __device__ __forceinline__ void exact_pair(float xi, float yi, float xj, float y
   ay = ay + (dy * mj) / den;
 }
 
+// Eight FAST pairs for one target as one hand-ordered instruction block.  Same operations as fast_pair, but
+// issued in phases (8 x v_pk_add | the 32-bit ops, v_max interleaved with v_add | 8 x v_rcp | 8 x v_pk_fma): on
+// gfx950 changing between the packed, transcendental and plain VALU classes costs issue cycles
+// (tools/mb/switch_bench) and hipcc's interleaved schedule of the same 64 instructions runs 7 % slower
+// (tools/mb/body_bench: 37.7 vs 34.9 cycles per pair).  p0..p7 come in as source positions and leave as the
+// differences.  Temporaries live in v40..v55: pair k = v[40+2k : 41+2k] = (s_k, d2_k), so that the pk_fma can
+// broadcast s_k with op_sel_hi.  0x12800000 = 2^-90 (kDenBias).  VALU->VALU dependencies are interlocked by
+// the hardware; every v_rcp result is consumed >= 8 instructions later (trans forwarding hazard needs 1).
+template <bool UNIFORM>
+__device__ __forceinline__ void fast_block8(float2 t, float clamp, float2& p0, float2& p1, float2& p2, float2& p3,
+                                            float2& p4, float2& p5, float2& p6, float2& p7, float m0, float m1,
+                                            float m2, float m3, float m4, float m5, float m6, float m7, float2& acc) {
+  asm volatile(
+      "v_pk_add_f32 %[p0], %[p0], %[t] neg_lo:[0,1] neg_hi:[0,1]\n\tv_pk_add_f32 %[p1], %[p1], %[t] neg_lo:[0,1] neg_hi:[0,1]\n\tv_pk_add_f32 %[p2], %[p2], %[t] neg_lo:[0,1] neg_hi:[0,1]\n\tv_pk_add_f32 %[p3], %[p3], %[t] neg_lo:[0,1] neg_hi:[0,1]\n\tv_pk_add_f32 %[p4], %[p4], %[t] neg_lo:[0,1] neg_hi:[0,1]\n\tv_pk_add_f32 %[p5], %[p5], %[t] neg_lo:[0,1] neg_hi:[0,1]\n\tv_pk_add_f32 %[p6], %[p6], %[t] neg_lo:[0,1] neg_hi:[0,1]\n\tv_pk_add_f32 %[p7], %[p7], %[t] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      : [p0] "+v"(p0), [p1] "+v"(p1), [p2] "+v"(p2), [p3] "+v"(p3), [p4] "+v"(p4), [p5] "+v"(p5), [p6] "+v"(p6),
+        [p7] "+v"(p7)
+      : [t] "v"(t));
+  if constexpr (UNIFORM) {
+    asm volatile(
+      "v_mul_f32 v41, %[x0], %[x0]\n\tv_mul_f32 v43, %[x1], %[x1]\n\tv_mul_f32 v45, %[x2], %[x2]\n\tv_mul_f32 v47, %[x3], %[x3]\n\tv_mul_f32 v49, %[x4], %[x4]\n\tv_mul_f32 v51, %[x5], %[x5]\n\tv_mul_f32 v53, %[x6], %[x6]\n\tv_mul_f32 v55, %[x7], %[x7]\n\t"
+      "v_fmac_f32 v41, %[y0], %[y0]\n\tv_fmac_f32 v43, %[y1], %[y1]\n\tv_fmac_f32 v45, %[y2], %[y2]\n\tv_fmac_f32 v47, %[y3], %[y3]\n\tv_fmac_f32 v49, %[y4], %[y4]\n\tv_fmac_f32 v51, %[y5], %[y5]\n\tv_fmac_f32 v53, %[y6], %[y6]\n\tv_fmac_f32 v55, %[y7], %[y7]\n\t"
+      "v_add_f32 v40, |%[x0]|, |%[y0]|\n\tv_max_f32 v41, v41, %[c]\n\tv_add_f32 v42, |%[x1]|, |%[y1]|\n\tv_max_f32 v43, v43, %[c]\n\tv_add_f32 v44, |%[x2]|, |%[y2]|\n\tv_max_f32 v45, v45, %[c]\n\tv_add_f32 v46, |%[x3]|, |%[y3]|\n\tv_max_f32 v47, v47, %[c]\n\tv_add_f32 v48, |%[x4]|, |%[y4]|\n\tv_max_f32 v49, v49, %[c]\n\tv_add_f32 v50, |%[x5]|, |%[y5]|\n\tv_max_f32 v51, v51, %[c]\n\tv_add_f32 v52, |%[x6]|, |%[y6]|\n\tv_max_f32 v53, v53, %[c]\n\tv_add_f32 v54, |%[x7]|, |%[y7]|\n\tv_max_f32 v55, v55, %[c]\n\t"
+      "v_fmaak_f32 v40, v40, v41, 0x12800000\n\tv_fmaak_f32 v42, v42, v43, 0x12800000\n\tv_fmaak_f32 v44, v44, v45, 0x12800000\n\tv_fmaak_f32 v46, v46, v47, 0x12800000\n\tv_fmaak_f32 v48, v48, v49, 0x12800000\n\tv_fmaak_f32 v50, v50, v51, 0x12800000\n\tv_fmaak_f32 v52, v52, v53, 0x12800000\n\tv_fmaak_f32 v54, v54, v55, 0x12800000\n\t"
+      "v_rcp_f32 v40, v40\n\tv_rcp_f32 v42, v42\n\tv_rcp_f32 v44, v44\n\tv_rcp_f32 v46, v46\n\tv_rcp_f32 v48, v48\n\tv_rcp_f32 v50, v50\n\tv_rcp_f32 v52, v52\n\tv_rcp_f32 v54, v54\n\t"
+      "v_pk_fma_f32 %[a], %[p0], v[40:41], %[a] op_sel_hi:[1,0,1]\n\tv_pk_fma_f32 %[a], %[p1], v[42:43], %[a] op_sel_hi:[1,0,1]\n\tv_pk_fma_f32 %[a], %[p2], v[44:45], %[a] op_sel_hi:[1,0,1]\n\tv_pk_fma_f32 %[a], %[p3], v[46:47], %[a] op_sel_hi:[1,0,1]\n\tv_pk_fma_f32 %[a], %[p4], v[48:49], %[a] op_sel_hi:[1,0,1]\n\tv_pk_fma_f32 %[a], %[p5], v[50:51], %[a] op_sel_hi:[1,0,1]\n\tv_pk_fma_f32 %[a], %[p6], v[52:53], %[a] op_sel_hi:[1,0,1]\n\tv_pk_fma_f32 %[a], %[p7], v[54:55], %[a] op_sel_hi:[1,0,1]\n\t"
+      : [a] "+v"(acc)
+      : [p0] "v"(p0), [p1] "v"(p1), [p2] "v"(p2), [p3] "v"(p3), [p4] "v"(p4), [p5] "v"(p5), [p6] "v"(p6), [p7] "v"(p7),
+        [x0] "v"(p0.x), [y0] "v"(p0.y), [x1] "v"(p1.x), [y1] "v"(p1.y), [x2] "v"(p2.x), [y2] "v"(p2.y), [x3] "v"(p3.x), [y3] "v"(p3.y), [x4] "v"(p4.x), [y4] "v"(p4.y), [x5] "v"(p5.x), [y5] "v"(p5.y), [x6] "v"(p6.x), [y6] "v"(p6.y), [x7] "v"(p7.x), [y7] "v"(p7.y),
+        [c] "v"(clamp)
+      : "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55");
+  } else {
+    asm volatile(
+      "v_mul_f32 v41, %[x0], %[x0]\n\tv_mul_f32 v43, %[x1], %[x1]\n\tv_mul_f32 v45, %[x2], %[x2]\n\tv_mul_f32 v47, %[x3], %[x3]\n\tv_mul_f32 v49, %[x4], %[x4]\n\tv_mul_f32 v51, %[x5], %[x5]\n\tv_mul_f32 v53, %[x6], %[x6]\n\tv_mul_f32 v55, %[x7], %[x7]\n\t"
+      "v_fmac_f32 v41, %[y0], %[y0]\n\tv_fmac_f32 v43, %[y1], %[y1]\n\tv_fmac_f32 v45, %[y2], %[y2]\n\tv_fmac_f32 v47, %[y3], %[y3]\n\tv_fmac_f32 v49, %[y4], %[y4]\n\tv_fmac_f32 v51, %[y5], %[y5]\n\tv_fmac_f32 v53, %[y6], %[y6]\n\tv_fmac_f32 v55, %[y7], %[y7]\n\t"
+      "v_add_f32 v40, |%[x0]|, |%[y0]|\n\tv_max_f32 v41, v41, %[c]\n\tv_add_f32 v42, |%[x1]|, |%[y1]|\n\tv_max_f32 v43, v43, %[c]\n\tv_add_f32 v44, |%[x2]|, |%[y2]|\n\tv_max_f32 v45, v45, %[c]\n\tv_add_f32 v46, |%[x3]|, |%[y3]|\n\tv_max_f32 v47, v47, %[c]\n\tv_add_f32 v48, |%[x4]|, |%[y4]|\n\tv_max_f32 v49, v49, %[c]\n\tv_add_f32 v50, |%[x5]|, |%[y5]|\n\tv_max_f32 v51, v51, %[c]\n\tv_add_f32 v52, |%[x6]|, |%[y6]|\n\tv_max_f32 v53, v53, %[c]\n\tv_add_f32 v54, |%[x7]|, |%[y7]|\n\tv_max_f32 v55, v55, %[c]\n\t"
+      "v_fmaak_f32 v40, v40, v41, 0x12800000\n\tv_fmaak_f32 v42, v42, v43, 0x12800000\n\tv_fmaak_f32 v44, v44, v45, 0x12800000\n\tv_fmaak_f32 v46, v46, v47, 0x12800000\n\tv_fmaak_f32 v48, v48, v49, 0x12800000\n\tv_fmaak_f32 v50, v50, v51, 0x12800000\n\tv_fmaak_f32 v52, v52, v53, 0x12800000\n\tv_fmaak_f32 v54, v54, v55, 0x12800000\n\t"
+      "v_rcp_f32 v40, v40\n\tv_rcp_f32 v42, v42\n\tv_rcp_f32 v44, v44\n\tv_rcp_f32 v46, v46\n\tv_rcp_f32 v48, v48\n\tv_rcp_f32 v50, v50\n\tv_rcp_f32 v52, v52\n\tv_rcp_f32 v54, v54\n\t"
+      "v_mul_f32 v40, %[m0], v40\n\tv_mul_f32 v42, %[m1], v42\n\tv_mul_f32 v44, %[m2], v44\n\tv_mul_f32 v46, %[m3], v46\n\tv_mul_f32 v48, %[m4], v48\n\tv_mul_f32 v50, %[m5], v50\n\tv_mul_f32 v52, %[m6], v52\n\tv_mul_f32 v54, %[m7], v54\n\t"
+      "v_pk_fma_f32 %[a], %[p0], v[40:41], %[a] op_sel_hi:[1,0,1]\n\tv_pk_fma_f32 %[a], %[p1], v[42:43], %[a] op_sel_hi:[1,0,1]\n\tv_pk_fma_f32 %[a], %[p2], v[44:45], %[a] op_sel_hi:[1,0,1]\n\tv_pk_fma_f32 %[a], %[p3], v[46:47], %[a] op_sel_hi:[1,0,1]\n\tv_pk_fma_f32 %[a], %[p4], v[48:49], %[a] op_sel_hi:[1,0,1]\n\tv_pk_fma_f32 %[a], %[p5], v[50:51], %[a] op_sel_hi:[1,0,1]\n\tv_pk_fma_f32 %[a], %[p6], v[52:53], %[a] op_sel_hi:[1,0,1]\n\tv_pk_fma_f32 %[a], %[p7], v[54:55], %[a] op_sel_hi:[1,0,1]\n\t"
+      : [a] "+v"(acc)
+      : [p0] "v"(p0), [p1] "v"(p1), [p2] "v"(p2), [p3] "v"(p3), [p4] "v"(p4), [p5] "v"(p5), [p6] "v"(p6), [p7] "v"(p7),
+        [x0] "v"(p0.x), [y0] "v"(p0.y), [x1] "v"(p1.x), [y1] "v"(p1.y), [x2] "v"(p2.x), [y2] "v"(p2.y), [x3] "v"(p3.x), [y3] "v"(p3.y), [x4] "v"(p4.x), [y4] "v"(p4.y), [x5] "v"(p5.x), [y5] "v"(p5.y), [x6] "v"(p6.x), [y6] "v"(p6.y), [x7] "v"(p7.x), [y7] "v"(p7.y),
+        [m0] "v"(m0), [m1] "v"(m1), [m2] "v"(m2), [m3] "v"(m3), [m4] "v"(m4), [m5] "v"(m5), [m6] "v"(m6), [m7] "v"(m7),
+        [c] "v"(clamp)
+      : "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55");
+  }
+}
+
 // main.rs:419-423, no contraction (TU flag).
 __device__ __forceinline__ void integrate_store(const DirectArgs& a, int t_local, float ax, float ay) {
   if (a.acc_out) a.acc_out[t_local] = make_float2(ax, ay);
@@ -89,7 +137,7 @@ __device__ __forceinline__ void integrate_store(const DirectArgs& a, int t_local
 //   the sum; for mass 1 the result is bit-identical to multiplying every term by 1.0).
 // USE_LDS=true: the classic tile in LDS, read back two sources per ds_read_b128 (positions) + ds_read_b64
 //   (masses); all operands are VGPRs, which is what general masses want.
-template <int TPT, int WSPLIT, bool USE_LDS, bool UNIFORM>
+template <int TPT, int WSPLIT, bool USE_LDS, bool UNIFORM, bool USE_ASM>
 __global__ __launch_bounds__(256) void direct_fast(const DirectArgs a) {
   if (a.gate && ((*a.gate != 0) != (a.run_if != 0))) return;
 
@@ -206,13 +254,28 @@ __global__ __launch_bounds__(256) void direct_fast(const DirectArgs a) {
           if (!UNIFORM) mm[h] = *reinterpret_cast<const float2*>(&tile_mass[u + 2 * h]);
           else mm[h] = make_float2(1.f, 1.f);
         }
-#pragma unroll
-        for (int h = 0; h < UNR / 2; ++h)
+        if constexpr (USE_ASM) {
 #pragma unroll
           for (int k = 0; k < TPT; ++k) {
-            fast_pair<UNIFORM>(xi[k], yi[k], pp[h].x, pp[h].y, mm[h].x, clamp, bx[k], by[k]);
-            fast_pair<UNIFORM>(xi[k], yi[k], pp[h].z, pp[h].w, mm[h].y, clamp, bx[k], by[k]);
+            float2 q0 = make_float2(pp[0].x, pp[0].y), q1 = make_float2(pp[0].z, pp[0].w);
+            float2 q2 = make_float2(pp[1].x, pp[1].y), q3 = make_float2(pp[1].z, pp[1].w);
+            float2 q4 = make_float2(pp[2].x, pp[2].y), q5 = make_float2(pp[2].z, pp[2].w);
+            float2 q6 = make_float2(pp[3].x, pp[3].y), q7 = make_float2(pp[3].z, pp[3].w);
+            float2 acc2 = make_float2(bx[k], by[k]);
+            fast_block8<UNIFORM>(make_float2(xi[k], yi[k]), clamp, q0, q1, q2, q3, q4, q5, q6, q7, mm[0].x, mm[0].y,
+                                 mm[1].x, mm[1].y, mm[2].x, mm[2].y, mm[3].x, mm[3].y, acc2);
+            bx[k] = acc2.x;
+            by[k] = acc2.y;
           }
+        } else {
+#pragma unroll
+          for (int h = 0; h < UNR / 2; ++h)
+#pragma unroll
+            for (int k = 0; k < TPT; ++k) {
+              fast_pair<UNIFORM>(xi[k], yi[k], pp[h].x, pp[h].y, mm[h].x, clamp, bx[k], by[k]);
+              fast_pair<UNIFORM>(xi[k], yi[k], pp[h].z, pp[h].w, mm[h].y, clamp, bx[k], by[k]);
+            }
+        }
       }
       for (; u < hi; ++u) {
         float2 p = tile_pos[u];
@@ -328,13 +391,17 @@ __global__ __launch_bounds__(256) void weights_to_mass(const uint32_t* __restric
 
 // ------------------------------------------------------------------------------------------------ host launchers
 template <int TPT, int WSPLIT, bool USE_LDS>
-static hipError_t launch_fast_t(hipStream_t s, const DirectArgs& a, int n_gsplit) {
+static hipError_t launch_fast_t(hipStream_t s, const DirectArgs& a, int n_gsplit, bool use_asm) {
   constexpr int TGT_PER_BLOCK = (4 / WSPLIT) * 64 * TPT;
   dim3 grid((unsigned)((a.n_tgt + TGT_PER_BLOCK - 1) / TGT_PER_BLOCK), (unsigned)n_gsplit);
-  if (a.uniform_mass > 0.f)
-    hipLaunchKernelGGL((direct_fast<TPT, WSPLIT, USE_LDS, true>), grid, dim3(256), 0, s, a);
-  else
-    hipLaunchKernelGGL((direct_fast<TPT, WSPLIT, USE_LDS, false>), grid, dim3(256), 0, s, a);
+  constexpr bool CAN_ASM = USE_LDS && TPT == 1;   // the hand-ordered block exists for the LDS flavour, 1 target/thread
+  if (a.uniform_mass > 0.f) {
+    if (CAN_ASM && use_asm) hipLaunchKernelGGL((direct_fast<TPT, WSPLIT, USE_LDS, true, CAN_ASM>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((direct_fast<TPT, WSPLIT, USE_LDS, true, false>), grid, dim3(256), 0, s, a);
+  } else {
+    if (CAN_ASM && use_asm) hipLaunchKernelGGL((direct_fast<TPT, WSPLIT, USE_LDS, false, CAN_ASM>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((direct_fast<TPT, WSPLIT, USE_LDS, false, false>), grid, dim3(256), 0, s, a);
+  }
   return hipGetLastError();
 }
 
@@ -342,7 +409,7 @@ hipError_t launch_direct_fast(hipStream_t s, const DirectArgs& a, const DirectCo
   if (a.n_tgt <= 0) return hipSuccess;
   hipError_t e = hipErrorInvalidValue;
 #define NB_CASE(T, W, L) \
-  if (c.tpt == T && c.wsplit == W && c.use_lds == L) e = launch_fast_t<T, W, L>(s, a, c.gsplit);
+  if (c.tpt == T && c.wsplit == W && c.use_lds == L) e = launch_fast_t<T, W, L>(s, a, c.gsplit, c.use_asm);
   NB_CASE(1, 1, false) NB_CASE(2, 1, false) NB_CASE(4, 1, false)
   NB_CASE(1, 4, false) NB_CASE(2, 4, false) NB_CASE(4, 4, false)
   NB_CASE(1, 1, true) NB_CASE(2, 1, true) NB_CASE(4, 1, true)

@@ -41,11 +41,9 @@ def run(n, n_tgt, cfgs, reps=3, uniform=1.0):
 
 
 if __name__ == "__main__":
-    base = []
-    for lds in (0, 1):
-        for tpt in (1, 2, 4):
-            for ws in (1, 4):
-                base.append({"NBODY_DIRECT_LDS": lds, "NBODY_DIRECT_TPT": tpt, "NBODY_DIRECT_WSPLIT": ws, "NBODY_DIRECT_GSPLIT": 1})
     n = 1 << 20
-    run(n, n, base, reps=2, uniform=1.0)
-    run(n, n, base, reps=2, uniform=0.0)
+    ab = [{"NBODY_DIRECT_ASM": a} for a in (0, 1, 0, 1)]
+    run(n, n, ab, reps=2, uniform=1.0)
+    run(n, n, ab[:2], reps=2, uniform=0.0)
+    run(n, n >> 3, ab[:2], reps=3, uniform=1.0)
+    run(1 << 16, 1 << 16, ab[:2], reps=5, uniform=1.0)
