@@ -179,6 +179,11 @@ int nbody_direct_step_dev(void* stream, int64_t n_sources, const void* pos_all, 
                           float uniform_mass, int64_t target_begin, int64_t n_targets, void* vel, void* pos_out, void* acc_out,
                           float delta, float clamp, int arith, void* workspace, size_t workspace_bytes,
                           nbody_timer* timer /* may be NULL */);
+/* Decision words of the last nbody_direct_step_dev call on that workspace (waits for the stream):
+ * out = {hazard flag, split fallback flag, number of near sources, state} with state 0 = near/far split (the main
+ * pass skips the clamp for sources proven far from every other body, the near ones are added with it), 1 = one
+ * clamped FAST pass, 2 = EXACT kernel.  Parity/diagnostic hook. */
+int nbody_direct_workspace_peek(void* stream, const void* workspace, int32_t out[4]);
 /* u32 weights -> f32 masses on device (the `as f32` of main.rs:360). */
 int nbody_weights_to_mass_dev(void* stream, int64_t n, const void* weight_u32, void* mass_f32);
 

@@ -78,6 +78,7 @@ _SIGS = {
     "nbody_get_counting": (C.c_int, [_vp, C.POINTER(Counting)]),
     "nbody_direct_workspace_bytes": (_sz, [_i64, _i64]),
     "nbody_direct_step_dev": (C.c_int, [_vp, _i64, _vp, _vp, _f32, _i64, _i64, _vp, _vp, _vp, _f32, _f32, _i32, _vp, _sz, _vp]),
+    "nbody_direct_workspace_peek": (C.c_int, [_vp, _vp, C.POINTER(C.c_int32 * 4)]),
     "nbody_weights_to_mass_dev": (C.c_int, [_vp, _i64, _vp, _vp]),
     "nbody_timer_create": (C.c_int, [C.POINTER(_vp)]),
     "nbody_timer_destroy": (None, [_vp]),
@@ -347,6 +348,13 @@ def direct_step_dev(stream, n_sources, pos_all, mass_all, target_begin, n_target
                                       _vp(acc_out) if acc_out else None, float(delta), float(clamp), int(arith),
                                       _vp(workspace), int(workspace_bytes), timer.h if timer else None)
     check(None, rc)
+
+
+def direct_workspace_peek(stream, workspace):
+    """-> (hazard, fallback, n_near, state) of the last direct_step_dev on that workspace."""
+    out = (C.c_int32 * 4)()
+    check(None, load().nbody_direct_workspace_peek(_vp(stream), _vp(workspace), C.byref(out)))
+    return tuple(out)
 
 
 def weights_to_mass_dev(stream, n, weight_u32, mass_f32):

@@ -167,42 +167,39 @@ int env_int(const char* name, int dflt) {
 
 // How the direct kernel covers (n_tgt x n_src): enough waves to fill 256 CUs x 4 SIMDs x 8 waves.
 DirectConfig choose_direct_config(int64_t n_src, int64_t n_tgt, bool uniform = true) {
-  (void)n_src;
   DirectConfig c;
-  c.use_lds = env_int("NBODY_DIRECT_LDS", 1) != 0;  // measured: LDS tile beats SGPR broadcast
   c.use_asm = env_int("NBODY_DIRECT_ASM", 1) != 0;
+  c.nearfar = env_int("NBODY_DIRECT_NEARFAR", 1) != 0;
   // measured at N = 1M (profiles/r01_direct_variant_sweep_*.txt): equal masses -> 1 target/thread with the
   // hand-ordered block; per-body masses -> 2 targets/thread, compiler-scheduled
   c.tpt = env_int("NBODY_DIRECT_TPT", uniform ? 1 : 2);
-  if (c.tpt != 1 && c.tpt != 2 && c.tpt != 4) c.tpt = 1;
+  if (c.tpt != 1 && c.tpt != 2) c.tpt = 1;
   const int64_t want_waves = 8192;
-  int64_t groups = (n_tgt + 64 * c.tpt - 1) / (64 * c.tpt);
-  int wsplit = env_int("NBODY_DIRECT_WSPLIT", 4);  // measured faster than 1 at every size
-  if (wsplit != 1 && wsplit != 4) wsplit = 4;
-  c.wsplit = wsplit;
-  int64_t waves = groups * wsplit;
+  int64_t waves = 4 * ((n_tgt + 64 * c.tpt - 1) / (64 * c.tpt));
   int64_t g = waves > 0 ? (want_waves + waves - 1) / waves : 1;
   if (g < 1) g = 1;
   if (g > 32) g = 32;
   g = env_int("NBODY_DIRECT_GSPLIT", (int)g);
   if (g < 1) g = 1;
   if (g > 64) g = 64;
-  // a split must still hold a few unrolled iterations
-  while (g > 1 && n_src / (g * c.wsplit) < 64) g /= 2;
+  while (g > 1 && n_src / g < 2048) g /= 2;  // a split should still hold a couple of tiles
   c.gsplit = (int)g;
   return c;
 }
 
 constexpr size_t kFlagBytes = 256;
 
-size_t direct_ws_bytes(int64_t n_src, int64_t n_tgt) {
+size_t direct_partial_bytes(int64_t n_src, int64_t n_tgt) {
   size_t partial = 0;
   for (bool uni : {false, true}) {
     DirectConfig c = choose_direct_config(n_src, n_tgt, uni);
-    size_t p = c.gsplit > 1 ? (size_t)c.gsplit * (size_t)n_tgt * sizeof(float2) : 0;
+    size_t p = (size_t)c.gsplit * (size_t)n_tgt * sizeof(float2);
     if (p > partial) partial = p;
   }
-  return kFlagBytes + ((partial + 255) & ~(size_t)255);
+  return (partial + 255) & ~(size_t)255;
+}
+size_t direct_ws_bytes(int64_t n_src, int64_t n_tgt) {
+  return kFlagBytes + direct_partial_bytes(n_src, n_tgt) + nearfar_layout(n_src).total;
 }
 
 int direct_step_dev(nbody_ctx* c, hipStream_t stream, int64_t n_src, const void* pos_all, const void* mass_all,
@@ -222,8 +219,10 @@ int direct_step_dev(nbody_ctx* c, hipStream_t stream, int64_t n_src, const void*
 
   const bool uni = uniform_mass > 0.f && env_int("NBODY_DIRECT_NO_UNIFORM", 0) == 0;
   DirectConfig cfg = choose_direct_config(n_src, n_tgt, uni);
+  int* flags = (int*)ws;
   DirectArgs a{};
   a.pos_all = (const float2*)pos_all;
+  a.src_pos = a.pos_all;
   a.mass_all = (const float*)mass_all;
   a.n_src = (int)n_src;
   a.tgt_begin = (int)tgt_begin;
@@ -235,20 +234,57 @@ int direct_step_dev(nbody_ctx* c, hipStream_t stream, int64_t n_src, const void*
   a.delta = delta;
   a.clamp = clamp;
   a.uniform_mass = uni ? uniform_mass : 0.f;
-  int* flag = (int*)ws;
-  if (arith == NBODY_ARITH_AUTO) {
-    HIPCHK(c, launch_hazard_scan(stream, (const float*)pos_all, 2 * n_src, flag));
-    a.gate = flag;
-  }
-  if (arith != NBODY_ARITH_EXACT) {
-    a.run_if = 0;
+  a.flags = flags;
+  a.run_state = -1;
+
+  if (arith == NBODY_ARITH_EXACT) {
     TimerScope ts(timer, stream);
-    HIPCHK(c, launch_direct_fast(stream, a, cfg));
-  }
-  if (arith != NBODY_ARITH_FAST) {
-    a.run_if = 1;
-    TimerScope ts(arith == NBODY_ARITH_EXACT ? timer : nullptr, stream);
     HIPCHK(c, launch_direct_exact(stream, a));
+    return NBODY_OK;
+  }
+  // ---- decide, on the stream, which kernels of this step do the work (flags[kFlagState])
+  const int use_hazard = arith == NBODY_ARITH_AUTO;
+  HIPCHK(c, hipMemsetAsync(flags, 0, kFlagBytes, stream));
+  if (use_hazard) HIPCHK(c, launch_hazard_scan(stream, (const float*)pos_all, 2 * n_src, flags));
+  char* nf_scratch = (char*)ws + kFlagBytes + direct_partial_bytes(n_src, n_tgt);
+  const float2* pos_far = nullptr;
+  const uint32_t* near_list = nullptr;
+  if (cfg.nearfar) {
+    NearFarLayout L = nearfar_layout(n_src);
+    HIPCHK(c, launch_nearfar(stream, a.pos_all, a.n_src, clamp, use_hazard, flags, nf_scratch, L, &pos_far, &near_list));
+  } else {
+    HIPCHK(c, launch_decide_simple(stream, use_hazard, flags));
+  }
+  {
+    TimerScope ts(timer, stream);
+    if (cfg.nearfar) {  // state 0: main pass over the far sources without the clamp, near sources added by finish
+      DirectArgs a0 = a;
+      a0.src_pos = pos_far;
+      a0.near_list = near_list;
+      a0.to_partial = 1;
+      a0.run_state = 0;
+      HIPCHK(c, launch_direct_fast(stream, a0, cfg, true));
+    }
+    DirectArgs a1 = a;  // state 1: one clamped pass over every source
+    a1.to_partial = cfg.gsplit > 1;
+    a1.run_state = 1;
+    HIPCHK(c, launch_direct_fast(stream, a1, cfg, false));
+  }
+  if (cfg.nearfar) {
+    DirectArgs a0 = a;
+    a0.near_list = near_list;
+    a0.run_state = 0;
+    HIPCHK(c, launch_direct_finish(stream, a0, cfg.gsplit, true));
+  }
+  if (cfg.gsplit > 1) {
+    DirectArgs a1 = a;
+    a1.run_state = 1;
+    HIPCHK(c, launch_direct_finish(stream, a1, cfg.gsplit, false));
+  }
+  if (use_hazard) {  // state 2
+    DirectArgs a2 = a;
+    a2.run_state = 2;
+    HIPCHK(c, launch_direct_exact(stream, a2));
   }
   return NBODY_OK;
 }
@@ -786,6 +822,13 @@ NB_API int nbody_direct_step_dev(void* stream, int64_t n_sources, const void* po
                                  nbody_timer* timer) {
   return direct_step_dev(nullptr, (hipStream_t)stream, n_sources, pos_all, mass_all, uniform_mass, target_begin, n_targets, vel,
                          pos_out, acc_out, delta, clamp, arith, workspace, workspace_bytes, timer);
+}
+
+NB_API int nbody_direct_workspace_peek(void* stream, const void* workspace, int32_t out[4]) {
+  if (!workspace || !out) return fail(nullptr, NBODY_ERR_INVALID, "workspace_peek: bad arguments");
+  hipError_t e = hipMemcpyAsync(out, workspace, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream);
+  if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+  return e == hipSuccess ? NBODY_OK : fail_hip(nullptr, e, "workspace_peek");
 }
 
 NB_API int nbody_weights_to_mass_dev(void* stream, int64_t n, const void* weight_u32, void* mass_f32) {

@@ -1,38 +1,54 @@
-// Launch interface of the direct O(N^2) kernels (direct_kernels.hip).  Internal to the library.
+// Launch interface of the direct O(N^2) kernels (direct_kernels.hip, nearfar.hip).  Internal to the library.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 
 namespace nbody {
 
+// Decision words at the start of the workspace (int each), written on the stream before the step's kernels.
+enum { kFlagHazard = 0, kFlagFallback = 1, kFlagNearCount = 2, kFlagState = 3 };
+// kFlagState: 0 = near/far split (main pass without the clamp), 1 = single clamped FAST pass, 2 = EXACT kernel.
+
 struct DirectArgs {
-  const float2* pos_all;  // [n_src] all source positions
+  const float2* pos_all;  // [n_src] all positions: targets, integration base, EXACT sources, near sources
+  const float2* src_pos;  // [n_src] sources of the FAST main pass (pos_all, or the far copy of nearfar.hip)
   const float* mass_all;  // [n_src] `weight as f32`
   int n_src;
-  int tgt_begin;  // targets are sources [tgt_begin, tgt_begin + n_tgt)
+  int tgt_begin;  // targets are bodies [tgt_begin, tgt_begin + n_tgt)
   int n_tgt;
   float2* vel;      // [n_tgt] in/out, or null (acceleration only)
   float2* pos_out;  // [n_tgt] out, or null
   float2* acc_out;  // [n_tgt] out, or null
-  float2* partial;  // [gsplit][n_tgt] scratch when the grid splits the sources
+  float2* partial;  // [gsplit][n_tgt] scratch
+  int to_partial;   // main pass writes partial sums (direct_finish completes the step)
   float delta;
   float clamp;
-  float uniform_mass;  // > 0: every mass equals this value (mass_all is not read by the FAST kernel)
-  const int* gate;  // optional device flag: the kernel runs only when (*gate != 0) == (run_if != 0)
-  int run_if;
+  float uniform_mass;  // > 0: every mass equals this value (mass_all is not read by the FAST main pass)
+  const int* flags;    // decision words
+  int run_state;       // the kernel runs only when flags[kFlagState] == run_state; < 0: always
+  const uint32_t* near_list;  // near sources (ascending body index), count in flags[kFlagNearCount]
 };
 
 struct DirectConfig {
-  int tpt = 1;        // targets per thread: 1, 2, 4
-  int wsplit = 1;     // waves of a block sharing one target group and splitting the sources: 1 or 4
-  int gsplit = 1;     // source split over blockIdx.y (partials + direct_finish)
-  bool use_lds = false;
-  bool use_asm = true;  // hand-ordered 8-pair block (LDS flavour, tpt 1)
+  int tpt = 1;     // targets per thread: 1 or 2
+  int gsplit = 1;  // source split over blockIdx.y
+  bool use_asm = true;  // hand-ordered 8-pair block (tpt 1)
+  bool nearfar = true;  // per-step near/far split of the sources
 };
 
-hipError_t launch_direct_fast(hipStream_t s, const DirectArgs& a, const DirectConfig& c);
+struct NearFarLayout {
+  size_t keys0, keys1, idx0, idx1, is_near, scan, near_list, pos_far, cub_temp, cub_temp_bytes, total;
+};
+NearFarLayout nearfar_layout(int64_t n_src);
+hipError_t launch_nearfar(hipStream_t s, const float2* pos, int n, float clamp, int use_hazard, int* flags,
+                          char* scratch, const NearFarLayout& L, const float2** pos_far, const uint32_t** near_list);
+hipError_t launch_decide_simple(hipStream_t s, int use_hazard, int* flags);
+
+hipError_t launch_direct_fast(hipStream_t s, const DirectArgs& a, const DirectConfig& c, bool noclamp);
+hipError_t launch_direct_finish(hipStream_t s, const DirectArgs& a, int n_gsplit, bool add_near);
 hipError_t launch_direct_exact(hipStream_t s, const DirectArgs& a);
-hipError_t launch_hazard_scan(hipStream_t s, const float* xy, long n_floats, int* flag);
+hipError_t launch_hazard_scan(hipStream_t s, const float* xy, long n_floats, int* flags);
 hipError_t launch_weights_to_mass(hipStream_t s, const uint32_t* w, float* m, long n);
 
 }  // namespace nbody

@@ -220,3 +220,95 @@ def test_device_level_sharded_targets_equal_whole(nb, ctx):
     b = run(2500, n - 2500)
     for k in range(3):
         assert np.array_equal(np.concatenate([a[k], b[k]]), whole[k])
+
+
+# ------------------------------------------------------------------ near/far split of the sources (nearfar.hip)
+def _dev_accel(nb, pos, w, arith=None, uniform=0.0):
+    """Acceleration of every body through nbody_direct_step_dev; returns (acc, (hazard, fallback, n_near, state))."""
+    import torch
+    C = nb._capi
+    n = pos.shape[0]
+    dev = torch.device("cuda:0")
+    tp = torch.from_numpy(np.ascontiguousarray(pos, F32)).to(dev)
+    tm = torch.from_numpy(w.astype(F32)).to(dev)
+    acc = torch.empty((n, 2), dtype=torch.float32, device=dev)
+    ws_bytes = C.direct_workspace_bytes(n, n)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    C.direct_step_dev(stream, n, tp.data_ptr(), tm.data_ptr(), 0, n, None, None, acc.data_ptr(), 0.0, 0.001,
+                      C.ARITH_AUTO if arith is None else arith, ws.data_ptr(), ws_bytes, uniform_mass=uniform)
+    torch.cuda.synchronize()
+    return acc.cpu().numpy(), C.direct_workspace_peek(stream, ws.data_ptr())
+
+
+def test_nearfar_split_with_close_pairs_and_clusters(nb, orc):
+    """Bodies closer than sqrt(clamp) = 0.0316 (pairs, a tight cluster, exact duplicates) must be found 'near' and
+    summed with the clamp; everything else goes through the clamp-free main pass.  Same tolerance as ever."""
+    n = 30000
+    pos, vel, w = nb.scenes.plummer(n, seed=81)
+    rng = np.random.default_rng(3)
+    pos[1000] = pos[2000] + F32(0.01)                      # a close pair
+    pos[3000] = pos[4000]                                  # exact duplicate
+    c = pos[5000].copy()
+    for k in range(40):                                    # a cluster of 40 within 0.02
+        pos[6000 + k] = c + (rng.random(2).astype(F32) - F32(0.5)) * F32(0.02)
+    pos[7000] = pos[8000] + np.array([0.031, 0.0], F32)    # just inside the clamp radius
+    pos[9000] = pos[9500] + np.array([0.033, 0.0], F32)    # just outside it (may or may not share a cell)
+    w = (np.arange(n) % 4 + 1).astype(np.uint32)
+    acc, (hazard, fallback, n_near, state) = _dev_accel(nb, pos, w)
+    assert (hazard, fallback, state) == (0, 0, 0)
+    assert n_near >= 2 + 2 + 40 + 2                        # at least the planted ones
+    check_fast(acc, *_refs(orc, pos, w))
+    # every planted body must be in the near set: compare with the single clamped pass bit for bit is not
+    # required (summation order differs), but the clamped pairs dominate their targets' sums:
+    ref64, norm, _ = _refs(orc, pos, w, targets=np.array([1000, 2000, 3000, 4000, 6000, 6039, 7000, 8000]))
+    assert np.all(np.abs(acc[[1000, 2000, 3000, 4000, 6000, 6039, 7000, 8000]] - ref64).sum(axis=1) <= 2e-5 * norm)
+
+
+def test_nearfar_uniform_mass_path(nb, orc):
+    n = 20000
+    pos, vel, w = nb.scenes.plummer(n, seed=82)
+    pos[10] = pos[11] + F32(0.005)
+    acc, (_, _, n_near, state) = _dev_accel(nb, pos, w, uniform=1.0)
+    assert state == 0 and n_near >= 2
+    check_fast(acc, *_refs(orc, pos, w))
+
+
+def test_nearfar_falls_back_when_dense_or_out_of_range(nb, orc):
+    rng = np.random.default_rng(5)
+    n = 4096
+    dense = (F32(50000.0) + rng.random((n, 2)).astype(F32) * F32(0.5)).astype(F32)   # everything within 0.5 x 0.5
+    w = np.ones(n, np.uint32)
+    acc, (_, _, n_near, state) = _dev_accel(nb, dense, w)
+    assert state == 1 and n_near > n // 64
+    check_fast(acc, *_refs(orc, dense, w))
+    pos, _, _ = nb.scenes.plummer(n, seed=83)
+    pos[17] = (3.0e8, 1.0)                                  # beyond the cell grid's range (|x|/h >= 2^30)
+    acc, (_, fallback, _, state) = _dev_accel(nb, pos, w)
+    assert fallback == 1 and state == 1
+    check_fast(acc, *_refs(orc, pos, w))
+
+
+def test_nearfar_off_gives_the_same_answer_within_tolerance(nb, orc, monkeypatch):
+    n = 16384
+    pos, vel, w = nb.scenes.plummer(n, seed=84)
+    pos[100] = pos[200] + F32(0.004)
+    a_on, st_on = _dev_accel(nb, pos, w, uniform=1.0)
+    monkeypatch.setenv("NBODY_DIRECT_NEARFAR", "0")
+    a_off, st_off = _dev_accel(nb, pos, w, uniform=1.0)
+    assert st_on[3] == 0 and st_off[3] == 1
+    ref64, norm, cpu32 = _refs(orc, pos, w)
+    check_fast(a_on, ref64, norm, cpu32)
+    check_fast(a_off, ref64, norm, cpu32)
+    # far sources see identical arithmetic in both modes; only the position of the near terms in the sum differs
+    assert np.abs(a_on - a_off).sum(axis=1).max() <= 2e-5 * norm.max()
+
+
+def test_nearfar_hazard_still_routes_to_exact(nb, orc):
+    n = 2048
+    pos, vel, w = nb.scenes.plummer(n, seed=85)
+    pos[5, 0] = np.nan
+    acc, (hazard, _, _, state) = _dev_accel(nb, pos, w)
+    assert hazard == 1 and state == 2
+    ref, _ = orc.direct_accel(pos, w, nthreads=8)
+    assert np.array_equal(acc, ref.astype(F32), equal_nan=True)
