@@ -16,6 +16,7 @@
 
 #include "common.h"
 #include "direct_kernels.h"
+#include "quad_build.h"
 #include "tree_build.hpp"
 #include "tree_kernels.h"
 
@@ -94,8 +95,15 @@ template <class T> struct State {
   void* link = nullptr;
   size_t node_cap = 0;
   uint32_t* order_dev = nullptr;
-  TreeHost<T> tree;
+  TreeHost<T> tree;          // host image of the last build (filled lazily after a device build)
   bool tree_valid = false;
+  bool tree_host_stale = false;  // the last build ran on the device and has not been downloaded
+  int n_nodes = 0, tree_kind = 0, tree_max_depth = 0;
+  int* node_depth = nullptr;     // device build: depth of every node
+  uint32_t* node_mass = nullptr; // device build: u32 mass of every node
+  size_t node_aux_cap = 0;
+  char* qb_scratch = nullptr;
+  size_t qb_scratch_bytes = 0;
   std::vector<T> h_pos;
   std::vector<uint32_t> h_weight;  // current row order
   std::vector<uint32_t> h_tmp;
@@ -148,6 +156,8 @@ template <class P> void free_dev(P*& p) {
 template <class T> void free_state(State<T>& s) {
   for (auto& st : s.set) { free_dev(st.pos); free_dev(st.vel); free_dev(st.weight); free_dev(st.ids); free_dev(st.mass); }
   free_dev(s.pos_next); free_dev(s.acc); free_dev(s.geom0); free_dev(s.geom1); free_dev(s.link); free_dev(s.order_dev);
+  free_dev(s.node_depth); free_dev(s.node_mass); free_dev(s.qb_scratch);
+  s.node_aux_cap = 0; s.qb_scratch_bytes = 0; s.tree_host_stale = false; s.n_nodes = 0;
   s.node_cap = 0; s.n = 0; s.tree_valid = false; s.tree.clear();
   s.h_pos.clear(); s.h_weight.clear();
 }
@@ -365,22 +375,112 @@ template <class T> int download(nbody_ctx* c, T* pos, T* vel, uint32_t* w, uint3
 }
 
 // -------------------------------------------------------------------------------------------- tree phases
-template <class T> int upload_tree(nbody_ctx* c, State<T>& s) {
-  const size_t m = s.tree.size();
+template <class T> int ensure_node_buffers(nbody_ctx* c, State<T>& s, size_t m) {
   using G4 = typename TreeHost<T>::G4;
   using L4 = typename TreeHost<T>::L4;
   if (m > s.node_cap) {
     free_dev(s.geom0); free_dev(s.geom1); free_dev(s.link);
+    s.node_cap = 0;
     size_t cap = m + m / 4 + 64;
     HIPCHK(c, hipMalloc(&s.geom0, cap * sizeof(G4)));
     HIPCHK(c, hipMalloc(&s.geom1, cap * sizeof(G4)));
     HIPCHK(c, hipMalloc(&s.link, cap * sizeof(L4)));
     s.node_cap = cap;
   }
+  return NBODY_OK;
+}
+
+template <class T> int upload_tree(nbody_ctx* c, State<T>& s) {
+  const size_t m = s.tree.size();
+  using G4 = typename TreeHost<T>::G4;
+  using L4 = typename TreeHost<T>::L4;
+  int rc0 = ensure_node_buffers<T>(c, s, m);
+  if (rc0) return rc0;
   HIPCHK(c, hipMemcpyAsync(s.geom0, s.tree.geom0.data(), m * sizeof(G4), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(s.geom1, s.tree.geom1.data(), m * sizeof(G4), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(s.link, s.tree.link.data(), m * sizeof(L4), hipMemcpyHostToDevice, c->stream));
   if (s.n) HIPCHK(c, hipMemcpyAsync(s.order_dev, s.tree.order.data(), (size_t)s.n * 4, hipMemcpyHostToDevice, c->stream));
+  return NBODY_OK;
+}
+
+// Quad tree built on the device (quad_build.hip).  Returns NBODY_OK, an error, or 1 when the device build declines.
+template <class T> int quad_build_device(nbody_ctx* c, State<T>& s) {
+  const int n = (int)s.n;
+  QuadBuildLayout L = quad_build_layout(n);
+  if (s.qb_scratch_bytes < L.total) {
+    free_dev(s.qb_scratch);
+    s.qb_scratch_bytes = 0;
+    HIPCHK(c, hipMalloc((void**)&s.qb_scratch, L.total));
+    s.qb_scratch_bytes = L.total;
+  }
+  auto& in = s.set[s.cur];
+  auto& out = s.set[1 - s.cur];
+  const T rx = (T)c->params.quad_root_x, ry = (T)c->params.quad_root_y, rh = (T)c->params.quad_root_h;
+  HIPCHK(c, quad_build_phase_a<T>(c->stream, in.pos, n, rx, ry, rh, s.qb_scratch, L, s.order_dev));
+  int flags[3] = {0, 0, 0};
+  HIPCHK(c, hipMemcpyAsync(flags, s.qb_scratch + L.flags, sizeof(flags), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (flags[0] != 0 || flags[1] <= 0) return 1;
+  const int m = flags[1];
+  int rc = ensure_node_buffers<T>(c, s, (size_t)m);
+  if (rc) return rc;
+  if ((size_t)m > s.node_aux_cap) {
+    free_dev(s.node_depth); free_dev(s.node_mass);
+    s.node_aux_cap = 0;
+    size_t cap = (size_t)m + m / 4 + 64;
+    HIPCHK(c, hipMalloc((void**)&s.node_depth, cap * sizeof(int)));
+    HIPCHK(c, hipMalloc((void**)&s.node_mass, cap * sizeof(uint32_t)));
+    s.node_aux_cap = cap;
+  }
+  HIPCHK(c, quad_build_phase_b<T>(c->stream, in.pos, in.weight, n, rx, ry, rh, s.qb_scratch, L, s.order_dev, m, flags[2],
+                                  s.geom0, s.geom1, s.link, s.node_depth, s.node_mass));
+  GatherArgs<T> g{};  // the leaves' own copies of their points, in tree order
+  g.perm = s.order_dev;
+  g.n = n;
+  g.pos_in = in.pos; g.pos_out = out.pos;
+  g.weight_in = in.weight;
+  g.mass_out = out.mass;
+  HIPCHK(c, launch_gather<T>(c->stream, g));
+  s.n_nodes = m;
+  s.tree_kind = NBODY_TREE_QUAD;
+  s.tree_max_depth = flags[2];
+  s.tree_host_stale = true;
+  s.tree_valid = true;
+  return NBODY_OK;
+}
+
+// Host image of a device-built tree, for the export API.
+template <class T> int download_tree(nbody_ctx* c, State<T>& s) {
+  if (!s.tree_host_stale) return NBODY_OK;
+  using G4 = typename TreeHost<T>::G4;
+  using L4 = typename TreeHost<T>::L4;
+  const size_t m = (size_t)s.n_nodes;
+  auto& t = s.tree;
+  t.clear();
+  t.kind = s.tree_kind;
+  t.max_depth = s.tree_max_depth;
+  t.geom0.resize(m); t.geom1.resize(m); t.link.resize(m); t.mass_u32.resize(m); t.order.resize((size_t)s.n);
+  HIPCHK(c, hipMemcpyAsync(t.geom0.data(), s.geom0, m * sizeof(G4), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(t.geom1.data(), s.geom1, m * sizeof(G4), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(t.link.data(), s.link, m * sizeof(L4), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(t.mass_u32.data(), s.node_mass, m * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  if (s.n) HIPCHK(c, hipMemcpyAsync(t.order.data(), s.order_dev, (size_t)s.n * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  t.size_x.resize(m); t.size_y.resize(m);
+  for (size_t i = 0; i < m; ++i) {
+    // height is not stored on the device; hi - lo would round.  Recover it exactly from the parent chain:
+    // a child's height is its parent's height / 2 (quad_tree.rs:172), the root's is the parameter.
+    t.size_x[i] = t.size_y[i] = T(0);
+  }
+  {
+    std::vector<int> depth(m);
+    HIPCHK(c, hipMemcpy(depth.data(), s.node_depth, m * sizeof(int), hipMemcpyDeviceToHost));
+    std::vector<T> hd((size_t)t.max_depth + 2);
+    hd[0] = (T)c->params.quad_root_h;
+    for (size_t d = 1; d < hd.size(); ++d) hd[d] = hd[d - 1] / (T)2.0;
+    for (size_t i = 0; i < m; ++i) t.size_x[i] = t.size_y[i] = hd[(size_t)depth[i]];
+  }
+  s.tree_host_stale = false;
   return NBODY_OK;
 }
 
@@ -392,6 +492,11 @@ template <class T> int tree_build_phase(nbody_ctx* c, State<T>& s, int kind) {
   if (kind != NBODY_TREE_BVH && kind != NBODY_TREE_QUAD) return fail(c, NBODY_ERR_INVALID, "unknown tree kind");
   const int64_t n = s.n;
   s.tree_valid = false;
+  s.tree_host_stale = false;
+  if (kind == NBODY_TREE_QUAD && n > 0 && env_int("NBODY_QUAD_BUILD_HOST", 0) == 0) {
+    int rc = quad_build_device<T>(c, s);
+    if (rc != 1) return rc;  // 1 = the device build declined (too deep for its key / sizes): host builder below
+  }
   s.h_pos.resize((size_t)(2 * n));
   if (n) {
     HIPCHK(c, hipMemcpyAsync(s.h_pos.data(), s.set[s.cur].pos, (size_t)n * sizeof(T2), hipMemcpyDeviceToHost, c->stream));
@@ -406,6 +511,9 @@ template <class T> int tree_build_phase(nbody_ctx* c, State<T>& s, int kind) {
   }
   if (s.tree.overflow)
     return fail(c, NBODY_ERR_DEGENERATE, "tree build exceeded the depth cap (more coincident points than a leaf holds)");
+  s.n_nodes = (int)s.tree.size();
+  s.tree_kind = s.tree.kind;
+  s.tree_max_depth = s.tree.max_depth;
   int rc = upload_tree(c, s);
   if (rc) return rc;
   auto& in = s.set[s.cur];
@@ -438,7 +546,7 @@ template <class T>
 int tree_walk_phase(nbody_ctx* c, State<T>& s, int kind, const void* tgt_pos, int64_t n_tgt, void* acc) {
   WalkArgs<T> w{};
   w.geom0 = s.geom0; w.geom1 = s.geom1; w.link = s.link;
-  w.n_nodes = (int)s.tree.size();
+  w.n_nodes = s.n_nodes;
   w.theta = (T)c->params.theta;
   w.clamp = (T)c->params.clamp;
   w.acc = acc;
@@ -568,8 +676,10 @@ int tree_export(const nbody_ctx* cc, T* geom, uint32_t* mass, int32_t* is_leaf, 
   nbody_ctx* c = const_cast<nbody_ctx*>(cc);
   if (!c) return NBODY_ERR_INVALID;
   if (!has_state<T>(c)) return fail(c, NBODY_ERR_INVALID, "tree_export: no particles of this precision uploaded");
-  const State<T>& s = state_of<T>(c);
+  State<T>& s = state_of<T>(c);
   if (!s.tree_valid) return fail(c, NBODY_ERR_INVALID, "tree_export: no tree built yet");
+  int rc = download_tree<T>(c, s);
+  if (rc) return rc;
   tree_export_host<T>(s.tree, geom, mass, is_leaf, first, count, skip, order);
   return NBODY_OK;
 }
@@ -730,11 +840,11 @@ NB_API int nbody_tree_info(const nbody_ctx* c, nbody_tree_view* out) {
   if (!c || !out) return NBODY_ERR_INVALID;
   nbody_ctx* mc = const_cast<nbody_ctx*>(c);
   if (c->has_f32 && c->sf.tree_valid) {
-    out->n_nodes = (int64_t)c->sf.tree.size(); out->kind = c->sf.tree.kind; out->max_depth = c->sf.tree.max_depth;
+    out->n_nodes = c->sf.n_nodes; out->kind = c->sf.tree_kind; out->max_depth = c->sf.tree_max_depth;
     return NBODY_OK;
   }
   if (c->has_f64 && c->sd.tree_valid) {
-    out->n_nodes = (int64_t)c->sd.tree.size(); out->kind = c->sd.tree.kind; out->max_depth = c->sd.tree.max_depth;
+    out->n_nodes = c->sd.n_nodes; out->kind = c->sd.tree_kind; out->max_depth = c->sd.tree_max_depth;
     return NBODY_OK;
   }
   return fail(mc, NBODY_ERR_INVALID, "tree_info: no tree built yet");

@@ -1,0 +1,23 @@
+// Device-side quad-tree build (quad_build.hip).  Internal to the library.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace nbody {
+
+struct QuadBuildLayout {
+  size_t flags, keys_a, keys_b, keys_by_index, idx_a, idx_b, ld_by_index, ld, fd, cnt, base, cub_temp, cub_temp_bytes, total;
+};
+QuadBuildLayout quad_build_layout(int64_t n);
+
+// flags (int[3] at scratch + L.flags) after phase A: {needs host fallback, n_nodes, max_depth}
+template <class T>
+hipError_t quad_build_phase_a(hipStream_t s, const void* pos, int n, T rx, T ry, T rh, char* scratch, const QuadBuildLayout& L,
+                              uint32_t* order_out);
+template <class T>
+hipError_t quad_build_phase_b(hipStream_t s, const void* pos, const uint32_t* weight, int n, T rx, T ry, T rh, char* scratch,
+                              const QuadBuildLayout& L, const uint32_t* order, int n_nodes, int max_depth, void* geom0,
+                              void* geom1, void* link, int* depth, uint32_t* mass);
+
+}  // namespace nbody

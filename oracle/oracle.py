@@ -38,6 +38,8 @@ def lib(native: bool = False) -> C.CDLL:
     return _LIBS[key]
 
 
+# The clamp is the f32 constant `0.001f32` upstream (main.rs:247-248); f64 runs widen that f32 value, exactly as the
+# product's `float clamp` parameter does, so every wrapper passes nt(np.float32(clamp)).
 def _p(a, ct):
     return None if a is None else a.ctypes.data_as(C.POINTER(ct))
 
@@ -61,7 +63,7 @@ def pair(p1, p2, force, clamp=0.001, acc=(0.0, 0.0), dtype=np.float32):
     f = getattr(lib(), f"orc_pair_{sfx}")
     f.restype = None
     f.argtypes = [ct] * 6 + [C.POINTER(ct)]
-    f(ct(nt(p1[0])), ct(nt(p1[1])), ct(nt(p2[0])), ct(nt(p2[1])), ct(nt(force)), ct(nt(clamp)), _p(a, ct))
+    f(ct(nt(p1[0])), ct(nt(p1[1])), ct(nt(p2[0])), ct(nt(p2[1])), ct(nt(force)), ct(nt(np.float32(clamp))), _p(a, ct))
     return a
 
 
@@ -91,7 +93,7 @@ def direct_accel(pos, weight, targets=None, target_pos=None, clamp=0.001, accum=
     f.restype = None
     f.argtypes = [C.c_int64, C.POINTER(ct), C.POINTER(C.c_uint32), C.c_int64, C.POINTER(C.c_int64),
                   C.POINTER(ct), ct, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
-    f(n, _p(pos, ct), _p(w, C.c_uint32), nt_, _p(idx, C.c_int64), _p(tp, ct), ct(nt(clamp)),
+    f(n, _p(pos, ct), _p(w, C.c_uint32), nt_, _p(idx, C.c_int64), _p(tp, ct), ct(nt(np.float32(clamp))),
       0 if accum == "native" else 1, int(nthreads), _p(acc, C.c_double), _p(norm, C.c_double))
     return acc, norm
 
@@ -108,7 +110,7 @@ def update_direct(pos, vel, weight, delta=0.1, clamp=0.001, nsteps=1, nthreads=1
     f.restype = C.c_int
     f.argtypes = [C.c_int64, C.POINTER(ct), C.POINTER(ct), C.POINTER(C.c_uint32), ct, ct, C.c_int, C.c_int,
                   C.POINTER(C.c_double)]
-    rc = f(pos.shape[0], _p(pos, ct), _p(vel, ct), _p(w, C.c_uint32), ct(nt(delta)), ct(nt(clamp)),
+    rc = f(pos.shape[0], _p(pos, ct), _p(vel, ct), _p(w, C.c_uint32), ct(nt(delta)), ct(nt(np.float32(clamp))),
            int(nsteps), int(nthreads), _p(cnt, C.c_double))
     if rc:
         raise RuntimeError(f"oracle update_direct rc={rc}")
@@ -134,7 +136,7 @@ def update_bvh(pos, vel, weight, delta=0.1, theta=50.0, clamp=0.001, leaf_size=6
     f.argtypes = [C.c_int64, C.POINTER(ct), C.POINTER(ct), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), ct, ct,
                   ct, C.c_int64, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
     rc = f(pos.shape[0], _p(pos, ct), _p(vel, ct), _p(w, C.c_uint32), _p(ids, C.c_uint32), ct(nt(delta)),
-           ct(nt(theta)), ct(nt(clamp)), int(leaf_size), int(mode), int(nsteps), int(nthreads),
+           ct(nt(theta)), ct(nt(np.float32(clamp))), int(leaf_size), int(mode), int(nsteps), int(nthreads),
            _p(cnt, C.c_double))
     if rc:
         raise RuntimeError(f"oracle update_bvh rc={rc} (degenerate input: recursion depth cap)")
@@ -154,7 +156,7 @@ def update_quad(pos, vel, weight, delta=0.1, theta=50.0, clamp=0.001, root=(0.0,
     f.argtypes = [C.c_int64, C.POINTER(ct), C.POINTER(ct), C.POINTER(C.c_uint32), ct, ct, ct, ct, ct, ct,
                   C.c_int, C.c_int, C.POINTER(C.c_double)]
     rc = f(pos.shape[0], _p(pos, ct), _p(vel, ct), _p(w, C.c_uint32), ct(nt(delta)), ct(nt(theta)),
-           ct(nt(clamp)), ct(nt(root[0])), ct(nt(root[1])), ct(nt(root[2])), int(nsteps), int(nthreads),
+           ct(nt(np.float32(clamp))), ct(nt(root[0])), ct(nt(root[1])), ct(nt(root[2])), int(nsteps), int(nthreads),
            _p(cnt, C.c_double))
     if rc:
         raise RuntimeError(f"oracle update_quad rc={rc} (degenerate input: recursion depth cap)")
@@ -236,7 +238,7 @@ class BVH:
         f = getattr(self._L, f"orc_bvh_walk_{self.sfx}")
         f.restype = None
         f.argtypes = [C.c_void_p, C.c_int64, C.POINTER(ct), ct, ct, C.c_int, C.POINTER(ct), C.POINTER(C.c_uint64)]
-        f(self.h, tg.shape[0], _p(tg, ct), ct(self.nt(theta)), ct(self.nt(clamp)), int(nthreads), _p(acc, ct),
+        f(self.h, tg.shape[0], _p(tg, ct), ct(self.nt(theta)), ct(self.nt(np.float32(clamp))), int(nthreads), _p(acc, ct),
           _p(st, C.c_uint64))
         return (acc, st) if stats else acc
 
@@ -321,6 +323,6 @@ class Quad:
         f = getattr(self._L, f"orc_quad_walk_{self.sfx}")
         f.restype = None
         f.argtypes = [C.c_void_p, C.c_int64, C.POINTER(ct), ct, ct, C.c_int, C.POINTER(ct), C.POINTER(C.c_uint64)]
-        f(self.h, tg.shape[0], _p(tg, ct), ct(self.nt(theta)), ct(self.nt(clamp)), int(nthreads), _p(acc, ct),
+        f(self.h, tg.shape[0], _p(tg, ct), ct(self.nt(theta)), ct(self.nt(np.float32(clamp))), int(nthreads), _p(acc, ct),
           _p(st, C.c_uint64))
         return (acc, st) if stats else acc

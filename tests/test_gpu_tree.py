@@ -140,3 +140,69 @@ def test_config4_4M_quad_f64_sampled(nb, orc):
         print(f"4M quad f64 step: build {cnt.build_bvh:.3f}s walk {cnt.sum_gravity:.3f}s integrate {cnt.post_calculations:.4f}s")
     finally:
         c.close()
+
+
+# ------------------------------------------------------------------ device-side quad build (quad_build.hip)
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("n", [1, 8, 9, 10, 100, 5000, 200000])
+def test_device_quad_build_equals_oracle_tree(nb, orc, ctx, dtype, n):
+    """The tree the device builds (path keys + two radix sorts + scans) must be the reference's tree: every cell,
+    child order, leaf slot order, mass and centre of gravity, bit for bit."""
+    C = nb._capi
+    pos, vel, _ = nb.scenes.plummer(n, seed=91, dtype=dtype)
+    w = (np.arange(n) % 5 + 1).astype(np.uint32)
+    ctx.set_params(theta=0.5)
+    ctx.upload(pos, vel, w)
+    acc = ctx.accel_tree(C.TREE_QUAD)
+    t = ctx.tree_export()
+    o = orc.Quad(pos, w).flat()
+    for k in ("geom", "mass", "is_leaf", "first", "count", "skip", "order"):
+        assert np.array_equal(t[k], getattr(o, k)), k
+    assert t["max_depth"] == int(o.depth.max())
+    assert np.array_equal(acc, orc.Quad(pos, w).walk(pos, theta=0.5, nthreads=8))
+
+
+def test_device_and_host_quad_builds_agree(nb, ctx, monkeypatch):
+    C = nb._capi
+    pos, vel, w = nb.scenes.galaxy()          # lattice points: many equal coordinates, mixed masses
+    ctx.set_params(theta=0.5)
+    ctx.upload(pos, vel, w)
+    ctx.accel_tree(C.TREE_QUAD, pos[:10])
+    dev = ctx.tree_export()
+    monkeypatch.setenv("NBODY_QUAD_BUILD_HOST", "1")
+    ctx.accel_tree(C.TREE_QUAD, pos[:10])
+    host = ctx.tree_export()
+    for k in ("geom", "mass", "is_leaf", "first", "count", "skip", "order"):
+        assert np.array_equal(dev[k], host[k]), k
+
+
+def test_device_quad_build_declines_deep_trees_and_host_takes_over(nb, orc, ctx):
+    """9 points within 1e-8 of each other need ~43 levels in f64: beyond the 31 levels of the device's path key.
+    The step must still be exact (host builder) rather than wrong or an error."""
+    C = nb._capi
+    rng = np.random.default_rng(7)
+    pos = (rng.random((2000, 2)) * 1e5)
+    pos[100:109] = pos[100] + rng.random((9, 2)) * 1e-8
+    w = np.ones(2000, np.uint32)
+    ctx.set_params(theta=0.5)
+    ctx.upload(pos, np.zeros_like(pos), w)
+    acc = ctx.accel_tree(C.TREE_QUAD)
+    o = orc.Quad(pos, w)
+    assert int(o.flat().depth.max()) > 31
+    assert ctx.tree_export()["max_depth"] == int(o.flat().depth.max())
+    assert np.array_equal(acc, o.walk(pos, theta=0.5, nthreads=8))
+
+
+def test_device_quad_points_outside_root_cell(nb, orc, ctx):
+    C = nb._capi
+    rng = np.random.default_rng(5)
+    inside = (rng.random((3000, 2)) * 1e5).astype(F32)
+    outside = np.array([[-5e4, 2e4], [1.7e5, 3e4], [4e4, -1e3], [5e4, 2.5e5], [-1.0, -1.0], [1e5 + 1, 1e5 + 1]], F32)
+    pos = np.concatenate([inside[:1500], outside, inside[1500:]])
+    ctx.set_params(theta=0.5)
+    ctx.upload(pos, np.zeros_like(pos), None)
+    ctx.accel_tree(C.TREE_QUAD, pos[:4])
+    t = ctx.tree_export()
+    o = orc.Quad(pos).flat()
+    for k in ("geom", "mass", "is_leaf", "first", "count", "skip", "order"):
+        assert np.array_equal(t[k], getattr(o, k)), k

@@ -23,7 +23,6 @@ def case(name, pos, vel, w, kind, theta, steps=3, cpu=True, cpu_steps=1):
         ctx.set_params(theta=theta, order=C.ORDER_CONSISTENT)
         ctx.upload(pos, vel, w)
         ctx.update_tree(kind, 0.1, 1)                     # warm-up (allocations, first build)
-        ctx.walk_stats(True)
         t = C.Timer()
         ctx.set_timer(t)
         cnt = C.Counting()
@@ -31,6 +30,9 @@ def case(name, pos, vel, w, kind, theta, steps=3, cpu=True, cpu_steps=1):
         ctx.update_tree(kind, 0.1, steps, cnt)
         wall = time.perf_counter() - t0
         walk_ms, launches = t.read()
+        ctx.set_timer(None)
+        ctx.walk_stats(True)                              # statistics in a separate, untimed walk (3 atomics per target)
+        ctx.accel_tree(kind)
         visits, accepted, leaf_pairs = ctx.walk_stats(False)
         info = ctx.tree_info()
     n = pos.shape[0]
@@ -67,8 +69,9 @@ if __name__ == "__main__":
     case("reference scene (World::new, seeded), theta 50", pos, vel, w, C.TREE_BVH, 50.0, steps=5)
     case("reference scene, theta 0.5", pos, vel, w, C.TREE_BVH, 0.5, steps=5)
     pos, vel, w = nb.scenes.plummer(1 << 20, seed=0x5EED0003)
-    case("plummer 1M bvh theta 0.5", pos, vel, w, C.TREE_BVH, 0.5, steps=3)
+    case("plummer 1M bvh theta 50 (the reference's theta)", pos, vel, w, C.TREE_BVH, 50.0, steps=3)
+    case("plummer 1M bvh theta 0.5 (needle boxes: ~direct sum)", pos, vel, w, C.TREE_BVH, 0.5, steps=1, cpu=False)
     case("plummer 1M quad theta 0.5", pos, vel, w, C.TREE_QUAD, 0.5, steps=3)
     pos, vel, w = nb.scenes.plummer(1 << 22, seed=0x5EED0004, dtype=np.float64)
     case("config 4: plummer 4M quad theta 0.5 f64", pos, vel, w, C.TREE_QUAD, 0.5, steps=3)
-    case("plummer 4M bvh theta 0.5 f64", pos, vel, w, C.TREE_BVH, 0.5, steps=3)
+    case("plummer 4M bvh theta 50 f64", pos, vel, w, C.TREE_BVH, 50.0, steps=3)
