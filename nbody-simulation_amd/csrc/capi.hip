@@ -569,7 +569,7 @@ int tree_walk_phase(nbody_ctx* c, State<T>& s, int kind, const void* tgt_pos, in
   }
   {
     TimerScope ts(c->timer, c->stream);
-    HIPCHK(c, launch_tree_walk<T>(c->stream, w));
+    HIPCHK(c, launch_tree_walk<T>(c->stream, w, env_int("NBODY_WALK_PER_THREAD", 0) == 0));
   }
   if (w.stats) {
     HIPCHK(c, hipMemcpyAsync(c->last_stats, c->stats_dev, sizeof(c->last_stats), hipMemcpyDeviceToHost, c->stream));

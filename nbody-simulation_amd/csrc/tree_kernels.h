@@ -30,7 +30,7 @@ template <class T> struct GatherArgs {
   T* mass_out;
 };
 
-template <class T> hipError_t launch_tree_walk(hipStream_t s, const WalkArgs<T>& a);
+template <class T> hipError_t launch_tree_walk(hipStream_t s, const WalkArgs<T>& a, bool wave_uniform);
 template <class T> hipError_t launch_gather(hipStream_t s, const GatherArgs<T>& a);
 template <class T> hipError_t launch_integrate(hipStream_t s, void* pos, void* vel, const void* acc, int64_t n, T delta);
 

@@ -103,6 +103,78 @@ __global__ __launch_bounds__(256) void tree_walk(const WalkArgs<T> a) {
   }
 }
 
+// Wave-uniform walk: the 64 targets of a wave traverse the tree TOGETHER, in pre-order, with one node index held in
+// an SGPR; each lane carries `resume`, the pre-order index at which it takes part again (a lane that accepted a node
+// or finished a leaf sleeps until that subtree's `skip`).  A lane acts on node i iff resume <= i, so every lane sees
+// exactly the nodes of its own depth-first walk, in the same order, with the same operations: bit-identical to
+// tree_walk and to the CPU recursion.  What changes is who fetches the tree: node and leaf data are wave-uniform,
+// so they arrive by scalar loads (no per-lane gathers, no divergent loop control), and the next node needs no
+// reduction: sleeping lanes resume at or after skip[i] (their sleeping subtree contains node i), therefore
+//     next = any(acting lane descends) ? i + 1 : skip[i].
+// The wave visits the union of its lanes' paths; targets are handed out in tree order so that union stays small.
+template <class T>
+__global__ __launch_bounds__(256) void tree_walk_wave(const WalkArgs<T> a) {
+  using T2 = typename V2<T>::type;
+  using T4 = typename V4<T>::type;
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool live = t < a.n_tgt;
+  const int64_t row = live ? (a.tgt_index ? (int64_t)a.tgt_index[t] : t) : 0;
+  const T2 p = live ? reinterpret_cast<const T2*>(a.tgt_pos)[row] : T2{0, 0};
+  const T4* __restrict__ g0 = reinterpret_cast<const T4*>(a.geom0);
+  const T4* __restrict__ g1 = reinterpret_cast<const T4*>(a.geom1);
+  const int4* __restrict__ lk = reinterpret_cast<const int4*>(a.link);
+  const T2* __restrict__ lpos = reinterpret_cast<const T2*>(a.leaf_pos);
+  const T* __restrict__ lmass = a.leaf_mass;
+  const T theta = a.theta, clamp = a.clamp;
+  const int n_nodes = a.n_nodes;
+  T ax = 0, ay = 0;
+  int resume = live ? 0 : n_nodes;
+  unsigned long long visits = 0, accepted = 0, leaf_pairs = 0;
+  int i = 0;
+  while (i < n_nodes) {
+    const int4 l = lk[i];  // wave-uniform index: scalar load
+    const bool act = resume <= i;
+    int next;
+    if (l.w) {  // Leaf arm, main.rs:351-363
+      if (act) {
+        for (int k = l.y; k < l.y + l.z; ++k) {
+          const T2 q = lpos[k];
+          pair_as_written<T>(p.x, p.y, q.x, q.y, lmass[k], clamp, ax, ay);
+        }
+        resume = l.x;
+        if (a.stats) { visits++; leaf_pairs += (unsigned long long)l.z; }
+      }
+      next = l.x;
+    } else {
+      const T4 b = g0[i];
+      const T4 c = g1[i];
+      bool descend = false;
+      if (act) {
+        const bool contains = p.y > b.y && p.x > b.x && p.x < b.z && p.y < b.w;  // bvh_tree.rs:15-20
+        const T ddx = p.x - c.x, ddy = p.y - c.y;
+        const T d2 = ddx * ddx + ddy * ddy;                                        // main.rs:228-232
+        if (!contains && c.w < d2 * theta * theta) {                               // :370-372
+          pair_as_written<T>(p.x, p.y, c.x, c.y, c.z, clamp, ax, ay);              // :374-379
+          resume = l.x;
+          if (a.stats) accepted++;
+        } else {
+          descend = true;                                                          // :381-382
+          resume = i + 1;
+        }
+        if (a.stats) visits++;
+      }
+      next = __builtin_amdgcn_ballot_w64(descend) != 0 ? i + 1 : l.x;
+    }
+    i = __builtin_amdgcn_readfirstlane(next);
+  }
+  if (live) reinterpret_cast<T2*>(a.acc)[row] = T2{ax, ay};
+  if (a.stats && live) {
+    atomicAdd(&a.stats[0], visits);
+    atomicAdd(&a.stats[1], accepted);
+    atomicAdd(&a.stats[2], leaf_pairs);
+  }
+}
+
 // out[i] = in[perm[i]] for the particle arrays (the device-side image of the in-place partition permutation).
 template <class T>
 __global__ __launch_bounds__(256) void gather_particles(const GatherArgs<T> a) {
@@ -135,9 +207,10 @@ __global__ __launch_bounds__(256) void integrate_inplace(void* pos, void* vel, c
   reinterpret_cast<T2*>(pos)[i] = p;
 }
 
-template <class T> hipError_t launch_tree_walk(hipStream_t s, const WalkArgs<T>& a) {
+template <class T> hipError_t launch_tree_walk(hipStream_t s, const WalkArgs<T>& a, bool wave_uniform) {
   if (a.n_tgt <= 0) return hipSuccess;
-  hipLaunchKernelGGL((tree_walk<T>), dim3((unsigned)((a.n_tgt + 255) / 256)), dim3(256), 0, s, a);
+  if (wave_uniform) hipLaunchKernelGGL((tree_walk_wave<T>), dim3((unsigned)((a.n_tgt + 255) / 256)), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((tree_walk<T>), dim3((unsigned)((a.n_tgt + 255) / 256)), dim3(256), 0, s, a);
   return hipGetLastError();
 }
 template <class T> hipError_t launch_gather(hipStream_t s, const GatherArgs<T>& a) {
@@ -151,8 +224,8 @@ template <class T> hipError_t launch_integrate(hipStream_t s, void* pos, void* v
   return hipGetLastError();
 }
 
-template hipError_t launch_tree_walk<float>(hipStream_t, const WalkArgs<float>&);
-template hipError_t launch_tree_walk<double>(hipStream_t, const WalkArgs<double>&);
+template hipError_t launch_tree_walk<float>(hipStream_t, const WalkArgs<float>&, bool);
+template hipError_t launch_tree_walk<double>(hipStream_t, const WalkArgs<double>&, bool);
 template hipError_t launch_gather<float>(hipStream_t, const GatherArgs<float>&);
 template hipError_t launch_gather<double>(hipStream_t, const GatherArgs<double>&);
 template hipError_t launch_integrate<float>(hipStream_t, void*, void*, const void*, int64_t, float);
