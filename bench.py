@@ -72,7 +72,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--n", type=int, default=N_BODIES, help="total bodies (default: the BASELINE config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-targets", type=int, default=16384)
+    ap.add_argument("--cpu-sample-targets", type=int, default=131072)
     args = ap.parse_args()
 
     import torch

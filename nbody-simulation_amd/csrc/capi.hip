@@ -180,15 +180,19 @@ DirectConfig choose_direct_config(int64_t n_src, int64_t n_tgt, bool uniform = t
   DirectConfig c;
   c.use_asm = env_int("NBODY_DIRECT_ASM", 1) != 0;
   c.nearfar = env_int("NBODY_DIRECT_NEARFAR", 1) != 0;
-  // measured at N = 1M (profiles/r01_direct_variant_sweep_*.txt): equal masses -> 1 target/thread with the
-  // hand-ordered block; per-body masses -> 2 targets/thread, compiler-scheduled
-  c.tpt = env_int("NBODY_DIRECT_TPT", uniform ? 1 : 2);
+  // measured at N = 1M (profiles/r01_direct_mass_variants.txt): 1 target/thread with the hand-ordered block wins for
+  // equal masses (44.0 %) and for per-body masses (39.8 % vs 36.1 % for 2 targets/thread)
+  (void)uniform;
+  c.tpt = env_int("NBODY_DIRECT_TPT", 1);
   if (c.tpt != 1 && c.tpt != 2) c.tpt = 1;
-  const int64_t want_waves = 8192;
+  // 256 CUs x 32 wave slots hold 8192 waves; several rounds of waves balance the tail, so the sources are split
+  // over blockIdx.y until there are ~16 rounds (measured, profiles/r01_direct_gsplit_sweep.txt: 131072 targets
+  // 40.5 % -> 43.8 %, 65536 x 65536 33.5 % -> 43.1 %, 1M x 1M 43.8 % -> 44.1 %)
+  const int64_t want_waves = 131072;
   int64_t waves = 4 * ((n_tgt + 64 * c.tpt - 1) / (64 * c.tpt));
   int64_t g = waves > 0 ? (want_waves + waves - 1) / waves : 1;
   if (g < 1) g = 1;
-  if (g > 32) g = 32;
+  if (g > 16) g = 16;
   g = env_int("NBODY_DIRECT_GSPLIT", (int)g);
   if (g < 1) g = 1;
   if (g > 64) g = 64;

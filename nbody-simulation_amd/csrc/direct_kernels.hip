@@ -208,7 +208,8 @@ __global__ __launch_bounds__(256) void direct_fast(const DirectArgs a) {
   if constexpr (USE_ASM) asm volatile("v_mov_b32 %0, %1" : "=v"(clamp) : "s"(a.clamp));  // keep it in a VGPR
 
   __shared__ __attribute__((aligned(16))) float2 tile_pos[TILE];
-  __shared__ __attribute__((aligned(16))) float tile_mass[UNIFORM ? 4 : TILE];
+  __shared__ __attribute__((aligned(16))) float4 tile_mass4[UNIFORM ? 1 : TILE / 4];  // masses, four per element
+  float* tile_mass = reinterpret_cast<float*>(tile_mass4);
 
   // sources of this grid split: [g0, g1)
   int gchunk = (a.n_src + (int)gridDim.y - 1) / (int)gridDim.y;
@@ -244,10 +245,14 @@ __global__ __launch_bounds__(256) void direct_fast(const DirectArgs a) {
       float4 pp[UNR / 2];
       float2 mm[UNR / 2];
 #pragma unroll
-      for (int h = 0; h < UNR / 2; ++h) {
-        pp[h] = *reinterpret_cast<const float4*>(&tile_pos[u + 2 * h]);
-        if (!UNIFORM) mm[h] = *reinterpret_cast<const float2*>(&tile_mass[u + 2 * h]);
-        else mm[h] = make_float2(1.f, 1.f);
+      for (int h = 0; h < UNR / 2; ++h) pp[h] = *reinterpret_cast<const float4*>(&tile_pos[u + 2 * h]);
+      if constexpr (!UNIFORM) {  // u is a multiple of 8: two ds_read_b128 fetch the eight masses
+        const float4 ma = tile_mass4[(u >> 2)], mb = tile_mass4[(u >> 2) + 1];
+        mm[0] = make_float2(ma.x, ma.y); mm[1] = make_float2(ma.z, ma.w);
+        mm[2] = make_float2(mb.x, mb.y); mm[3] = make_float2(mb.z, mb.w);
+      } else {
+#pragma unroll
+        for (int h = 0; h < UNR / 2; ++h) mm[h] = make_float2(1.f, 1.f);
       }
       if constexpr (USE_ASM) {
         static_assert(!USE_ASM || TPT == 1, "the hand-ordered block handles one target per thread");

@@ -40,7 +40,7 @@ def test_workspace_size_is_monotone_and_small(nb):
     C = nb._capi
     a = C.direct_workspace_bytes(1 << 20, 1 << 20)
     b = C.direct_workspace_bytes(1 << 20, 1 << 17)
-    assert 256 <= a <= 64 << 20 and 256 <= b <= 64 << 20
+    assert 256 <= a <= 128 << 20 and 256 <= b <= 128 << 20
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])

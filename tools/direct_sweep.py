@@ -42,8 +42,7 @@ def run(n, n_tgt, cfgs, reps=3, uniform=1.0):
 
 if __name__ == "__main__":
     n = 1 << 20
-    ab = [{"NBODY_DIRECT_NEARFAR": a} for a in (0, 1, 0, 1)]
-    run(n, n, ab, reps=2, uniform=1.0)
-    run(n, n, ab[:2], reps=2, uniform=0.0)
-    run(n, n >> 3, ab[:2], reps=3, uniform=1.0)
-    run(1 << 16, 1 << 16, ab[:2], reps=5, uniform=1.0)
+    cfgs = [{"NBODY_DIRECT_TPT": 1, "NBODY_DIRECT_ASM": 1}, {"NBODY_DIRECT_TPT": 1, "NBODY_DIRECT_ASM": 0}, {"NBODY_DIRECT_TPT": 2}]
+    run(n, n, cfgs, reps=2, uniform=0.0)
+    run(n, n, cfgs[:1], reps=2, uniform=1.0)
+    run(n, n >> 3, cfgs[:1], reps=3, uniform=1.0)
