@@ -72,6 +72,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--n", type=int, default=N_BODIES, help="total bodies (default: the BASELINE config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
+                                                      "several ranks on one GPU)")
     ap.add_argument("--cpu-sample-targets", type=int, default=131072)
     args = ap.parse_args()
 
@@ -91,11 +93,15 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; the HIP path has no CPU fallback", file=sys.stderr)
         sys.exit(3)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank % torch.cuda.device_count()   # one rank per GPU; the modulo only matters in a rehearsal
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=args.backend)
 
     n = args.n
     pos, vel, w = nb.scenes.plummer(n, seed=SEED)          # every rank generates the same bodies
@@ -141,16 +147,17 @@ def main():
             except Exception:
                 traffic = None
         out = {
-            "metric": "pair-interactions/sec, direct O(N^2) force + integration step, N=1,048,576",
+            "metric": "pair-interactions/sec + ms/step at N=1M direct O(N^2) (force + integration step)",
             "value": value, "unit": "pair-interactions/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"direct O(N^2) f32, N={n} bodies, seeded 2-D Plummer sphere, masses 1, "
                                    f"dt={DT}, clamp={CLAMP} (BASELINE.json configs[2])",
                        "n_bodies": n, "targets_per_gpu": n_tgt,
-                       "exchange": "none" if world == 1 else "RCCL all-gather of float2 positions per step",
+                       "exchange": "none" if world == 1 else f"{args.backend} all-gather of float2 positions per step"
+                                   + (" (RCCL over xGMI)" if args.backend == "nccl" else " (rehearsal)"),
                        "arith": "AUTO (FAST kernel; EXACT on hazardous positions)"},
-            "roofline": {"bound": "valu_f32", "kernel": "nbody::direct_fast", "achieved": achieved,
+            "roofline": {"bound": "valu_f32", "bound_class": "compute", "kernel": "nbody::direct_fast", "achieved": achieved,
                          "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_TFLOPS,
                          "traffic": traffic, "flops_per_pair": FLOPS_PER_PAIR, "pairs_per_launch": float(n) * n_tgt,
                          "kernel_ms": kern_ms, "launches_timed": kern_launches,
