@@ -323,7 +323,7 @@ template <class T> int upload(nbody_ctx* c, int64_t n, const T* pos, const T* ve
   State<T>& s = state_of<T>(c);
   using T2 = typename State<T>::T2;
   s.n = n;
-  const size_t nn = (size_t)(n > 0 ? n : 1);
+  const size_t nn = (size_t)(n > 0 ? n : 1) + 16;  // tree_walk_wave reads leaf particles 8 at a time: padded
   for (auto& st : s.set) {
     HIPCHK(c, hipMalloc((void**)&st.pos, nn * sizeof(T2)));
     HIPCHK(c, hipMalloc((void**)&st.vel, nn * sizeof(T2)));
@@ -501,11 +501,14 @@ template <class T> int tree_build_phase(nbody_ctx* c, State<T>& s, int kind) {
     int rc = quad_build_device<T>(c, s);
     if (rc != 1) return rc;  // 1 = the device build declined (too deep for its key / sizes): host builder below
   }
+  const bool trace = env_int("NBODY_TRACE", 0) != 0;
+  double tt0 = now_s();
   s.h_pos.resize((size_t)(2 * n));
   if (n) {
     HIPCHK(c, hipMemcpyAsync(s.h_pos.data(), s.set[s.cur].pos, (size_t)n * sizeof(T2), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
   }
+  double tt1 = now_s();
   if (kind == NBODY_TREE_BVH) {
     if (c->params.leaf_size < 1) return fail(c, NBODY_ERR_INVALID, "leaf_size must be >= 1");
     build_bvh<T>(s.h_pos.data(), s.h_weight.data(), n, c->params.leaf_size, s.tree);
@@ -513,6 +516,8 @@ template <class T> int tree_build_phase(nbody_ctx* c, State<T>& s, int kind) {
     build_quad<T>(s.h_pos.data(), s.h_weight.data(), n, (T)c->params.quad_root_x, (T)c->params.quad_root_y,
                   (T)c->params.quad_root_h, s.tree);
   }
+  double tt2 = now_s();
+  if (trace) std::fprintf(stderr, "[nbody] host tree build: D2H %.3f ms, build %.3f ms (%zu nodes)\n", 1e3 * (tt1 - tt0), 1e3 * (tt2 - tt1), s.tree.size());
   if (s.tree.overflow)
     return fail(c, NBODY_ERR_DEGENERATE, "tree build exceeded the depth cap (more coincident points than a leaf holds)");
   s.n_nodes = (int)s.tree.size();
@@ -551,6 +556,7 @@ int tree_walk_phase(nbody_ctx* c, State<T>& s, int kind, const void* tgt_pos, in
   WalkArgs<T> w{};
   w.geom0 = s.geom0; w.geom1 = s.geom1; w.link = s.link;
   w.n_nodes = s.n_nodes;
+  w.big_leaves = kind == NBODY_TREE_BVH && c->params.leaf_size >= 16;
   w.theta = (T)c->params.theta;
   w.clamp = (T)c->params.clamp;
   w.acc = acc;

@@ -78,8 +78,8 @@ template <class T> struct SubTree {
   }
 };
 
-constexpr int64_t kParallelMinLen = 32768;  // subtrees at least this big get their own thread ...
-constexpr int kParallelMaxDepth = 5;        // ... down to this depth (<= 2^5 / 4^5 concurrent tasks)
+constexpr int64_t kParallelMinLen = 8192;  // subtrees at least this big get their own thread ...
+constexpr int kParallelMaxDepth = 6;       // ... down to this depth (<= 2^6 concurrent BVH tasks)
 
 inline int build_threads() {
   if (const char* e = std::getenv("NBODY_BUILD_THREADS")) {

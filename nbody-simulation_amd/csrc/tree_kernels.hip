@@ -10,6 +10,7 @@
 // subtree (leaf done, or node accepted) is link.skip.  No per-thread stack is needed at all.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "tree_kernels.h"
 
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(256) void tree_walk(const WalkArgs<T> a) {
 // reduction: sleeping lanes resume at or after skip[i] (their sleeping subtree contains node i), therefore
 //     next = any(acting lane descends) ? i + 1 : skip[i].
 // The wave visits the union of its lanes' paths; targets are handed out in tree order so that union stays small.
-template <class T>
+template <class T, int LB, bool PREFETCH>
 __global__ __launch_bounds__(256) void tree_walk_wave(const WalkArgs<T> a) {
   using T2 = typename V2<T>::type;
   using T4 = typename V4<T>::type;
@@ -130,24 +131,50 @@ __global__ __launch_bounds__(256) void tree_walk_wave(const WalkArgs<T> a) {
   T ax = 0, ay = 0;
   int resume = live ? 0 : n_nodes;
   unsigned long long visits = 0, accepted = 0, leaf_pairs = 0;
+  if (n_nodes <= 0) {
+    if (live) reinterpret_cast<T2*>(a.acc)[row] = T2{ax, ay};
+    return;
+  }
+  // The walk is bound by the latency of its scalar loads, so a node's three records are fetched together, the
+  // pre-order successor (the common next node) is fetched while the current node is processed, and leaf
+  // particles come eight at a time (the arrays are padded, so reading past a leaf's end is safe; the extra
+  // entries are not used).
   int i = 0;
+  int4 l = lk[0];
+  T4 b = g0[0], c = g1[0];
   while (i < n_nodes) {
-    const int4 l = lk[i];  // wave-uniform index: scalar load
+    int4 ln = l;
+    T4 bn = b, cn = c;
+    if constexpr (PREFETCH) {  // speculative: node i+1
+      const int ip = (i + 1 < n_nodes) ? i + 1 : i;
+      ln = lk[ip];
+      bn = g0[ip];
+      cn = g1[ip];
+    }
     const bool act = resume <= i;
     int next;
     if (l.w) {  // Leaf arm, main.rs:351-363
-      if (act) {
-        for (int k = l.y; k < l.y + l.z; ++k) {
-          const T2 q = lpos[k];
-          pair_as_written<T>(p.x, p.y, q.x, q.y, lmass[k], clamp, ax, ay);
+      const int end = l.y + l.z;
+      for (int k0 = l.y; k0 < end; k0 += LB) {
+        T2 q[LB];
+        T m[LB];
+#pragma unroll
+        for (int j = 0; j < LB; ++j) {
+          q[j] = lpos[k0 + j];
+          m[j] = lmass[k0 + j];
         }
+        if (act) {
+#pragma unroll
+          for (int j = 0; j < LB; ++j)
+            if (k0 + j < end) pair_as_written<T>(p.x, p.y, q[j].x, q[j].y, m[j], clamp, ax, ay);
+        }
+      }
+      if (act) {
         resume = l.x;
         if (a.stats) { visits++; leaf_pairs += (unsigned long long)l.z; }
       }
       next = l.x;
     } else {
-      const T4 b = g0[i];
-      const T4 c = g1[i];
       bool descend = false;
       if (act) {
         const bool contains = p.y > b.y && p.x > b.x && p.x < b.z && p.y < b.w;  // bvh_tree.rs:15-20
@@ -165,7 +192,13 @@ __global__ __launch_bounds__(256) void tree_walk_wave(const WalkArgs<T> a) {
       }
       next = __builtin_amdgcn_ballot_w64(descend) != 0 ? i + 1 : l.x;
     }
-    i = __builtin_amdgcn_readfirstlane(next);
+    next = __builtin_amdgcn_readfirstlane(next);
+    if (PREFETCH && next == i + 1) {
+      l = ln; b = bn; c = cn;
+    } else if (next < n_nodes) {
+      l = lk[next]; b = g0[next]; c = g1[next];
+    }
+    i = next;
   }
   if (live) reinterpret_cast<T2*>(a.acc)[row] = T2{ax, ay};
   if (a.stats && live) {
@@ -209,8 +242,24 @@ __global__ __launch_bounds__(256) void integrate_inplace(void* pos, void* vel, c
 
 template <class T> hipError_t launch_tree_walk(hipStream_t s, const WalkArgs<T>& a, bool wave_uniform) {
   if (a.n_tgt <= 0) return hipSuccess;
-  if (wave_uniform) hipLaunchKernelGGL((tree_walk_wave<T>), dim3((unsigned)((a.n_tgt + 255) / 256)), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((tree_walk<T>), dim3((unsigned)((a.n_tgt + 255) / 256)), dim3(256), 0, s, a);
+  const dim3 grid((unsigned)((a.n_tgt + 255) / 256));
+  if (!wave_uniform) {
+    hipLaunchKernelGGL((tree_walk<T>), grid, dim3(256), 0, s, a);
+    return hipGetLastError();
+  }
+  // leaf batch / successor prefetch, measured in profiles/r01_walk_kernels_ab.txt: big leaves (BVH, 64) want 8
+  // particles per fetch, small ones (quad, <= 8) 4; prefetching node i+1 never pays (the walk is bound by the
+  // IEEE divides of the as-written pair function, not by scalar-load latency)
+  const int env_lb = getenv("NBODY_WALK_LB") ? atoi(getenv("NBODY_WALK_LB")) : 0;
+  const int env_pf = getenv("NBODY_WALK_PREFETCH") ? atoi(getenv("NBODY_WALK_PREFETCH")) : -1;
+  const int lb = env_lb ? env_lb : (a.big_leaves ? 8 : 4);
+  const bool pf = env_pf >= 0 ? env_pf != 0 : false;
+#define NB_W(L, P) hipLaunchKernelGGL((tree_walk_wave<T, L, P>), grid, dim3(256), 0, s, a)
+  if (lb >= 8) { if (pf) NB_W(8, true); else NB_W(8, false); }
+  else if (lb >= 4) { if (pf) NB_W(4, true); else NB_W(4, false); }
+  else if (lb >= 2) { if (pf) NB_W(2, true); else NB_W(2, false); }
+  else { if (pf) NB_W(1, true); else NB_W(1, false); }
+#undef NB_W
   return hipGetLastError();
 }
 template <class T> hipError_t launch_gather(hipStream_t s, const GatherArgs<T>& a) {

@@ -5,8 +5,9 @@ dx*dx + dy*dy and the accumulation into FMAs, and sums the sources in 4 x gsplit
 Each term carries a relative error of a few ulp (<= ~4 * 2^-24); the dominant error of BOTH the GPU and the
 reference is f32 summation: once a near neighbour has put a large term into the accumulator, every later
 addition rounds at that magnitude.  Measured on MI355X at N = 65 536 (tests/test_gpu_direct.py::test_config2):
-the reference's own single sequential f32 chain deviates from the exactly accumulated sum by up to 5.9e-4 of
-sum_j |term_j|, the GPU's shorter chains by up to 7.7e-5 (median 2e-7, 99th percentile 1.8e-6).
+the reference's own single sequential f32 chain deviates from the exactly accumulated sum by up to 6.9e-4 of
+sum_j |term_j|, the GPU (two-level summation over 256-source blocks) by up to 2.6e-6 (median 3.6e-8); at N = 1M,
+4 096 sampled targets: reference order up to 5.0e-3, GPU up to 1.7e-6.
 
 With  a_ref64 = every term evaluated in f32 exactly as main.rs:252 writes it, accumulated in double,
       a_cpu32 = the reference order: the same terms accumulated sequentially in f32 (ascending j),

@@ -206,3 +206,20 @@ def test_device_quad_points_outside_root_cell(nb, orc, ctx):
     o = orc.Quad(pos).flat()
     for k in ("geom", "mass", "is_leaf", "first", "count", "skip", "order"):
         assert np.array_equal(t[k], getattr(o, k)), k
+
+
+def test_cpp_world_mirror_headless_driver(nb):
+    """csrc/world.hpp + csrc/nbody_run.cpp: the C++ host mirror of World::update over the C ABI runs the reference's
+    scene and prints the reference's once-a-second block (main.rs:149-156)."""
+    import os
+    import re
+    import subprocess
+    exe = os.path.join(os.path.dirname(nb._capi.LIB_PATH), "nbody_run")
+    if not os.path.exists(exe):
+        pytest.skip("nbody_run not built")
+    r = subprocess.run([exe, "5", "bvh", "12345"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    m = re.search(r"len: (\d+)", r.stdout)
+    assert m and 140000 < int(m.group(1)) < 165000          # 2 heavy + ~51k lattice + 100 000 (main.rs:343)
+    assert "step: 5" in r.stdout and "Counting { build_bvh:" in r.stdout
+    assert "centroid after 5 steps" in r.stdout

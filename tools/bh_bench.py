@@ -65,8 +65,11 @@ def case(name, pos, vel, w, kind, theta, steps=3, cpu=True, cpu_steps=1):
 
 
 if __name__ == "__main__":
+    quick = len(sys.argv) > 1 and sys.argv[1] == "quick"
     pos, vel, w = nb.scenes.galaxy()
     case("reference scene (World::new, seeded), theta 50", pos, vel, w, C.TREE_BVH, 50.0, steps=5)
+    if quick:
+        sys.exit(0)
     case("reference scene, theta 0.5", pos, vel, w, C.TREE_BVH, 0.5, steps=5)
     pos, vel, w = nb.scenes.plummer(1 << 20, seed=0x5EED0003)
     case("plummer 1M bvh theta 50 (the reference's theta)", pos, vel, w, C.TREE_BVH, 50.0, steps=3)

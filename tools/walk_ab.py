@@ -5,10 +5,23 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import nbody_simulation_amd as nb
 C = nb._capi
 
+VARIANTS = [("per-thread", {"NBODY_WALK_PER_THREAD": "1"})] + [
+    (f"wave lb={lb} pf={pf}", {"NBODY_WALK_PER_THREAD": "0", "NBODY_WALK_LB": str(lb), "NBODY_WALK_PREFETCH": str(pf)})
+    for lb in (1, 2, 4, 8) for pf in (0, 1)]
+
+
 def run(name, pos, vel, w, kind, theta, order=C.ORDER_CONSISTENT):
+    import subprocess
+    out = []
+    for vname, env in VARIANTS:
+        e = dict(os.environ); e.update(env); e["WALK_AB_CHILD"] = "1"
+        out.append((vname, env))
     res = {}
-    for mode in ("1", "0", "1", "0"):
-        os.environ["NBODY_WALK_PER_THREAD"] = mode
+    for vname, env in VARIANTS * 2:
+        for k in ("NBODY_WALK_PER_THREAD", "NBODY_WALK_LB", "NBODY_WALK_PREFETCH"):
+            os.environ.pop(k, None)
+        os.environ.update(env)
+        mode = vname
         with C.Context(0) as ctx:
             ctx.set_params(theta=theta, order=order)
             ctx.upload(pos, vel, w)
@@ -17,7 +30,7 @@ def run(name, pos, vel, w, kind, theta, order=C.ORDER_CONSISTENT):
             ctx.update_tree(kind, 0.1, 3)
             ms, _ = t.read()
             res.setdefault(mode, []).append(ms)
-    print(f"{name}: per-thread {min(res['1']):.3f} ms, wave-uniform {min(res['0']):.3f} ms, x{min(res['1'])/min(res['0']):.2f}", flush=True)
+    print(name + ": " + " | ".join(f"{k} {min(v):.3f}" for k, v in res.items()), flush=True)
 
 pos, vel, w = nb.scenes.galaxy()
 run("reference scene bvh theta 50 (as written)", pos, vel, w, C.TREE_BVH, 50.0, C.ORDER_AS_WRITTEN)
