@@ -557,6 +557,7 @@ int tree_walk_phase(nbody_ctx* c, State<T>& s, int kind, const void* tgt_pos, in
   w.geom0 = s.geom0; w.geom1 = s.geom1; w.link = s.link;
   w.n_nodes = s.n_nodes;
   w.big_leaves = kind == NBODY_TREE_BVH && c->params.leaf_size >= 16;
+  w.fast = c->params.arith == NBODY_ARITH_FAST;  // AUTO and EXACT walk with the reference's operations
   w.theta = (T)c->params.theta;
   w.clamp = (T)c->params.clamp;
   w.acc = acc;

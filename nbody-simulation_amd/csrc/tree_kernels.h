@@ -18,6 +18,7 @@ template <class T> struct WalkArgs {
   void* acc;              // T2[*] indexed like tgt_pos
   T theta, clamp;
   unsigned long long* stats;  // optional [3]: node visits, accepted nodes, leaf pairs
+  int fast;                   // FAST pair arithmetic (one reciprocal) instead of the as-written IEEE divides
   int big_leaves;             // leaves hold tens of particles (BVH) rather than a handful (quad)
 };
 

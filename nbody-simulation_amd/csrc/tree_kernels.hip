@@ -51,6 +51,37 @@ __device__ __forceinline__ void pair_as_written<float>(float px, float py, float
   ay = ay + (dy * force) / den;
 }
 
+// FAST pair for the walk (opt-in, nbody_arith FAST): one reciprocal instead of two IEEE divisions, fused
+// multiply-adds; a zero difference contributes exactly 0 through the biased denominator (direct_kernels.hip).  The
+// node tests are untouched, so a target interacts with exactly the reference's list of nodes and particles; only
+// the rounding of each term differs (tolerance of tests/_tol.py, not bit parity).
+__device__ __forceinline__ void pair_fast(float px, float py, float qx, float qy, float force, float clamp, float& ax,
+                                          float& ay) {
+  float dx = qx - px, dy = qy - py;
+  float sum = __builtin_fabsf(dx) + __builtin_fabsf(dy);
+  float d2 = __builtin_fmaxf(__builtin_fmaf(dy, dy, dx * dx), clamp);
+  float s = force * __builtin_amdgcn_rcpf(__builtin_fmaf(sum, d2, 8.0779356694631609e-28f));  // 2^-90
+  ax = __builtin_fmaf(dx, s, ax);
+  ay = __builtin_fmaf(dy, s, ay);
+}
+__device__ __forceinline__ void pair_fast(double px, double py, double qx, double qy, double force, double clamp,
+                                          double& ax, double& ay) {
+  double dx = qx - px, dy = qy - py;
+  double sum = __builtin_fabs(dx) + __builtin_fabs(dy);
+  double d2 = __builtin_fmax(__builtin_fma(dy, dy, dx * dx), clamp);
+  double den = __builtin_fma(sum, d2, 0x1p-700);
+  double r = __builtin_amdgcn_rcp(den);          // ~27 bits
+  r = __builtin_fma(__builtin_fma(-den, r, 1.0), r, r);   // Newton: ~54 bits
+  double s = force * r;
+  ax = __builtin_fma(dx, s, ax);
+  ay = __builtin_fma(dy, s, ay);
+}
+template <class T, bool FAST>
+__device__ __forceinline__ void walk_pair(T px, T py, T qx, T qy, T force, T clamp, T& ax, T& ay) {
+  if constexpr (FAST) pair_fast(px, py, qx, qy, force, clamp, ax, ay);
+  else pair_as_written<T>(px, py, qx, qy, force, clamp, ax, ay);
+}
+
 // One thread per target.  tgt_index (optional) maps thread t to the target's row: targets are visited in tree
 // order so the lanes of a wave share most of their path, and results are scattered back to acc[row].
 template <class T>
@@ -113,7 +144,7 @@ __global__ __launch_bounds__(256) void tree_walk(const WalkArgs<T> a) {
 // reduction: sleeping lanes resume at or after skip[i] (their sleeping subtree contains node i), therefore
 //     next = any(acting lane descends) ? i + 1 : skip[i].
 // The wave visits the union of its lanes' paths; targets are handed out in tree order so that union stays small.
-template <class T, int LB, bool PREFETCH>
+template <class T, int LB, bool PREFETCH, bool FAST>
 __global__ __launch_bounds__(256) void tree_walk_wave(const WalkArgs<T> a) {
   using T2 = typename V2<T>::type;
   using T4 = typename V4<T>::type;
@@ -166,7 +197,7 @@ __global__ __launch_bounds__(256) void tree_walk_wave(const WalkArgs<T> a) {
         if (act) {
 #pragma unroll
           for (int j = 0; j < LB; ++j)
-            if (k0 + j < end) pair_as_written<T>(p.x, p.y, q[j].x, q[j].y, m[j], clamp, ax, ay);
+            if (k0 + j < end) walk_pair<T, FAST>(p.x, p.y, q[j].x, q[j].y, m[j], clamp, ax, ay);
         }
       }
       if (act) {
@@ -181,7 +212,7 @@ __global__ __launch_bounds__(256) void tree_walk_wave(const WalkArgs<T> a) {
         const T ddx = p.x - c.x, ddy = p.y - c.y;
         const T d2 = ddx * ddx + ddy * ddy;                                        // main.rs:228-232
         if (!contains && c.w < d2 * theta * theta) {                               // :370-372
-          pair_as_written<T>(p.x, p.y, c.x, c.y, c.z, clamp, ax, ay);              // :374-379
+          walk_pair<T, FAST>(p.x, p.y, c.x, c.y, c.z, clamp, ax, ay);              // :374-379
           resume = l.x;
           if (a.stats) accepted++;
         } else {
@@ -254,11 +285,11 @@ template <class T> hipError_t launch_tree_walk(hipStream_t s, const WalkArgs<T>&
   const int env_pf = getenv("NBODY_WALK_PREFETCH") ? atoi(getenv("NBODY_WALK_PREFETCH")) : -1;
   const int lb = env_lb ? env_lb : (a.big_leaves ? 8 : 4);
   const bool pf = env_pf >= 0 ? env_pf != 0 : false;
-#define NB_W(L, P) hipLaunchKernelGGL((tree_walk_wave<T, L, P>), grid, dim3(256), 0, s, a)
+#define NB_W(L, P) do { if (a.fast) hipLaunchKernelGGL((tree_walk_wave<T, L, P, true>), grid, dim3(256), 0, s, a); \
+                        else hipLaunchKernelGGL((tree_walk_wave<T, L, P, false>), grid, dim3(256), 0, s, a); } while (0)
   if (lb >= 8) { if (pf) NB_W(8, true); else NB_W(8, false); }
   else if (lb >= 4) { if (pf) NB_W(4, true); else NB_W(4, false); }
-  else if (lb >= 2) { if (pf) NB_W(2, true); else NB_W(2, false); }
-  else { if (pf) NB_W(1, true); else NB_W(1, false); }
+  else { if (pf) NB_W(2, true); else NB_W(2, false); }
 #undef NB_W
   return hipGetLastError();
 }

@@ -223,3 +223,29 @@ def test_cpp_world_mirror_headless_driver(nb):
     assert m and 140000 < int(m.group(1)) < 165000          # 2 heavy + ~51k lattice + 100 000 (main.rs:343)
     assert "step: 5" in r.stdout and "Counting { build_bvh:" in r.stdout
     assert "centroid after 5 steps" in r.stdout
+
+
+@pytest.mark.parametrize("dtype,kind", [(np.float32, "bvh"), (np.float32, "quad"), (np.float64, "quad")])
+def test_fast_walk_is_within_tolerance_of_the_exact_walk(nb, orc, ctx, dtype, kind):
+    """arith = FAST on a tree: same node tests and interaction lists, one reciprocal per pair.  Not bit parity: the
+    per-target error must stay within 2e-5 of sum|term| (f32) / 1e-12 (f64) of the reference walk."""
+    C = nb._capi
+    n = 20000
+    pos, vel, _ = nb.scenes.plummer(n, seed=93, dtype=dtype)
+    pos[10] = pos[11]                                   # a coincident pair inside one leaf
+    w = (np.arange(n) % 4 + 1).astype(np.uint32)
+    k = C.TREE_BVH if kind == "bvh" else C.TREE_QUAD
+    ctx.set_params(theta=0.5, arith=C.ARITH_FAST)
+    ctx.upload(pos, vel, w)
+    fast = ctx.accel_tree(k, pos)
+    ctx.set_params(arith=C.ARITH_AUTO)
+    ctx.upload(pos, vel, w)
+    exact = ctx.accel_tree(k, pos)
+    tree = orc.BVH(pos, w) if kind == "bvh" else orc.Quad(pos, w)
+    assert np.array_equal(exact, tree.walk(pos, theta=0.5, nthreads=8))
+    assert np.all(np.isfinite(fast)) and not np.array_equal(fast, exact)
+    # scale: the direct-sum norm bounds the walk's sum of |term| from above for the particle part; use |a| + norm/N
+    _, norm = orc.direct_accel(pos.astype(np.float32), w, targets=np.arange(0, n, 50), accum="f64", nthreads=8)
+    err = np.abs(fast[::50].astype(np.float64) - exact[::50]).sum(axis=1)
+    tol = 2e-5 if dtype == np.float32 else 1e-12
+    assert np.all(err <= tol * norm), float((err / norm).max())

@@ -5,31 +5,22 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import nbody_simulation_amd as nb
 C = nb._capi
 
-VARIANTS = [("per-thread", {"NBODY_WALK_PER_THREAD": "1"})] + [
-    (f"wave lb={lb} pf={pf}", {"NBODY_WALK_PER_THREAD": "0", "NBODY_WALK_LB": str(lb), "NBODY_WALK_PREFETCH": str(pf)})
-    for lb in (1, 2, 4, 8) for pf in (0, 1)]
+VARIANTS = [("per-thread exact", {"NBODY_WALK_PER_THREAD": "1", "ARITH": "0"}), ("wave exact", {"NBODY_WALK_PER_THREAD": "0", "ARITH": "0"}),
+            ("wave FAST", {"NBODY_WALK_PER_THREAD": "0", "ARITH": "1"})]
 
 
 def run(name, pos, vel, w, kind, theta, order=C.ORDER_CONSISTENT):
-    import subprocess
-    out = []
-    for vname, env in VARIANTS:
-        e = dict(os.environ); e.update(env); e["WALK_AB_CHILD"] = "1"
-        out.append((vname, env))
     res = {}
     for vname, env in VARIANTS * 2:
-        for k in ("NBODY_WALK_PER_THREAD", "NBODY_WALK_LB", "NBODY_WALK_PREFETCH"):
-            os.environ.pop(k, None)
-        os.environ.update(env)
-        mode = vname
+        os.environ["NBODY_WALK_PER_THREAD"] = env["NBODY_WALK_PER_THREAD"]
         with C.Context(0) as ctx:
-            ctx.set_params(theta=theta, order=order)
+            ctx.set_params(theta=theta, order=order, arith=int(env["ARITH"]))
             ctx.upload(pos, vel, w)
             ctx.update_tree(kind, 0.1, 1)
             t = C.Timer(); ctx.set_timer(t)
             ctx.update_tree(kind, 0.1, 3)
             ms, _ = t.read()
-            res.setdefault(mode, []).append(ms)
+            res.setdefault(vname, []).append(ms)
     print(name + ": " + " | ".join(f"{k} {min(v):.3f}" for k, v in res.items()), flush=True)
 
 pos, vel, w = nb.scenes.galaxy()
