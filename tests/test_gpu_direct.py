@@ -312,3 +312,36 @@ def test_nearfar_hazard_still_routes_to_exact(nb, orc):
     assert hazard == 1 and state == 2
     ref, _ = orc.direct_accel(pos, w, nthreads=8)
     assert np.array_equal(acc, ref.astype(F32), equal_nan=True)
+
+
+def test_config5_shard_slice_of_16M(nb, orc):
+    """BASELINE config 5 (16 777 216 bodies sharded over 8 GPUs): on the one GPU of the test box, a slice of rank 5's
+    target shard against all 16.7 M sources through the device-pointer API, checked against the oracle on sampled
+    targets.  Exercises the 16.7 M-source indexing, the near/far split at that size and a mid-array target_begin."""
+    import torch
+    C = nb._capi
+    n = 1 << 24
+    pos, vel, w = nb.scenes.plummer(n, seed=0x5EED0005)
+    dev = torch.device("cuda:0")
+    tp = torch.from_numpy(pos).to(dev)
+    tm = torch.ones(n, dtype=torch.float32, device=dev)
+    begin, cnt = 5 * (n // 8) + 12345, 8192
+    tv = torch.from_numpy(vel[begin:begin + cnt].copy()).to(dev)
+    out = torch.empty((cnt, 2), dtype=torch.float32, device=dev)
+    acc = torch.empty((cnt, 2), dtype=torch.float32, device=dev)
+    ws_bytes = C.direct_workspace_bytes(n, cnt)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    C.direct_step_dev(stream, n, tp.data_ptr(), tm.data_ptr(), begin, cnt, tv.data_ptr(), out.data_ptr(), acc.data_ptr(),
+                      0.1, 0.001, C.ARITH_AUTO, ws.data_ptr(), ws_bytes, uniform_mass=1.0)
+    torch.cuda.synchronize()
+    hazard, fallback, n_near, state = C.direct_workspace_peek(stream, ws.data_ptr())
+    assert (hazard, state) == (0, 0) and 0 < n_near < n // 64      # the dense core has neighbours within sqrt(clamp)
+    a = acc.cpu().numpy()
+    tg = np.arange(begin, begin + cnt, 128)
+    rg, rc = check_fast(a[::128], *_refs(orc, pos, w, targets=tg), label=" 16M")
+    # integrate: the reference's multiply-then-add, bit exact given the accelerations
+    dt = F32(0.1)
+    v_exp = vel[begin:begin + cnt] + a * dt
+    assert np.array_equal(tv.cpu().numpy(), v_exp)
+    assert np.array_equal(out.cpu().numpy(), pos[begin:begin + cnt] + v_exp * dt)

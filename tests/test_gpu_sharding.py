@@ -72,3 +72,20 @@ def test_single_rank_stepper_equals_context_path(nb):
         ctx.update_direct(0.1, 4)
         cp, cv, _, _ = ctx.download()
     assert np.array_equal(p, cp) and np.array_equal(v, cv)
+
+
+def test_bench_two_rank_rehearsal_via_torchrun():
+    """bench.py exactly as the driver launches it for N > 1 (torch.distributed.run, one process per rank), rehearsed
+    with 2 ranks sharing the test box's one GPU and gloo standing in for RCCL."""
+    import json
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--n", "65536", "--backend", "gloo"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "strong" and d["unit"] == "pair-interactions/s"
+    assert d["config"]["targets_per_gpu"] == 32768 and d["value"] > 0 and d["roofline"]["frac"] > 0
+    assert "cpu_baseline" not in d            # rank 0 at N = 1 only
