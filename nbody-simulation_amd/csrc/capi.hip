@@ -111,7 +111,34 @@ template <class T> struct State {
 
 }  // namespace
 
+// Two consecutive direct steps (A -> B -> A position buffers) captured once as a hipGraph and replayed: a small-N step
+// is ~15 launches (hazard scan, near/far split, gated kernels), i.e. launch-bound (N = 1024: 78 us per eager step
+// against 13 us of kernels).  The graph is rebuilt when anything it baked in changes.
+struct DirectGraph {
+  hipGraphExec_t exec = nullptr;
+  int64_t n = -1;
+  const void *pos_a = nullptr, *pos_b = nullptr, *vel = nullptr, *mass = nullptr, *ws = nullptr;
+  float delta = 0.f, clamp = 0.f, uniform = 0.f;
+  int arith = -1;
+  std::string env;  // the NBODY_DIRECT_* switches read at capture time
+  void reset() {
+    if (exec) (void)hipGraphExecDestroy(exec);
+    exec = nullptr;
+    n = -1;
+  }
+};
+static inline std::string direct_env_signature() {
+  std::string sig;
+  for (const char* k : {"NBODY_DIRECT_ASM", "NBODY_DIRECT_NEARFAR", "NBODY_DIRECT_TPT", "NBODY_DIRECT_GSPLIT", "NBODY_DIRECT_NO_UNIFORM"}) {
+    const char* v = getenv(k);
+    sig += v ? v : "-";
+    sig += ';';
+  }
+  return sig;
+}
+
 struct nbody_ctx {
+  DirectGraph direct_graph;
   int device = 0;
   hipStream_t stream = nullptr;
   std::string err;
@@ -179,7 +206,10 @@ int env_int(const char* name, int dflt) {
 DirectConfig choose_direct_config(int64_t n_src, int64_t n_tgt, bool uniform = true) {
   DirectConfig c;
   c.use_asm = env_int("NBODY_DIRECT_ASM", 1) != 0;
-  c.nearfar = env_int("NBODY_DIRECT_NEARFAR", 1) != 0;
+  // near/far split: ~0.1-0.3 ms of preparation per step against 10 % of the pair work, break-even measured at
+  // 65536 x 65536 pairs (profiles/r01_small_n_steps.txt).  NBODY_DIRECT_NEARFAR: 0 never, 1 by size (default), 2 always.
+  const int nf = env_int("NBODY_DIRECT_NEARFAR", 1);
+  c.nearfar = nf == 2 || (nf == 1 && (double)n_src * (double)n_tgt >= 8589934592.0);
   // measured at N = 1M (profiles/r01_direct_mass_variants.txt): 1 target/thread with the hand-ordered block wins for
   // equal masses (44.0 %) and for per-body masses (39.8 % vs 36.1 % for 2 targets/thread)
   (void)uniform;
@@ -317,6 +347,7 @@ template <class T> int upload(nbody_ctx* c, int64_t n, const T* pos, const T* ve
   if (!c) return NBODY_ERR_INVALID;
   if (n < 0 || n > 0x7fffffffLL || (n > 0 && (!pos || !vel))) return fail(c, NBODY_ERR_INVALID, "upload: bad arguments");
   HIPCHK(c, hipSetDevice(c->device));
+  c->direct_graph.reset();
   free_state(c->sf);
   free_state(c->sd);
   c->has_f32 = c->has_f64 = false;
@@ -751,6 +782,7 @@ NB_API void nbody_destroy(nbody_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  c->direct_graph.reset();
   free_state(c->sf);
   free_state(c->sd);
   free_dev(c->workspace);
@@ -800,19 +832,57 @@ NB_API int nbody_update_direct_f32(nbody_ctx* c, float delta, int n_steps, nbody
   State<float>& s = c->sf;
   int rc = ensure_workspace(c, direct_ws_bytes(s.n, s.n));
   if (rc) return rc;
-  for (int step = 0; step < n_steps; ++step) {
-    double t0 = now_s();
+  const double t_begin = now_s();
+  int step = 0;
+  // ---- graph replay of step pairs (no timer attached: event records do not belong in a captured graph)
+  const bool want_graph = n_steps >= 4 && s.n > 0 && s.n <= (1 << 17) && !c->timer && env_int("NBODY_DIRECT_GRAPH", 1) != 0;
+  if (want_graph) {
+    auto& st = s.set[s.cur];
+    DirectGraph& g = c->direct_graph;
+    const std::string sig = direct_env_signature();
+    const bool stale = !g.exec || g.n != s.n || g.pos_a != st.pos || g.pos_b != s.pos_next || g.vel != st.vel ||
+                       g.mass != st.mass || g.ws != c->workspace || g.delta != delta || g.clamp != c->params.clamp ||
+                       g.uniform != s.uniform_mass || g.arith != c->params.arith || g.env != sig;
+    if (stale) {
+      g.reset();
+      hipGraph_t graph = nullptr;
+      hipError_t e = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal);
+      int rc1 = NBODY_OK, rc2 = NBODY_OK;
+      if (e == hipSuccess) {
+        rc1 = direct_step_dev(c, c->stream, s.n, st.pos, st.mass, s.uniform_mass, 0, s.n, st.vel, s.pos_next, nullptr, delta,
+                              c->params.clamp, c->params.arith, c->workspace, c->workspace_bytes, nullptr);
+        if (!rc1)
+          rc2 = direct_step_dev(c, c->stream, s.n, s.pos_next, st.mass, s.uniform_mass, 0, s.n, st.vel, st.pos, nullptr, delta,
+                                c->params.clamp, c->params.arith, c->workspace, c->workspace_bytes, nullptr);
+        e = hipStreamEndCapture(c->stream, &graph);
+      }
+      if (e == hipSuccess && !rc1 && !rc2 && graph) e = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0);
+      if (graph) (void)hipGraphDestroy(graph);
+      if (e != hipSuccess || rc1 || rc2 || !g.exec) {
+        g.reset();  // capture is an optimisation: fall through to eager steps
+        (void)hipGetLastError();
+      } else {
+        g.n = s.n; g.pos_a = st.pos; g.pos_b = s.pos_next; g.vel = st.vel; g.mass = st.mass; g.ws = c->workspace;
+        g.delta = delta; g.clamp = c->params.clamp; g.uniform = s.uniform_mass; g.arith = c->params.arith; g.env = sig;
+      }
+    }
+    if (g.exec) {
+      for (; step + 2 <= n_steps; step += 2) HIPCHK(c, hipGraphLaunch(g.exec, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));  // an even number of steps: positions are back in st.pos
+    }
+  }
+  for (; step < n_steps; ++step) {
     auto& st = s.set[s.cur];
     rc = direct_step_dev(c, c->stream, s.n, st.pos, st.mass, s.uniform_mass, 0, s.n, st.vel, s.pos_next, nullptr, delta,
                          c->params.clamp, c->params.arith, c->workspace, c->workspace_bytes, c->timer);
     if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     std::swap(st.pos, s.pos_next);
-    double t1 = now_s();
-    // force and integrate are one fused kernel: the whole step is booked under sum_gravity
-    c->counting.sum_gravity += t1 - t0;
-    if (counter) counter->sum_gravity += t1 - t0;
   }
+  // force and integrate are one fused kernel: the whole call is booked under sum_gravity
+  const double dt = now_s() - t_begin;
+  c->counting.sum_gravity += dt;
+  if (counter) counter->sum_gravity += dt;
   s.tree_valid = false;
   return NBODY_OK;
 }

@@ -241,7 +241,20 @@ def _dev_accel(nb, pos, w, arith=None, uniform=0.0):
     return acc.cpu().numpy(), C.direct_workspace_peek(stream, ws.data_ptr())
 
 
-def test_nearfar_split_with_close_pairs_and_clusters(nb, orc):
+@pytest.fixture
+def force_nearfar(monkeypatch):
+    """The split is chosen by problem size (>= 2^33 pairs); these tests force it on small inputs."""
+    monkeypatch.setenv("NBODY_DIRECT_NEARFAR", "2")
+
+
+def test_nearfar_is_chosen_by_size(nb):
+    n = 4096
+    pos, vel, w = nb.scenes.plummer(n, seed=80)
+    _, (_, _, _, state) = _dev_accel(nb, pos, w)
+    assert state == 1                       # small problem: the single clamped pass (the split would cost more than it saves)
+
+
+def test_nearfar_split_with_close_pairs_and_clusters(nb, orc, force_nearfar):
     """Bodies closer than sqrt(clamp) = 0.0316 (pairs, a tight cluster, exact duplicates) must be found 'near' and
     summed with the clamp; everything else goes through the clamp-free main pass.  Same tolerance as ever."""
     n = 30000
@@ -265,7 +278,7 @@ def test_nearfar_split_with_close_pairs_and_clusters(nb, orc):
     assert np.all(np.abs(acc[[1000, 2000, 3000, 4000, 6000, 6039, 7000, 8000]] - ref64).sum(axis=1) <= 2e-5 * norm)
 
 
-def test_nearfar_uniform_mass_path(nb, orc):
+def test_nearfar_uniform_mass_path(nb, orc, force_nearfar):
     n = 20000
     pos, vel, w = nb.scenes.plummer(n, seed=82)
     pos[10] = pos[11] + F32(0.005)
@@ -274,7 +287,7 @@ def test_nearfar_uniform_mass_path(nb, orc):
     check_fast(acc, *_refs(orc, pos, w))
 
 
-def test_nearfar_falls_back_when_dense_or_out_of_range(nb, orc):
+def test_nearfar_falls_back_when_dense_or_out_of_range(nb, orc, force_nearfar):
     rng = np.random.default_rng(5)
     n = 4096
     dense = (F32(50000.0) + rng.random((n, 2)).astype(F32) * F32(0.5)).astype(F32)   # everything within 0.5 x 0.5
@@ -293,6 +306,7 @@ def test_nearfar_off_gives_the_same_answer_within_tolerance(nb, orc, monkeypatch
     n = 16384
     pos, vel, w = nb.scenes.plummer(n, seed=84)
     pos[100] = pos[200] + F32(0.004)
+    monkeypatch.setenv("NBODY_DIRECT_NEARFAR", "2")
     a_on, st_on = _dev_accel(nb, pos, w, uniform=1.0)
     monkeypatch.setenv("NBODY_DIRECT_NEARFAR", "0")
     a_off, st_off = _dev_accel(nb, pos, w, uniform=1.0)
@@ -304,7 +318,7 @@ def test_nearfar_off_gives_the_same_answer_within_tolerance(nb, orc, monkeypatch
     assert np.abs(a_on - a_off).sum(axis=1).max() <= 2e-5 * norm.max()
 
 
-def test_nearfar_hazard_still_routes_to_exact(nb, orc):
+def test_nearfar_hazard_still_routes_to_exact(nb, orc, force_nearfar):
     n = 2048
     pos, vel, w = nb.scenes.plummer(n, seed=85)
     pos[5, 0] = np.nan
