@@ -210,8 +210,8 @@ __global__ void qb_totals(const uint32_t* __restrict__ cnt, const uint32_t* __re
   flags[1] = n > 0 ? (int)(base[n - 1] + cnt[n - 1]) : 1;
 }
 __global__ __launch_bounds__(256) void qb_max_depth(const int* __restrict__ ld, int n, int* __restrict__ flags) {
-  int r = blockIdx.x * 256 + threadIdx.x;
-  int v = r < n ? ld[r] : 0;
+  int v = 0;  // grid-stride: a few hundred atomics in all (one per wave of <= 512 blocks), not one per 64 particles
+  for (int r = blockIdx.x * 256 + threadIdx.x; r < n; r += gridDim.x * 256) { int w = ld[r]; v = w > v ? w : v; }
   for (int o = 32; o > 0; o >>= 1) { int w = __shfl_xor(v, o); v = w > v ? w : v; }
   if ((threadIdx.x & 63) == 0) atomicMax(&flags[2], v);
 }
@@ -301,7 +301,7 @@ hipError_t quad_build_phase_a(hipStream_t s, const void* pos, int n, T rx, T ry,
   e = hipcub::DeviceScan::ExclusiveSum(scratch + L.cub_temp, tb, cnt, base, n, s);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(qb_totals, dim3(1), dim3(1), 0, s, cnt, base, ld, n, flags);
-  hipLaunchKernelGGL(qb_max_depth, dim3(blocks), dim3(256), 0, s, ld, n, flags);
+  hipLaunchKernelGGL(qb_max_depth, dim3(blocks < 512 ? blocks : 512), dim3(256), 0, s, ld, n, flags);
   return hipGetLastError();
 }
 

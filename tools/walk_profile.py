@@ -1,0 +1,13 @@
+"""Config 4 (4 194 304 bodies, quad tree, theta 0.5, f64): a few steps, for rocprofv3."""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import nbody_simulation_amd as nb
+C = nb._capi
+pos, vel, w = nb.scenes.plummer(1 << 22, seed=0x5EED0004, dtype=np.float64)
+with C.Context(0) as ctx:
+    ctx.set_params(theta=0.5)
+    ctx.upload(pos, vel, w)
+    cnt = C.Counting()
+    ctx.update_tree(C.TREE_QUAD, 0.1, 4, cnt)
+    print("build %.2f ms walk %.2f ms integrate %.3f ms per step" % (cnt.build_bvh / 4 * 1e3, cnt.sum_gravity / 4 * 1e3, cnt.post_calculations / 4 * 1e3))
