@@ -78,8 +78,17 @@ template <class T> struct SubTree {
   }
 };
 
-constexpr int64_t kParallelMinLen = 8192;  // subtrees at least this big get their own thread ...
-constexpr int kParallelMaxDepth = 6;       // ... down to this depth (<= 2^6 concurrent BVH tasks)
+// subtrees at least kParallelMinLen big get their own thread, down to depth kParallelMaxDepth
+inline int64_t par_min_len() {
+  static const int64_t v = [] { const char* e = std::getenv("NBODY_BUILD_PAR_MINLEN"); return e ? std::atoll(e) : 8192LL; }();  // tuned on the GPU box, N = 151k
+  return v;
+}
+inline int par_max_depth() {
+  static const int v = [] { const char* e = std::getenv("NBODY_BUILD_PAR_DEPTH"); return e ? std::atoi(e) : 4; }();
+  return v;
+}
+#define kParallelMinLen par_min_len()
+#define kParallelMaxDepth par_max_depth()
 
 inline int build_threads() {
   if (const char* e = std::getenv("NBODY_BUILD_THREADS")) {
@@ -156,7 +165,9 @@ void bvh_rec(BvhPoint<T>* pts, int64_t first, int64_t len, int depth, bool leaf,
 }
 
 template <class F> void parallel_chunks(int64_t n, int threads, F f) {
-  if (threads <= 1 || n < 4096) { f(0, n); return; }
+  // a std::thread costs tens of microseconds to start: only worth it for >= 64k elements per thread
+  if (threads > n / 65536) threads = (int)(n / 65536);
+  if (threads <= 1) { f(0, n); return; }
   std::vector<std::thread> th;
   int64_t per = (n + threads - 1) / threads;
   for (int t = 0; t < threads; ++t) {
