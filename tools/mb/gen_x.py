@@ -1,6 +1,7 @@
 """Generates and builds a microbenchmark of whole inner-loop bodies (asm text) — wall clock, 8 waves/SIMD."""
 import re, sys, subprocess
-S = open('/tmp/k_uniform.s').read().split('\n')
+import os
+S = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'compiler_body_v1.s')).read().split('\n')  # hipcc's inner loop of direct_fast (v1, clamped, equal masses)
 start = next(i for i,l in enumerate(S) if '.LBB22_18:' in l)
 end = next(i for i,l in enumerate(S) if i > start and 's_cbranch_scc0 .LBB22_18' in l)
 raw = [l.strip() for l in S[start+1:end]]
