@@ -657,8 +657,6 @@ template <class T> int accel_tree(nbody_ctx* c, int kind, int64_t n_targets, con
   if (rc) return rc;
   if (!target_xy) {
     // particles themselves, post-build row order, regardless of params.order
-    WalkArgs<T> dummy{};
-    (void)dummy;
     const void* tp = s.set[s.cur].pos;
     int saved = c->params.order;
     c->params.order = NBODY_ORDER_CONSISTENT;
