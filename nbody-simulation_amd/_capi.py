@@ -62,6 +62,10 @@ _SIGS = {
     "nbody_update_direct_f32": (C.c_int, [_vp, _f32, _i32, C.POINTER(Counting)]),
     "nbody_update_tree_f32": (C.c_int, [_vp, _i32, _f32, _i32, C.POINTER(Counting)]),
     "nbody_update_tree_f64": (C.c_int, [_vp, _i32, _f64, _i32, C.POINTER(Counting)]),
+    "nbody_update_tree_shard_f32": (C.c_int, [_vp, _i32, _f32, _i64, _i64, C.POINTER(Counting)]),
+    "nbody_update_tree_shard_f64": (C.c_int, [_vp, _i32, _f64, _i64, _i64, C.POINTER(Counting)]),
+    "nbody_export_slice_dev": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _vp]),
+    "nbody_import_rows_dev": (C.c_int, [_vp, _i64, _vp, _vp, _vp]),
     "nbody_accel_direct_f32": (C.c_int, [_vp, _vp]),
     "nbody_accel_tree_f32": (C.c_int, [_vp, _i32, _i64, _vp, _vp]),
     "nbody_accel_tree_f64": (C.c_int, [_vp, _i32, _i64, _vp, _vp]),
@@ -287,6 +291,17 @@ class Context:
         f = self.lib.nbody_update_tree_f64 if self.dtype == np.float64 else self.lib.nbody_update_tree_f32
         check(self.h, f(self.h, int(kind), float(delta), int(n_steps),
                         C.byref(counter) if counter is not None else None))
+
+    def update_tree_shard(self, kind, delta, begin, count, counter: Counting | None = None):
+        f = self.lib.nbody_update_tree_shard_f64 if self.dtype == np.float64 else self.lib.nbody_update_tree_shard_f32
+        check(self.h, f(self.h, int(kind), float(delta), int(begin), int(count),
+                        C.byref(counter) if counter is not None else None))
+
+    def export_slice_dev(self, begin, count, rows_ptr, pos_ptr, vel_ptr):
+        check(self.h, self.lib.nbody_export_slice_dev(self.h, int(begin), int(count), _vp(rows_ptr), _vp(pos_ptr), _vp(vel_ptr)))
+
+    def import_rows_dev(self, n_rows, rows_ptr, pos_ptr, vel_ptr):
+        check(self.h, self.lib.nbody_import_rows_dev(self.h, int(n_rows), _vp(rows_ptr), _vp(pos_ptr), _vp(vel_ptr)))
 
     def accel_direct(self):
         acc = np.zeros((self.n, 2), np.float32)

@@ -99,6 +99,7 @@ template <class T> struct State {
   bool tree_valid = false;
   bool tree_host_stale = false;  // the last build ran on the device and has not been downloaded
   int n_nodes = 0, tree_kind = 0, tree_max_depth = 0;
+  int shard_kind = 0;            // tree kind of the last sharded step (decides how a slice maps to rows)
   int* node_depth = nullptr;     // device build: depth of every node
   uint32_t* node_mass = nullptr; // device build: u32 mass of every node
   size_t node_aux_cap = 0;
@@ -583,7 +584,9 @@ template <class T> int tree_build_phase(nbody_ctx* c, State<T>& s, int kind) {
 
 // Phase 2 (main.rs:406-416).  tgt_pos == nullptr: the particles themselves.
 template <class T>
-int tree_walk_phase(nbody_ctx* c, State<T>& s, int kind, const void* tgt_pos, int64_t n_tgt, void* acc) {
+int tree_walk_phase(nbody_ctx* c, State<T>& s, int kind, const void* tgt_pos, int64_t n_tgt, void* acc,
+                    int64_t slice_begin = 0, int64_t slice_count = -1) {
+  using T2w = typename State<T>::T2;
   WalkArgs<T> w{};
   w.geom0 = s.geom0; w.geom1 = s.geom1; w.link = s.link;
   w.n_nodes = s.n_nodes;
@@ -600,13 +603,21 @@ int tree_walk_phase(nbody_ctx* c, State<T>& s, int kind, const void* tgt_pos, in
     if (tgt_pos) { w.tgt_pos = tgt_pos; w.n_tgt = n_tgt; }
     else {
       // AS_WRITTEN: accelerations are computed for the snapshot's rows (main.rs:406-412 iterate `cloned`)
-      w.tgt_pos = (c->params.order == NBODY_ORDER_AS_WRITTEN) ? s.set[1 - s.cur].pos : s.set[s.cur].pos;
-      w.n_tgt = s.n;
+      const T2w* base = (c->params.order == NBODY_ORDER_AS_WRITTEN) ? s.set[1 - s.cur].pos : s.set[s.cur].pos;
+      if (slice_count >= 0) {  // a contiguous block of rows (tree order = row order after the build's permutation)
+        w.tgt_pos = base + slice_begin;
+        w.acc = (T2w*)acc + slice_begin;
+        w.n_tgt = slice_count;
+      } else {
+        w.tgt_pos = base;
+        w.n_tgt = s.n;
+      }
     }
   } else {
     w.leaf_pos = s.set[1 - s.cur].pos;
     w.leaf_mass = s.set[1 - s.cur].mass;
     if (tgt_pos) { w.tgt_pos = tgt_pos; w.n_tgt = n_tgt; }
+    else if (slice_count >= 0) { w.tgt_pos = s.set[s.cur].pos; w.n_tgt = slice_count; w.tgt_index = s.order_dev + slice_begin; }
     else { w.tgt_pos = s.set[s.cur].pos; w.n_tgt = s.n; w.tgt_index = s.order_dev; }
   }
   {
@@ -643,6 +654,58 @@ template <class T> int update_tree(nbody_ctx* c, int kind, T delta, int n_steps,
     c->counting.post_calculations += t3 - t2;
     if (counter) { counter->build_bvh += t1 - t0; counter->sum_gravity += t2 - t1; counter->post_calculations += t3 - t2; }
   }
+  return NBODY_OK;
+}
+
+// One tree step of a rank that owns the slice [begin, begin+count) of the tree-ordered targets: the tree is built over
+// ALL particles (every rank holds them all and builds the same tree), the walk and the integration touch only the slice.
+template <class T> int update_tree_shard(nbody_ctx* c, int kind, T delta, int64_t begin, int64_t count, nbody_counting* counter) {
+  if (!c) return NBODY_ERR_INVALID;
+  if (!has_state<T>(c)) return fail(c, NBODY_ERR_INVALID, "update_tree_shard: no particles of this precision uploaded");
+  State<T>& s = state_of<T>(c);
+  if (begin < 0 || count < 0 || begin + count > s.n) return fail(c, NBODY_ERR_INVALID, "update_tree_shard: slice out of range");
+  HIPCHK(c, hipSetDevice(c->device));
+  double t0 = now_s();
+  int rc = tree_build_phase<T>(c, s, kind);
+  if (rc) return rc;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  double t1 = now_s();
+  rc = tree_walk_phase<T>(c, s, kind, nullptr, 0, s.acc, begin, count);
+  if (rc) return rc;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  double t2 = now_s();
+  const uint32_t* rows = kind == NBODY_TREE_QUAD ? s.order_dev + begin : nullptr;
+  HIPCHK(c, launch_integrate_rows<T>(c->stream, s.set[s.cur].pos, s.set[s.cur].vel, s.acc, rows, begin, count, delta));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  double t3 = now_s();
+  c->counting.build_bvh += t1 - t0; c->counting.sum_gravity += t2 - t1; c->counting.post_calculations += t3 - t2;
+  if (counter) { counter->build_bvh += t1 - t0; counter->sum_gravity += t2 - t1; counter->post_calculations += t3 - t2; }
+  s.shard_kind = kind;
+  return NBODY_OK;
+}
+template <class T>
+int export_slice(nbody_ctx* c, int64_t begin, int64_t count, void* rows_dev, void* pos_dev, void* vel_dev) {
+  if (!c) return NBODY_ERR_INVALID;
+  if (!has_state<T>(c)) return fail(c, NBODY_ERR_INVALID, "export_slice: no particles of this precision uploaded");
+  State<T>& s = state_of<T>(c);
+  if (!s.tree_valid) return fail(c, NBODY_ERR_INVALID, "export_slice: no tree step yet");
+  if (begin < 0 || count < 0 || begin + count > s.n || !rows_dev || !pos_dev || !vel_dev)
+    return fail(c, NBODY_ERR_INVALID, "export_slice: bad arguments");
+  HIPCHK(c, hipSetDevice(c->device));
+  const uint32_t* rows = s.shard_kind == NBODY_TREE_QUAD ? s.order_dev + begin : nullptr;
+  HIPCHK(c, launch_export_rows<T>(c->stream, s.set[s.cur].pos, s.set[s.cur].vel, rows, begin, count, (uint32_t*)rows_dev, pos_dev, vel_dev));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return NBODY_OK;
+}
+template <class T> int import_rows_api(nbody_ctx* c, int64_t n_rows, const void* rows_dev, const void* pos_dev, const void* vel_dev) {
+  if (!c) return NBODY_ERR_INVALID;
+  if (!has_state<T>(c)) return fail(c, NBODY_ERR_INVALID, "import_rows: no particles of this precision uploaded");
+  State<T>& s = state_of<T>(c);
+  if (n_rows < 0 || (n_rows > 0 && (!rows_dev || !pos_dev || !vel_dev))) return fail(c, NBODY_ERR_INVALID, "import_rows: bad arguments");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, launch_import_rows<T>(c->stream, s.set[s.cur].pos, s.set[s.cur].vel, (const uint32_t*)rows_dev, n_rows, s.n, pos_dev, vel_dev));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  s.tree_valid = false;
   return NBODY_OK;
 }
 
@@ -907,6 +970,22 @@ NB_API int nbody_update_tree_f32(nbody_ctx* c, int kind, float delta, int n_step
 }
 NB_API int nbody_update_tree_f64(nbody_ctx* c, int kind, double delta, int n_steps, nbody_counting* counter) {
   return update_tree<double>(c, kind, delta, n_steps, counter);
+}
+NB_API int nbody_update_tree_shard_f32(nbody_ctx* c, int kind, float delta, int64_t begin, int64_t count, nbody_counting* counter) {
+  return update_tree_shard<float>(c, kind, delta, begin, count, counter);
+}
+NB_API int nbody_update_tree_shard_f64(nbody_ctx* c, int kind, double delta, int64_t begin, int64_t count, nbody_counting* counter) {
+  return update_tree_shard<double>(c, kind, delta, begin, count, counter);
+}
+NB_API int nbody_export_slice_dev(nbody_ctx* c, int64_t begin, int64_t count, void* rows_u32, void* pos_xy, void* vel_xy) {
+  if (!c) return NBODY_ERR_INVALID;
+  return c->has_f64 ? export_slice<double>(c, begin, count, rows_u32, pos_xy, vel_xy)
+                    : export_slice<float>(c, begin, count, rows_u32, pos_xy, vel_xy);
+}
+NB_API int nbody_import_rows_dev(nbody_ctx* c, int64_t n_rows, const void* rows_u32, const void* pos_xy, const void* vel_xy) {
+  if (!c) return NBODY_ERR_INVALID;
+  return c->has_f64 ? import_rows_api<double>(c, n_rows, rows_u32, pos_xy, vel_xy)
+                    : import_rows_api<float>(c, n_rows, rows_u32, pos_xy, vel_xy);
 }
 NB_API int nbody_accel_tree_f32(nbody_ctx* c, int kind, int64_t n_targets, const float* target_xy, float* acc_xy) {
   return accel_tree<float>(c, kind, n_targets, target_xy, acc_xy);

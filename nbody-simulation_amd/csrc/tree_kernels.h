@@ -36,4 +36,13 @@ template <class T> hipError_t launch_tree_walk(hipStream_t s, const WalkArgs<T>&
 template <class T> hipError_t launch_gather(hipStream_t s, const GatherArgs<T>& a);
 template <class T> hipError_t launch_integrate(hipStream_t s, void* pos, void* vel, const void* acc, int64_t n, T delta);
 
+template <class T>
+hipError_t launch_integrate_rows(hipStream_t s, void* pos, void* vel, const void* acc, const uint32_t* rows, int64_t row0, int64_t n, T delta);
+template <class T>
+hipError_t launch_export_rows(hipStream_t s, const void* pos, const void* vel, const uint32_t* rows, int64_t row0, int64_t n,
+                              uint32_t* rows_out, void* pos_out, void* vel_out);
+template <class T>
+hipError_t launch_import_rows(hipStream_t s, void* pos, void* vel, const uint32_t* rows, int64_t n, int64_t n_total, const void* pos_in,
+                              const void* vel_in);
+
 }  // namespace nbody

@@ -271,6 +271,75 @@ __global__ __launch_bounds__(256) void integrate_inplace(void* pos, void* vel, c
   reinterpret_cast<T2*>(pos)[i] = p;
 }
 
+// ---- sharded tree steps (one process per GPU): integrate / export / import a set of rows given by an index list
+template <class T>
+__global__ __launch_bounds__(256) void integrate_rows(void* pos, void* vel, const void* acc, const uint32_t* rows,
+                                                       int64_t row0, int64_t n, T delta) {
+  using T2 = typename V2<T>::type;
+  const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (k >= n) return;
+  const int64_t i = rows ? (int64_t)rows[k] : row0 + k;
+  T2 v = reinterpret_cast<T2*>(vel)[i];
+  T2 p = reinterpret_cast<T2*>(pos)[i];
+  const T2 ac = reinterpret_cast<const T2*>(acc)[i];
+  v.x = v.x + ac.x * delta;  // main.rs:419-423
+  v.y = v.y + ac.y * delta;
+  const T vx = v.x * delta, vy = v.y * delta;
+  p.x = p.x + vx;
+  p.y = p.y + vy;
+  reinterpret_cast<T2*>(vel)[i] = v;
+  reinterpret_cast<T2*>(pos)[i] = p;
+}
+template <class T>
+__global__ __launch_bounds__(256) void export_rows(const void* pos, const void* vel, const uint32_t* rows, int64_t row0, int64_t n,
+                                                    uint32_t* rows_out, void* pos_out, void* vel_out) {
+  using T2 = typename V2<T>::type;
+  const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (k >= n) return;
+  const int64_t i = rows ? (int64_t)rows[k] : row0 + k;
+  rows_out[k] = (uint32_t)i;
+  reinterpret_cast<T2*>(pos_out)[k] = reinterpret_cast<const T2*>(pos)[i];
+  reinterpret_cast<T2*>(vel_out)[k] = reinterpret_cast<const T2*>(vel)[i];
+}
+template <class T>
+__global__ __launch_bounds__(256) void import_rows(void* pos, void* vel, const uint32_t* rows, int64_t n, int64_t n_total,
+                                                    const void* pos_in, const void* vel_in) {
+  using T2 = typename V2<T>::type;
+  const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (k >= n) return;
+  const int64_t i = (int64_t)rows[k];
+  if (i >= n_total) return;  // never write outside the state, whatever the caller sent
+  reinterpret_cast<T2*>(pos)[i] = reinterpret_cast<const T2*>(pos_in)[k];
+  reinterpret_cast<T2*>(vel)[i] = reinterpret_cast<const T2*>(vel_in)[k];
+}
+template <class T>
+hipError_t launch_integrate_rows(hipStream_t s, void* pos, void* vel, const void* acc, const uint32_t* rows, int64_t row0, int64_t n, T delta) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL((integrate_rows<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, pos, vel, acc, rows, row0, n, delta);
+  return hipGetLastError();
+}
+template <class T>
+hipError_t launch_export_rows(hipStream_t s, const void* pos, const void* vel, const uint32_t* rows, int64_t row0, int64_t n,
+                              uint32_t* rows_out, void* pos_out, void* vel_out) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL((export_rows<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, pos, vel, rows, row0, n, rows_out, pos_out, vel_out);
+  return hipGetLastError();
+}
+template <class T>
+hipError_t launch_import_rows(hipStream_t s, void* pos, void* vel, const uint32_t* rows, int64_t n, int64_t n_total, const void* pos_in,
+                              const void* vel_in) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL((import_rows<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, pos, vel, rows, n, n_total, pos_in, vel_in);
+  return hipGetLastError();
+}
+#define NB_INST(T)                                                                                                        \
+  template hipError_t launch_integrate_rows<T>(hipStream_t, void*, void*, const void*, const uint32_t*, int64_t, int64_t, T); \
+  template hipError_t launch_export_rows<T>(hipStream_t, const void*, const void*, const uint32_t*, int64_t, int64_t, uint32_t*, void*, void*); \
+  template hipError_t launch_import_rows<T>(hipStream_t, void*, void*, const uint32_t*, int64_t, int64_t, const void*, const void*);
+NB_INST(float)
+NB_INST(double)
+#undef NB_INST
+
 template <class T> hipError_t launch_tree_walk(hipStream_t s, const WalkArgs<T>& a, bool wave_uniform) {
   if (a.n_tgt <= 0) return hipSuccess;
   const dim3 grid((unsigned)((a.n_tgt + 255) / 256));

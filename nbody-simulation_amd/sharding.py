@@ -87,3 +87,64 @@ class ShardedDirectStepper:
 
     def all_positions(self):
         return self.pos_all.cpu().numpy()
+
+
+class ShardedTreeStepper:
+    """Barnes-Hut steps sharded over ranks (second bullet).
+
+    Every rank holds ALL particles in its own context and builds the same tree (the quad tree on the device, the BVH
+    on the host: both deterministic); rank r walks and integrates only the r-th slice of the tree-ordered targets
+    (tree order keeps a wave's 64 targets close together).  The exchange step: each rank exports {row, position,
+    velocity} of its slice into device buffers, one all-gather per array (RCCL over xGMI; gloo staging in the
+    rehearsal), and every rank imports all rows, after which all contexts hold the same state again.  Results are
+    bit-identical to the single-context step: a target's walk does not depend on who performs it."""
+
+    def __init__(self, pos, vel, weight, *, kind=_capi.TREE_QUAD, rank=0, world=1, device_index=0, group=None, **params):
+        import torch
+        self.torch = torch
+        self.kind, self.rank, self.world, self.group = kind, rank, world, group
+        self.ctx = _capi.Context(device_index)
+        if params:
+            self.ctx.set_params(**params)
+        self.ctx.upload(pos, vel, weight)
+        n = self.ctx.n
+        if n % world:
+            raise ValueError(f"N={n} must be divisible by the number of ranks ({world})")
+        self.n, self.n_local = n, n // world
+        self.begin = rank * self.n_local
+        dev = torch.device("cuda", device_index)
+        self.device = dev
+        ft = torch.float64 if self.ctx.dtype == np.float64 else torch.float32
+        self.rows = torch.empty(self.n_local, dtype=torch.int32, device=dev)
+        self.pos = torch.empty((self.n_local, 2), dtype=ft, device=dev)
+        self.vel = torch.empty((self.n_local, 2), dtype=ft, device=dev)
+        if world > 1:
+            self.all_rows = torch.empty(n, dtype=torch.int32, device=dev)
+            self.all_pos = torch.empty((n, 2), dtype=ft, device=dev)
+            self.all_vel = torch.empty((n, 2), dtype=ft, device=dev)
+
+    def _all_gather(self, out, inp):
+        import torch.distributed as dist
+        if dist.get_backend(self.group) == "gloo":   # rehearsal: several ranks on one GPU, stage through the host
+            host = self.torch.empty(out.shape, dtype=out.dtype)
+            dist.all_gather_into_tensor(host.view(-1), inp.cpu().view(-1), group=self.group)
+            out.copy_(host)
+        else:
+            dist.all_gather_into_tensor(out.view(-1), inp.view(-1), group=self.group)
+
+    def step(self, dt, counter=None):
+        self.ctx.update_tree_shard(self.kind, dt, self.begin, self.n_local, counter)
+        if self.world == 1:
+            return
+        self.ctx.export_slice_dev(self.begin, self.n_local, self.rows.data_ptr(), self.pos.data_ptr(), self.vel.data_ptr())
+        self._all_gather(self.all_rows, self.rows)
+        self._all_gather(self.all_pos, self.pos)
+        self._all_gather(self.all_vel, self.vel)
+        self.torch.cuda.synchronize(self.device)
+        self.ctx.import_rows_dev(self.n, self.all_rows.data_ptr(), self.all_pos.data_ptr(), self.all_vel.data_ptr())
+
+    def particles(self):
+        return self.ctx.download()
+
+    def close(self):
+        self.ctx.close()
