@@ -41,3 +41,239 @@ def direct_accel_seq(pos, weight, targets, clamp=0.001, dtype=np.float32):
             ay = dtype(ay + terms[j, 1])
         out[k] = (ax, ay)
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Second, independent reading of the trees and the walker, in plain Python with numpy scalars (small inputs only).
+# Written from the reference text (src/bvh_tree.rs, src/quad_tree.rs, src/main.rs:348-386), not from the C++ oracle.
+# ---------------------------------------------------------------------------------------------------------------------
+def _f(dtype):
+    return np.dtype(dtype).type
+
+
+def _gravity(p1, p2, acc, force, clamp, T):
+    """calculate_gravity, main.rs:234-253.  acc is a 2-list of T scalars, updated in place."""
+    dx, dy = T(p2[0] - p1[0]), T(p2[1] - p1[1])
+    s = T(abs(dx) + abs(dy))
+    tiny = np.finfo(T).tiny
+    if not (np.isfinite(s) and abs(s) >= tiny):           # !sum.is_normal()
+        return
+    dist = T(T(dx * dx) + T(dy * dy))
+    if dist < clamp:
+        dist = clamp
+    den = T(s * dist)
+    with np.errstate(all="ignore"):
+        acc[0] = T(acc[0] + T(T(dx * force) / den))
+        acc[1] = T(acc[1] + T(T(dy * force) / den))
+
+
+class PyBVH:
+    """BVHTree::from / make_leaf / calculate_gravity (bvh_tree.rs:40-158) on a Python list of [x, y, weight, id]."""
+
+    def __init__(self, pos, weight, leaf_size=64, dtype=np.float32):
+        self.T = T = _f(dtype)
+        self.leaf_size = leaf_size
+        self.pts = [[T(p[0]), T(p[1]), int(w), i] for i, (p, w) in enumerate(zip(pos, weight))]
+        self.root = self._from(0, len(self.pts))            # the top call is unconditional (main.rs:400)
+        self._upward(self.root)
+
+    def _fold_box(self, lo, hi):
+        T = self.T
+        mnx = mny = np.finfo(T).max
+        mxx = mxy = T(0)
+        for k in range(lo, hi):
+            x, y = self.pts[k][0], self.pts[k][1]
+            mnx = mnx if mnx < x else x                     # min.min(p): minps semantics
+            mny = mny if mny < y else y
+            mxx = mxx if mxx > x else x
+            mxy = mxy if mxy > y else y
+        return (mnx, mny), (T(mxx - mnx), T(mxy - mny))
+
+    def _leaf(self, lo, hi):
+        off, size = self._fold_box(lo, hi)
+        return {"leaf": True, "off": off, "size": size, "lo": lo, "hi": hi}
+
+    def _from(self, lo, hi):
+        T = self.T
+        n = hi - lo
+        off, size = self._fold_box(lo, hi)
+        sx = sy = T(0)
+        for k in range(lo, hi):                              # sum.add(p.position), in slice order
+            sx = T(sx + self.pts[k][0])
+            sy = T(sy + self.pts[k][1])
+        with np.errstate(all="ignore"):
+            hx, hy = T(sx / T(n)), T(sy / T(n))
+        half = n // 2
+        cx = sum(1 for k in range(lo, hi) if self.pts[k][0] > hx)
+        cy = sum(1 for k in range(lo, hi) if self.pts[k][1] > hy)
+        hori, vert = abs(half - cx), abs(half - cy)
+        axis, mean = (0, hx) if vert > hori else (1, hy)
+        # partition 0.1.2: two pointers
+        pts = self.pts
+        split = 0
+        if n > 0:
+            l, r = lo, hi - 1
+            while True:
+                while l < hi and pts[l][axis] > mean:
+                    l += 1
+                while r > lo and not (pts[r][axis] > mean):
+                    r -= 1
+                if l >= r:
+                    split = l
+                    break
+                pts[l], pts[r] = pts[r], pts[l]
+        left = self._from(lo, split) if split - lo > self.leaf_size else self._leaf(lo, split)
+        right = self._from(split, hi) if hi - split > self.leaf_size else self._leaf(split, hi)
+        return {"leaf": False, "off": off, "size": size, "kids": (left, right), "cog": (T(0), T(0)), "mass": 0}
+
+    def _cog_mass(self, node):
+        T = self.T
+        if node["leaf"]:
+            ax = ay = T(0)
+            m = 0
+            for k in range(node["lo"], node["hi"]):
+                ax = T(ax + self.pts[k][0])
+                ay = T(ay + self.pts[k][1])
+                m = (m + self.pts[k][2]) & 0xFFFFFFFF
+            cnt = T(node["hi"] - node["lo"])
+            with np.errstate(all="ignore"):
+                return (T(ax / cnt), T(ay / cnt)), m
+        return node["cog"], node["mass"]
+
+    def _upward(self, node):
+        T = self.T
+        if node["leaf"]:
+            return
+        a, b = node["kids"]
+        self._upward(a)
+        self._upward(b)
+        (c0, m0), (c1, m1) = self._cog_mass(a), self._cog_mass(b)
+        mass = (m0 + m1) & 0xFFFFFFFF
+        with np.errstate(all="ignore"):
+            bx = T(T(c0[0] * T(m0)) + T(c1[0] * T(m1)))
+            by = T(T(c0[1] * T(m0)) + T(c1[1] * T(m1)))
+            node["cog"] = (T(bx / T(mass)), T(by / T(mass)))
+        node["mass"] = mass
+
+    def walk(self, p, theta, clamp=0.001):
+        T = self.T
+        acc = [T(0), T(0)]
+        self._walk((T(p[0]), T(p[1])), self.root, acc, T(theta), T(np.float32(clamp)))
+        return acc
+
+    def _walk(self, p, node, acc, theta, clamp):
+        T = self.T
+        if node["leaf"]:
+            for k in range(node["lo"], node["hi"]):
+                q = self.pts[k]
+                _gravity(p, (q[0], q[1]), acc, T(q[2]), clamp, T)
+            return
+        ox, oy = node["off"]
+        w, h = node["size"]
+        contains = p[1] > oy and p[0] > ox and p[0] < T(ox + w) and p[1] < T(oy + h)
+        m = w if w > h else h                               # size.max(size.yx()) -> x*y
+        m2 = T(m * m)
+        cg = node["cog"]
+        ddx, ddy = T(p[0] - cg[0]), T(p[1] - cg[1])
+        d2 = T(T(ddx * ddx) + T(ddy * ddy))
+        if (not contains) and m2 < T(T(d2 * theta) * theta):
+            _gravity(p, cg, acc, T(node["mass"]), clamp, T)
+        else:
+            self._walk(p, node["kids"][0], acc, theta, clamp)
+            self._walk(p, node["kids"][1], acc, theta, clamp)
+
+    def ids(self):
+        return np.array([q[3] for q in self.pts], np.uint32)
+
+
+class PyQuad:
+    """QuadTree::new / insert / subdivide / calculate_gravity (quad_tree.rs:55-270), points inserted in index order."""
+
+    def __init__(self, pos, weight, root=(0.0, 0.0, 100000.0), dtype=np.float32):
+        self.T = T = _f(dtype)
+        self.root = self._new((T(root[0]), T(root[1])), T(root[2]))
+        for i, (p, w) in enumerate(zip(pos, weight)):
+            self._insert(self.root, (T(p[0]), T(p[1]), int(w), i))
+        self._upward(self.root)
+
+    def _new(self, off, h):
+        return {"leaf": True, "off": off, "h": h, "pts": [], "cog": (self.T(0), self.T(0))}
+
+    def _insert(self, node, pt):
+        T = self.T
+        if node["leaf"]:
+            if len(node["pts"]) == 8:                       # MAX_CAPACITY
+                old = node["pts"]
+                node.update({"leaf": False, "kids": [None] * 4, "mass": len(old), "pts": None})
+                for q in old:
+                    self._insert(node, q)
+                self._insert(node, pt)
+            else:
+                node["pts"].append(pt)
+            return
+        half = T(node["h"] / T(2.0))
+        ox, oy = node["off"]
+        xm, ym = T(ox + half), T(oy + half)
+        child = (2 if pt[1] > ym else 0) + (1 if pt[0] > xm else 0)
+        if node["kids"][child] is None:
+            off = [(ox, oy), (T(ox + half), T(oy + T(0))), (T(ox + T(0)), T(oy + half)), (T(ox + half), T(oy + half))][child]
+            node["kids"][child] = self._new(off, half)
+        self._insert(node["kids"][child], pt)
+
+    def _mass(self, node):
+        if node["leaf"]:
+            m = 0
+            for q in node["pts"]:
+                m = (m + q[2]) & 0xFFFFFFFF
+            return m
+        return node["mass"]
+
+    def _upward(self, node):
+        T = self.T
+        if node["leaf"]:
+            if node["pts"]:
+                ax = ay = T(0)
+                for q in node["pts"]:
+                    ax = T(ax + q[0])
+                    ay = T(ay + q[1])
+                c = T(len(node["pts"]))
+                node["cog"] = (T(ax / c), T(ay / c))
+            return
+        kids = [k for k in node["kids"] if k is not None]
+        for k in kids:
+            self._upward(k)
+        mass = 0
+        for k in kids:
+            mass = (mass + self._mass(k)) & 0xFFFFFFFF
+        bx = by = T(0)
+        for k in kids:
+            bx = T(bx + T(k["cog"][0] * T(self._mass(k))))
+            by = T(by + T(k["cog"][1] * T(self._mass(k))))
+        with np.errstate(all="ignore"):
+            node["cog"] = (T(bx / T(mass)), T(by / T(mass)))
+        node["mass"] = mass
+
+    def walk(self, p, theta, clamp=0.001):
+        T = self.T
+        acc = [T(0), T(0)]
+        self._walk((T(p[0]), T(p[1])), self.root, acc, T(theta), T(np.float32(clamp)))
+        return acc
+
+    def _walk(self, p, node, acc, theta, clamp):
+        T = self.T
+        if node["leaf"]:
+            for q in node["pts"]:
+                _gravity(p, (q[0], q[1]), acc, T(q[2]), clamp, T)
+            return
+        ox, oy = node["off"]
+        h = node["h"]
+        contains = p[1] > oy and p[0] > ox and p[0] < T(ox + h) and p[1] < T(oy + h)
+        cg = node["cog"]
+        ddx, ddy = T(p[0] - cg[0]), T(p[1] - cg[1])
+        d2 = T(T(ddx * ddx) + T(ddy * ddy))
+        if (not contains) and T(h * h) < T(T(d2 * theta) * theta):
+            _gravity(p, cg, acc, T(node["mass"]), clamp, T)
+        else:
+            for k in node["kids"]:
+                if k is not None:
+                    self._walk(p, k, acc, theta, clamp)

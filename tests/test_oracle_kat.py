@@ -386,3 +386,35 @@ def test_f64_restatement_agrees_with_f32_loosely(orc, nb):
     a64 = orc.BVH(pos.astype(np.float64), w).walk(pos[:64].astype(np.float64), theta=0.5)
     # different rounding can flip a borderline split, so this is only a sanity bound
     assert np.median(np.abs(a32 - a64) / (np.abs(a64) + 1e-12)) < 1e-3
+
+
+# ---------------------------------------------------------------- second reading of trees + walker (plain Python)
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("n,leaf,theta", [(300, 64, 0.5), (700, 16, 50.0), (1200, 64, 2.0)])
+def test_oracle_bvh_agrees_with_python_restatement(orc, nb, dtype, n, leaf, theta):
+    """The C++ oracle and an independently written Python reading of bvh_tree.rs + main.rs:348-386 must agree bit for
+    bit: permutation of the particles, and the walked acceleration of every sampled target."""
+    pos, _, _ = nb.scenes.plummer(n, seed=101, dtype=dtype)
+    w = (np.arange(n) % 9 + 1).astype(np.uint32)
+    w[3] = 75_000_000
+    py = npr.PyBVH(pos, w, leaf_size=leaf, dtype=dtype)
+    bvh = orc.BVH(pos, w, leaf_size=leaf)
+    assert np.array_equal(py.ids(), bvh.flat().ids)
+    tg = pos[::17]
+    ref = bvh.walk(tg, theta=theta)
+    got = np.array([py.walk(p, theta) for p in tg], dtype=dtype)
+    assert np.array_equal(got, ref)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("n,theta", [(200, 0.5), (900, 0.5), (900, 50.0)])
+def test_oracle_quad_agrees_with_python_restatement(orc, nb, dtype, n, theta):
+    pos, _, _ = nb.scenes.plummer(n, seed=102, dtype=dtype)
+    w = (np.arange(n) % 4 + 1).astype(np.uint32)
+    py = npr.PyQuad(pos, w, dtype=dtype)
+    q = orc.Quad(pos, w)
+    tg = pos[::13]
+    ref = q.walk(tg, theta=theta)
+    got = np.array([py.walk(p, theta) for p in tg], dtype=dtype)
+    assert np.array_equal(got, ref)
+    assert int(py.root["mass"] if not py.root["leaf"] else 0) == int(q.flat().mass[0])
