@@ -58,15 +58,20 @@ __device__ __forceinline__ void fast_pair(float xi, float yi, float xj, float yj
 }
 
 // Eight FAST pairs for one target as one hand-ordered instruction block: the same operations as fast_pair,
-// issued in phases (8 x v_pk_add | the 32-bit ops | 8 x v_rcp | 8 x v_pk_fma).  p0..p7 come in as source
+// issued in phases (8 x v_pk_add | the 32-bit ops | 8 x v_rcp | 8 x v_pk_fma).  With per-body masses m0..m7 are the
+// INVERSE masses and scale the denominator before the reciprocal (s = 1/(den/m) instead of m * (1/den)).  p0..p7 come in as source
 // positions and leave as the differences.  Temporaries live in v40..v55: pair k = v[40+2k : 41+2k] = (s_k, d2_k),
 // so that the pk_fma can broadcast s_k with op_sel_hi.  0x12800000 = 2^-90 (kDenBias).  VALU->VALU
 // dependencies are interlocked by the hardware; every v_rcp result is consumed >= 8 instructions later (the
 // trans forwarding hazard of gfx940+ needs 1).  Worth 2 % over hipcc's schedule of the same instructions.
+// Operands are native 2-vectors (HIP's float2 is a struct: as an asm operand it is coerced through an i64 and costs
+// shift/or/move instructions around every block).
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
 template <bool UNIFORM, bool NOCLAMP>
-__device__ __forceinline__ void fast_block8(float2 t, float clamp, float2& p0, float2& p1, float2& p2, float2& p3,
-                                            float2& p4, float2& p5, float2& p6, float2& p7, float m0, float m1,
-                                            float m2, float m3, float m4, float m5, float m6, float m7, float2& acc) {
+__device__ __forceinline__ void fast_block8(v2f t, float clamp, v2f& p0, v2f& p1, v2f& p2, v2f& p3, v2f& p4, v2f& p5,
+                                            v2f& p6, v2f& p7, float m0, float m1, float m2, float m3, float m4,
+                                            float m5, float m6, float m7, v2f& acc) {
   asm volatile(
       "v_pk_add_f32 %[p0], %[p0], %[t] neg_lo:[0,1] neg_hi:[0,1]\n\tv_pk_add_f32 %[p1], %[p1], %[t] neg_lo:[0,1] neg_hi:[0,1]\n\tv_pk_add_f32 %[p2], %[p2], %[t] neg_lo:[0,1] neg_hi:[0,1]\n\tv_pk_add_f32 %[p3], %[p3], %[t] neg_lo:[0,1] neg_hi:[0,1]\n\tv_pk_add_f32 %[p4], %[p4], %[t] neg_lo:[0,1] neg_hi:[0,1]\n\tv_pk_add_f32 %[p5], %[p5], %[t] neg_lo:[0,1] neg_hi:[0,1]\n\tv_pk_add_f32 %[p6], %[p6], %[t] neg_lo:[0,1] neg_hi:[0,1]\n\tv_pk_add_f32 %[p7], %[p7], %[t] neg_lo:[0,1] neg_hi:[0,1]\n\t"
       : [p0] "+v"(p0), [p1] "+v"(p1), [p2] "+v"(p2), [p3] "+v"(p3), [p4] "+v"(p4), [p5] "+v"(p5), [p6] "+v"(p6),
@@ -110,8 +115,8 @@ __device__ __forceinline__ void fast_block8(float2 t, float clamp, float2& p0, f
         "v_fmac_f32 v41, %[y0], %[y0]\n\tv_fmac_f32 v43, %[y1], %[y1]\n\tv_fmac_f32 v45, %[y2], %[y2]\n\tv_fmac_f32 v47, %[y3], %[y3]\n\tv_fmac_f32 v49, %[y4], %[y4]\n\tv_fmac_f32 v51, %[y5], %[y5]\n\tv_fmac_f32 v53, %[y6], %[y6]\n\tv_fmac_f32 v55, %[y7], %[y7]\n\t"
         "v_add_f32 v40, |%[x0]|, |%[y0]|\n\tv_add_f32 v42, |%[x1]|, |%[y1]|\n\tv_add_f32 v44, |%[x2]|, |%[y2]|\n\tv_add_f32 v46, |%[x3]|, |%[y3]|\n\tv_add_f32 v48, |%[x4]|, |%[y4]|\n\tv_add_f32 v50, |%[x5]|, |%[y5]|\n\tv_add_f32 v52, |%[x6]|, |%[y6]|\n\tv_add_f32 v54, |%[x7]|, |%[y7]|\n\t"
         "v_fmaak_f32 v40, v40, v41, 0x12800000\n\tv_fmaak_f32 v42, v42, v43, 0x12800000\n\tv_fmaak_f32 v44, v44, v45, 0x12800000\n\tv_fmaak_f32 v46, v46, v47, 0x12800000\n\tv_fmaak_f32 v48, v48, v49, 0x12800000\n\tv_fmaak_f32 v50, v50, v51, 0x12800000\n\tv_fmaak_f32 v52, v52, v53, 0x12800000\n\tv_fmaak_f32 v54, v54, v55, 0x12800000\n\t"
-        "v_rcp_f32 v40, v40\n\tv_rcp_f32 v42, v42\n\tv_rcp_f32 v44, v44\n\tv_rcp_f32 v46, v46\n\tv_rcp_f32 v48, v48\n\tv_rcp_f32 v50, v50\n\tv_rcp_f32 v52, v52\n\tv_rcp_f32 v54, v54\n\t"
         "v_mul_f32 v40, %[m0], v40\n\tv_mul_f32 v42, %[m1], v42\n\tv_mul_f32 v44, %[m2], v44\n\tv_mul_f32 v46, %[m3], v46\n\tv_mul_f32 v48, %[m4], v48\n\tv_mul_f32 v50, %[m5], v50\n\tv_mul_f32 v52, %[m6], v52\n\tv_mul_f32 v54, %[m7], v54\n\t"
+        "v_rcp_f32 v40, v40\n\tv_rcp_f32 v42, v42\n\tv_rcp_f32 v44, v44\n\tv_rcp_f32 v46, v46\n\tv_rcp_f32 v48, v48\n\tv_rcp_f32 v50, v50\n\tv_rcp_f32 v52, v52\n\tv_rcp_f32 v54, v54\n\t"
         "v_pk_fma_f32 %[a], %[p0], v[40:41], %[a] op_sel_hi:[1,0,1]\n\tv_pk_fma_f32 %[a], %[p1], v[42:43], %[a] op_sel_hi:[1,0,1]\n\tv_pk_fma_f32 %[a], %[p2], v[44:45], %[a] op_sel_hi:[1,0,1]\n\tv_pk_fma_f32 %[a], %[p3], v[46:47], %[a] op_sel_hi:[1,0,1]\n\tv_pk_fma_f32 %[a], %[p4], v[48:49], %[a] op_sel_hi:[1,0,1]\n\tv_pk_fma_f32 %[a], %[p5], v[50:51], %[a] op_sel_hi:[1,0,1]\n\tv_pk_fma_f32 %[a], %[p6], v[52:53], %[a] op_sel_hi:[1,0,1]\n\tv_pk_fma_f32 %[a], %[p7], v[54:55], %[a] op_sel_hi:[1,0,1]\n\t"
         : [a] "+v"(acc)
         :[p0] "v"(p0), [p1] "v"(p1), [p2] "v"(p2), [p3] "v"(p3), [p4] "v"(p4), [p5] "v"(p5), [p6] "v"(p6), [p7] "v"(p7),
@@ -131,8 +136,8 @@ __device__ __forceinline__ void fast_block8(float2 t, float clamp, float2& p0, f
         "v_add_f32 v52, |%[x6]|, |%[y6]|\n\tv_max_f32 v53, v53, %[c]\n\t"
         "v_add_f32 v54, |%[x7]|, |%[y7]|\n\tv_max_f32 v55, v55, %[c]\n\t"
         "v_fmaak_f32 v40, v40, v41, 0x12800000\n\tv_fmaak_f32 v42, v42, v43, 0x12800000\n\tv_fmaak_f32 v44, v44, v45, 0x12800000\n\tv_fmaak_f32 v46, v46, v47, 0x12800000\n\tv_fmaak_f32 v48, v48, v49, 0x12800000\n\tv_fmaak_f32 v50, v50, v51, 0x12800000\n\tv_fmaak_f32 v52, v52, v53, 0x12800000\n\tv_fmaak_f32 v54, v54, v55, 0x12800000\n\t"
-        "v_rcp_f32 v40, v40\n\tv_rcp_f32 v42, v42\n\tv_rcp_f32 v44, v44\n\tv_rcp_f32 v46, v46\n\tv_rcp_f32 v48, v48\n\tv_rcp_f32 v50, v50\n\tv_rcp_f32 v52, v52\n\tv_rcp_f32 v54, v54\n\t"
         "v_mul_f32 v40, %[m0], v40\n\tv_mul_f32 v42, %[m1], v42\n\tv_mul_f32 v44, %[m2], v44\n\tv_mul_f32 v46, %[m3], v46\n\tv_mul_f32 v48, %[m4], v48\n\tv_mul_f32 v50, %[m5], v50\n\tv_mul_f32 v52, %[m6], v52\n\tv_mul_f32 v54, %[m7], v54\n\t"
+        "v_rcp_f32 v40, v40\n\tv_rcp_f32 v42, v42\n\tv_rcp_f32 v44, v44\n\tv_rcp_f32 v46, v46\n\tv_rcp_f32 v48, v48\n\tv_rcp_f32 v50, v50\n\tv_rcp_f32 v52, v52\n\tv_rcp_f32 v54, v54\n\t"
         "v_pk_fma_f32 %[a], %[p0], v[40:41], %[a] op_sel_hi:[1,0,1]\n\tv_pk_fma_f32 %[a], %[p1], v[42:43], %[a] op_sel_hi:[1,0,1]\n\tv_pk_fma_f32 %[a], %[p2], v[44:45], %[a] op_sel_hi:[1,0,1]\n\tv_pk_fma_f32 %[a], %[p3], v[46:47], %[a] op_sel_hi:[1,0,1]\n\tv_pk_fma_f32 %[a], %[p4], v[48:49], %[a] op_sel_hi:[1,0,1]\n\tv_pk_fma_f32 %[a], %[p5], v[50:51], %[a] op_sel_hi:[1,0,1]\n\tv_pk_fma_f32 %[a], %[p6], v[52:53], %[a] op_sel_hi:[1,0,1]\n\tv_pk_fma_f32 %[a], %[p7], v[54:55], %[a] op_sel_hi:[1,0,1]\n\t"
         : [a] "+v"(acc)
         :[p0] "v"(p0), [p1] "v"(p1), [p2] "v"(p2), [p3] "v"(p3), [p4] "v"(p4), [p5] "v"(p5), [p6] "v"(p6), [p7] "v"(p7),
@@ -210,6 +215,10 @@ __global__ __launch_bounds__(256) void direct_fast(const DirectArgs a) {
   __shared__ __attribute__((aligned(16))) float2 tile_pos[TILE];
   __shared__ __attribute__((aligned(16))) float4 tile_mass4[UNIFORM ? 1 : TILE / 4];  // masses, four per element
   float* tile_mass = reinterpret_cast<float*>(tile_mass4);
+  // the hand-ordered block multiplies the denominator by 1/m before the reciprocal (one class switch fewer than
+  // multiplying the reciprocal by m afterwards); 1/0 = inf makes a zero-mass source contribute exactly 0
+  __shared__ __attribute__((aligned(16))) float4 tile_minv4[(UNIFORM || !USE_ASM) ? 1 : TILE / 4];
+  float* tile_minv = reinterpret_cast<float*>(tile_minv4);
 
   // sources of this grid split: [g0, g1)
   int gchunk = (a.n_src + (int)gridDim.y - 1) / (int)gridDim.y;
@@ -232,40 +241,56 @@ __global__ __launch_bounds__(256) void direct_fast(const DirectArgs a) {
       }
       tile_pos[s] = p;
       if (!UNIFORM) tile_mass[s] = m;
+      if (!UNIFORM && USE_ASM) tile_minv[s] = 1.0f / m;
     }
     __syncthreads();
     const int lo = ws * SHARE;
     int hi = lo + SHARE;
     if (hi > cnt) hi = cnt > lo ? cnt : lo;
-    float bx[TPT], by[TPT];
-#pragma unroll
-    for (int k = 0; k < TPT; ++k) bx[k] = by[k] = 0.f;
     int u = lo;
-    for (; u + UNR <= hi; u += UNR) {
-      float4 pp[UNR / 2];
-      float2 mm[UNR / 2];
-#pragma unroll
-      for (int h = 0; h < UNR / 2; ++h) pp[h] = *reinterpret_cast<const float4*>(&tile_pos[u + 2 * h]);
-      if constexpr (!UNIFORM) {  // u is a multiple of 8: two ds_read_b128 fetch the eight masses
-        const float4 ma = tile_mass4[(u >> 2)], mb = tile_mass4[(u >> 2) + 1];
-        mm[0] = make_float2(ma.x, ma.y); mm[1] = make_float2(ma.z, ma.w);
-        mm[2] = make_float2(mb.x, mb.y); mm[3] = make_float2(mb.z, mb.w);
-      } else {
-#pragma unroll
-        for (int h = 0; h < UNR / 2; ++h) mm[h] = make_float2(1.f, 1.f);
+    if constexpr (USE_ASM) {
+      static_assert(!USE_ASM || TPT == 1, "the hand-ordered block handles one target per thread");
+      // the wave's share of the tile, 8 sources per block, summed on its own (two-level summation); everything the
+      // block touches stays in 64-bit register pairs so that no repacking moves surround the asm
+      v2f accb = {0.f, 0.f};
+      const v2f tgt = {xi[0], yi[0]};
+      for (; u + UNR <= hi; u += UNR) {
+        const v4f* src4 = reinterpret_cast<const v4f*>(&tile_pos[u]);
+        const v4f s0 = src4[0], s1 = src4[1], s2 = src4[2], s3 = src4[3];
+        v2f q0 = s0.xy, q1 = s0.zw, q2 = s1.xy, q3 = s1.zw, q4 = s2.xy, q5 = s2.zw, q6 = s3.xy, q7 = s3.zw;
+        float4 ma = make_float4(1.f, 1.f, 1.f, 1.f), mb = ma;
+        if constexpr (!UNIFORM) {  // u is a multiple of 8: two ds_read_b128 fetch the eight inverse masses
+          ma = tile_minv4[(u >> 2)];
+          mb = tile_minv4[(u >> 2) + 1];
+        }
+        fast_block8<UNIFORM, NOCLAMP>(tgt, clamp, q0, q1, q2, q3, q4, q5, q6, q7, ma.x, ma.y, ma.z, ma.w, mb.x, mb.y,
+                                      mb.z, mb.w, accb);
       }
-      if constexpr (USE_ASM) {
-        static_assert(!USE_ASM || TPT == 1, "the hand-ordered block handles one target per thread");
-        float2 q0 = make_float2(pp[0].x, pp[0].y), q1 = make_float2(pp[0].z, pp[0].w);
-        float2 q2 = make_float2(pp[1].x, pp[1].y), q3 = make_float2(pp[1].z, pp[1].w);
-        float2 q4 = make_float2(pp[2].x, pp[2].y), q5 = make_float2(pp[2].z, pp[2].w);
-        float2 q6 = make_float2(pp[3].x, pp[3].y), q7 = make_float2(pp[3].z, pp[3].w);
-        float2 acc2 = make_float2(bx[0], by[0]);
-        fast_block8<UNIFORM, NOCLAMP>(make_float2(xi[0], yi[0]), clamp, q0, q1, q2, q3, q4, q5, q6, q7, mm[0].x,
-                                      mm[0].y, mm[1].x, mm[1].y, mm[2].x, mm[2].y, mm[3].x, mm[3].y, acc2);
-        bx[0] = acc2.x;
-        by[0] = acc2.y;
-      } else {
+      float bx = accb.x, by = accb.y;
+      for (; u < hi; ++u) {
+        float2 p = tile_pos[u];
+        float m = UNIFORM ? 1.0f : tile_mass[u];
+        fast_pair<UNIFORM, NOCLAMP>(xi[0], yi[0], p.x, p.y, m, clamp, bx, by);
+      }
+      ax[0] += bx;
+      ay[0] += by;
+    } else {
+      float bx[TPT], by[TPT];
+#pragma unroll
+      for (int k = 0; k < TPT; ++k) bx[k] = by[k] = 0.f;
+      for (; u + UNR <= hi; u += UNR) {
+        float4 pp[UNR / 2];
+        float2 mm[UNR / 2];
+#pragma unroll
+        for (int h = 0; h < UNR / 2; ++h) pp[h] = *reinterpret_cast<const float4*>(&tile_pos[u + 2 * h]);
+        if constexpr (!UNIFORM) {
+          const float4 ma = tile_mass4[(u >> 2)], mb = tile_mass4[(u >> 2) + 1];
+          mm[0] = make_float2(ma.x, ma.y); mm[1] = make_float2(ma.z, ma.w);
+          mm[2] = make_float2(mb.x, mb.y); mm[3] = make_float2(mb.z, mb.w);
+        } else {
+#pragma unroll
+          for (int h = 0; h < UNR / 2; ++h) mm[h] = make_float2(1.f, 1.f);
+        }
 #pragma unroll
         for (int h = 0; h < UNR / 2; ++h)
 #pragma unroll
@@ -274,17 +299,17 @@ __global__ __launch_bounds__(256) void direct_fast(const DirectArgs a) {
             fast_pair<UNIFORM, NOCLAMP>(xi[k], yi[k], pp[h].z, pp[h].w, mm[h].y, clamp, bx[k], by[k]);
           }
       }
-    }
-    for (; u < hi; ++u) {
-      float2 p = tile_pos[u];
-      float m = UNIFORM ? 1.0f : tile_mass[u];
+      for (; u < hi; ++u) {
+        float2 p = tile_pos[u];
+        float m = UNIFORM ? 1.0f : tile_mass[u];
 #pragma unroll
-      for (int k = 0; k < TPT; ++k) fast_pair<UNIFORM, NOCLAMP>(xi[k], yi[k], p.x, p.y, m, clamp, bx[k], by[k]);
-    }
+        for (int k = 0; k < TPT; ++k) fast_pair<UNIFORM, NOCLAMP>(xi[k], yi[k], p.x, p.y, m, clamp, bx[k], by[k]);
+      }
 #pragma unroll
-    for (int k = 0; k < TPT; ++k) {
-      ax[k] += bx[k];
-      ay[k] += by[k];
+      for (int k = 0; k < TPT; ++k) {
+        ax[k] += bx[k];
+        ay[k] += by[k];
+      }
     }
     __syncthreads();
   }

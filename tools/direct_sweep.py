@@ -42,7 +42,6 @@ def run(n, n_tgt, cfgs, reps=3, uniform=1.0):
 
 if __name__ == "__main__":
     n = 1 << 20
-    cfgs = [{"NBODY_DIRECT_TPT": 1, "NBODY_DIRECT_ASM": 1}, {"NBODY_DIRECT_TPT": 1, "NBODY_DIRECT_ASM": 0}, {"NBODY_DIRECT_TPT": 2}]
+    cfgs = [{"NBODY_DIRECT_ASM": 1}, {"NBODY_DIRECT_ASM": 0}]
     run(n, n, cfgs, reps=2, uniform=0.0)
     run(n, n, cfgs[:1], reps=2, uniform=1.0)
-    run(n, n >> 3, cfgs[:1], reps=3, uniform=1.0)
