@@ -201,6 +201,18 @@ int nbody_direct_workspace_peek(void* stream, const void* workspace, int32_t out
 /* u32 weights -> f32 masses on device (the `as f32` of main.rs:360). */
 int nbody_weights_to_mass_dev(void* stream, int64_t n, const void* weight_u32, void* mass_f32);
 
+/* ---- self-test hooks (host only, no device needed) --------------------------------------------------- */
+/* The device BVH build reproduces the sequential f32 sum of bvh_tree.rs:58-61 with a parallel scan
+ * (csrc/exact_sum.h).  This runs the same scan functions on the CPU, `tile` addends per scan and `seq_run` plain
+ * adds after every restart, so the CPU tests can check them against the plain loop. */
+int nbody_selftest_exact_sum(const float* x, int64_t n, int tile, int seq_run, float* out_sum, int64_t* out_restarts);
+/* Restarts of that scan during the last device BVH build of this context (diagnostic; 0 after a host build). */
+int nbody_bvh_build_restarts(const nbody_ctx* ctx);
+/* 1 if the last tree build of this context ran on the device, 0 if the host builder did it (the device builders
+ * decline what they cannot express, e.g. NaN positions or very deep trees; NBODY_BVH_BUILD_HOST=1 /
+ * NBODY_QUAD_BUILD_HOST=1 force the host). */
+int nbody_last_build_on_device(const nbody_ctx* ctx);
+
 /* ---- kernel timing (bench.py's roofline leg) -------------------------------------------------------- */
 /* A timer brackets every launch of the dominant kernel of a call (direct: direct_fast / direct_exact; tree:
  * the walk kernel) with HIP events recorded on the stream the kernel is launched on. */

@@ -84,6 +84,9 @@ _SIGS = {
     "nbody_direct_step_dev": (C.c_int, [_vp, _i64, _vp, _vp, _f32, _i64, _i64, _vp, _vp, _vp, _f32, _f32, _i32, _vp, _sz, _vp]),
     "nbody_direct_workspace_peek": (C.c_int, [_vp, _vp, C.POINTER(C.c_int32 * 4)]),
     "nbody_weights_to_mass_dev": (C.c_int, [_vp, _i64, _vp, _vp]),
+    "nbody_selftest_exact_sum": (C.c_int, [_vp, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int64)]),
+    "nbody_bvh_build_restarts": (C.c_int, [_vp]),
+    "nbody_last_build_on_device": (C.c_int, [_vp]),
     "nbody_timer_create": (C.c_int, [C.POINTER(_vp)]),
     "nbody_timer_destroy": (None, [_vp]),
     "nbody_timer_read": (C.c_int, [_vp, _i32, C.POINTER(_f64), C.POINTER(_i64)]),
@@ -180,6 +183,15 @@ class Timer:
             self.h = None
 
     __del__ = close
+
+
+def selftest_exact_sum(x, tile=4096, seq_run=64):
+    """CPU emulation of the device build's exact sequential-sum scan -> (sum as np.float32, restarts)."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    out, st = C.c_float(0), _i64(0)
+    check(None, load().nbody_selftest_exact_sum(_ptr(x) if x.size else None, x.size, int(tile), int(seq_run),
+                                                C.byref(out), C.byref(st)))
+    return np.float32(out.value), st.value
 
 
 def host_tree(kind, pos, weight=None, params: "Params | None" = None):
@@ -319,6 +331,12 @@ class Context:
         acc = np.zeros_like(tg)
         check(self.h, f(self.h, int(kind), tg.shape[0], _ptr(tg), _ptr(acc)))
         return acc
+
+    def last_build_on_device(self) -> bool:
+        return bool(self.lib.nbody_last_build_on_device(self.h))
+
+    def bvh_build_restarts(self) -> int:
+        return int(self.lib.nbody_bvh_build_restarts(self.h))
 
     def tree_info(self) -> TreeView:
         v = TreeView()

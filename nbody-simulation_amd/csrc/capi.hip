@@ -13,9 +13,12 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <type_traits>
 
 #include "common.h"
 #include "direct_kernels.h"
+#include "bvh_build.h"
+#include "exact_sum.h"
 #include "quad_build.h"
 #include "tree_build.hpp"
 #include "tree_kernels.h"
@@ -102,9 +105,13 @@ template <class T> struct State {
   int shard_kind = 0;            // tree kind of the last sharded step (decides how a slice maps to rows)
   int* node_depth = nullptr;     // device build: depth of every node
   uint32_t* node_mass = nullptr; // device build: u32 mass of every node
+  float2* node_size = nullptr;   // device BVH build: boundary.size of every node
   size_t node_aux_cap = 0;
   char* qb_scratch = nullptr;
   size_t qb_scratch_bytes = 0;
+  char* bb_scratch = nullptr;    // device BVH build
+  size_t bb_scratch_bytes = 0;
+  bool h_weight_stale = false;   // a device BVH build permuted the rows without touching h_weight
   std::vector<T> h_pos;
   std::vector<uint32_t> h_weight;  // current row order
   std::vector<uint32_t> h_tmp;
@@ -150,6 +157,8 @@ struct nbody_ctx {
   State<float> sf;
   State<double> sd;
   void* workspace = nullptr;
+  int bvh_stops = 0;  // exact-sum restarts of the last device BVH build (diagnostic)
+  bool last_build_device = false;
   size_t workspace_bytes = 0;
   unsigned long long* stats_dev = nullptr;
   unsigned long long last_stats[3] = {0, 0, 0};
@@ -184,8 +193,9 @@ template <class P> void free_dev(P*& p) {
 template <class T> void free_state(State<T>& s) {
   for (auto& st : s.set) { free_dev(st.pos); free_dev(st.vel); free_dev(st.weight); free_dev(st.ids); free_dev(st.mass); }
   free_dev(s.pos_next); free_dev(s.acc); free_dev(s.geom0); free_dev(s.geom1); free_dev(s.link); free_dev(s.order_dev);
-  free_dev(s.node_depth); free_dev(s.node_mass); free_dev(s.qb_scratch);
-  s.node_aux_cap = 0; s.qb_scratch_bytes = 0; s.tree_host_stale = false; s.n_nodes = 0;
+  free_dev(s.node_depth); free_dev(s.node_mass); free_dev(s.node_size); free_dev(s.qb_scratch); free_dev(s.bb_scratch);
+  s.node_aux_cap = 0; s.qb_scratch_bytes = 0; s.bb_scratch_bytes = 0; s.h_weight_stale = false;
+  s.tree_host_stale = false; s.n_nodes = 0;
   s.node_cap = 0; s.n = 0; s.tree_valid = false; s.tree.clear();
   s.h_pos.clear(); s.h_weight.clear();
 }
@@ -386,6 +396,7 @@ template <class T> int upload(nbody_ctx* c, int64_t n, const T* pos, const T* ve
     HIPCHK(c, hipMemcpyAsync(st.mass, mass.data(), (size_t)n * sizeof(T), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
   }
+  s.h_weight_stale = false;
   s.uniform_mass = (uniform && s.h_weight[0] > 0) ? (float)s.h_weight[0] : 0.f;
   s.tree_valid = false;
   if (sizeof(T) == 4) c->has_f32 = true; else c->has_f64 = true;
@@ -439,6 +450,86 @@ template <class T> int upload_tree(nbody_ctx* c, State<T>& s) {
   return NBODY_OK;
 }
 
+template <class T> int ensure_node_aux(nbody_ctx* c, State<T>& s, size_t m) {
+  if (m > s.node_aux_cap) {
+    free_dev(s.node_depth); free_dev(s.node_mass); free_dev(s.node_size);
+    s.node_aux_cap = 0;
+    size_t cap = m + m / 4 + 64;
+    HIPCHK(c, hipMalloc((void**)&s.node_depth, cap * sizeof(int)));
+    HIPCHK(c, hipMalloc((void**)&s.node_mass, cap * sizeof(uint32_t)));
+    HIPCHK(c, hipMalloc((void**)&s.node_size, cap * sizeof(float2)));
+    s.node_aux_cap = cap;
+  }
+  return NBODY_OK;
+}
+
+// BVH built on the device (bvh_build.hip, f32 only).  Returns NBODY_OK, an error, or 1 when the device build declines.
+template <class T> int bvh_build_device(nbody_ctx* c, State<T>& s) {
+  if constexpr (!std::is_same<T, float>::value) {
+    return 1;
+  } else {
+    const int n = (int)s.n;
+    const int leaf = c->params.leaf_size;
+    BvhBuildLayout L = bvh_build_layout(n, leaf);
+    if (s.bb_scratch_bytes < L.total) {
+      free_dev(s.bb_scratch);
+      s.bb_scratch_bytes = 0;
+      HIPCHK(c, hipMalloc((void**)&s.bb_scratch, L.total));
+      s.bb_scratch_bytes = L.total;
+    }
+    auto& in = s.set[s.cur];
+    auto& out = s.set[1 - s.cur];
+    HIPCHK(c, bvh_build_begin(c->stream, in.pos, n, s.bb_scratch, L));
+    // levels are enqueued blind (an empty level costs a few microseconds, a round trip to ask costs more): first as
+    // many as a balanced tree needs plus slack, then four at a time while the next level still has work
+    int lv = 0, lv_end = 3;
+    for (int64_t k = leaf > 0 ? leaf : 1; k < n; k *= 2) ++lv_end;
+    std::vector<int> hostf(kBvhFlagWords + kBvhClasses * kBvhLevels);
+    for (;;) {
+      if (lv_end > kBvhKeyDepth + 1) lv_end = kBvhKeyDepth + 1;
+      HIPCHK(c, bvh_build_levels(c->stream, n, leaf, lv, lv_end, s.bb_scratch, L));
+      HIPCHK(c, hipMemcpyAsync(hostf.data(), s.bb_scratch + L.flags, kBvhFlagWords * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipMemcpyAsync(hostf.data() + kBvhFlagWords, s.bb_scratch + L.qcount, kBvhClasses * kBvhLevels * sizeof(int),
+                               hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      if (hostf[kBvhFallback] != 0) return 1;
+      int pending = 0;
+      for (int k = 0; k < kBvhClasses; ++k) pending += hostf[kBvhFlagWords + k * kBvhLevels + lv_end];
+      if (!pending) break;
+      if (lv_end >= kBvhKeyDepth + 1) return 1;
+      lv = lv_end;
+      lv_end += 4;
+    }
+    const int m = hostf[kBvhNodeCount];
+    if (m <= 0) return 1;
+    int rc = ensure_node_buffers<T>(c, s, (size_t)m);
+    if (rc) return rc;
+    rc = ensure_node_aux<T>(c, s, (size_t)m);
+    if (rc) return rc;
+    HIPCHK(c, bvh_build_finish(c->stream, in.weight, n, m, s.bb_scratch, L, s.order_dev, s.geom0, s.geom1, s.link, s.node_depth,
+                               s.node_mass, s.node_size));
+    GatherArgs<T> g{};  // rows into tree order, as the in-place partition leaves `self.particles` (bvh_tree.rs:73-77)
+    g.perm = s.order_dev;
+    g.n = n;
+    g.pos_in = in.pos; g.pos_out = out.pos;
+    g.weight_in = in.weight;
+    g.mass_out = out.mass;
+    g.vel_in = in.vel; g.vel_out = out.vel;
+    g.weight_out = out.weight;
+    g.ids_in = in.ids; g.ids_out = out.ids;
+    HIPCHK(c, launch_gather<T>(c->stream, g));
+    s.cur = 1 - s.cur;
+    s.h_weight_stale = true;
+    s.n_nodes = m;
+    s.tree_kind = NBODY_TREE_BVH;
+    s.tree_max_depth = hostf[kBvhMaxDepth];
+    s.tree_host_stale = true;
+    s.tree_valid = true;
+    c->bvh_stops = hostf[kBvhStops];
+    return NBODY_OK;
+  }
+}
+
 // Quad tree built on the device (quad_build.hip).  Returns NBODY_OK, an error, or 1 when the device build declines.
 template <class T> int quad_build_device(nbody_ctx* c, State<T>& s) {
   const int n = (int)s.n;
@@ -460,14 +551,8 @@ template <class T> int quad_build_device(nbody_ctx* c, State<T>& s) {
   const int m = flags[1];
   int rc = ensure_node_buffers<T>(c, s, (size_t)m);
   if (rc) return rc;
-  if ((size_t)m > s.node_aux_cap) {
-    free_dev(s.node_depth); free_dev(s.node_mass);
-    s.node_aux_cap = 0;
-    size_t cap = (size_t)m + m / 4 + 64;
-    HIPCHK(c, hipMalloc((void**)&s.node_depth, cap * sizeof(int)));
-    HIPCHK(c, hipMalloc((void**)&s.node_mass, cap * sizeof(uint32_t)));
-    s.node_aux_cap = cap;
-  }
+  rc = ensure_node_aux<T>(c, s, (size_t)m);
+  if (rc) return rc;
   HIPCHK(c, quad_build_phase_b<T>(c->stream, in.pos, in.weight, n, rx, ry, rh, s.qb_scratch, L, s.order_dev, m, flags[2],
                                   s.geom0, s.geom1, s.link, s.node_depth, s.node_mass));
   GatherArgs<T> g{};  // the leaves' own copies of their points, in tree order
@@ -503,6 +588,13 @@ template <class T> int download_tree(nbody_ctx* c, State<T>& s) {
   if (s.n) HIPCHK(c, hipMemcpyAsync(t.order.data(), s.order_dev, (size_t)s.n * 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   t.size_x.resize(m); t.size_y.resize(m);
+  if (s.tree_kind == NBODY_TREE_BVH) {  // boundary.size as the build computed it (max - min)
+    std::vector<float2> sz(m);
+    HIPCHK(c, hipMemcpy(sz.data(), s.node_size, m * sizeof(float2), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < m; ++i) { t.size_x[i] = (T)sz[i].x; t.size_y[i] = (T)sz[i].y; }
+    s.tree_host_stale = false;
+    return NBODY_OK;
+  }
   for (size_t i = 0; i < m; ++i) {
     // height is not stored on the device; hi - lo would round.  Recover it exactly from the parent chain:
     // a child's height is its parent's height / 2 (quad_tree.rs:172), the root's is the parameter.
@@ -529,9 +621,22 @@ template <class T> int tree_build_phase(nbody_ctx* c, State<T>& s, int kind) {
   const int64_t n = s.n;
   s.tree_valid = false;
   s.tree_host_stale = false;
+  c->last_build_device = true;
+  c->bvh_stops = 0;
   if (kind == NBODY_TREE_QUAD && n > 0 && env_int("NBODY_QUAD_BUILD_HOST", 0) == 0) {
     int rc = quad_build_device<T>(c, s);
     if (rc != 1) return rc;  // 1 = the device build declined (too deep for its key / sizes): host builder below
+  }
+  if (kind == NBODY_TREE_BVH && n > 0 && c->params.leaf_size >= 1 && env_int("NBODY_BVH_BUILD_HOST", 0) == 0) {
+    int rc = bvh_build_device<T>(c, s);
+    if (rc != 1) return rc;
+  }
+  c->last_build_device = false;
+  if (s.h_weight_stale) {  // the host builder reads the weights in the current row order
+    s.h_weight.resize((size_t)n);
+    if (n) HIPCHK(c, hipMemcpyAsync(s.h_weight.data(), s.set[s.cur].weight, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    s.h_weight_stale = false;
   }
   const bool trace = env_int("NBODY_TRACE", 0) != 0;
   double tt0 = now_s();
@@ -1104,6 +1209,14 @@ NB_API int nbody_weights_to_mass_dev(void* stream, int64_t n, const void* weight
   hipError_t e = launch_weights_to_mass((hipStream_t)stream, (const uint32_t*)weight_u32, (float*)mass_f32, n);
   return e == hipSuccess ? NBODY_OK : fail_hip(nullptr, e, "weights_to_mass");
 }
+
+NB_API int nbody_selftest_exact_sum(const float* x, int64_t n, int tile, int seq_run, float* out_sum, int64_t* out_restarts) {
+  if ((!x && n > 0) || n < 0 || tile < 1 || seq_run < 1 || !out_sum) return NBODY_ERR_INVALID;
+  *out_sum = xsum::emulate_fold(x, n, tile, seq_run, out_restarts);
+  return NBODY_OK;
+}
+NB_API int nbody_bvh_build_restarts(const nbody_ctx* ctx) { return ctx ? ctx->bvh_stops : 0; }
+NB_API int nbody_last_build_on_device(const nbody_ctx* ctx) { return ctx && ctx->last_build_device ? 1 : 0; }
 
 NB_API int nbody_timer_create(nbody_timer** out) {
   if (!out) return NBODY_ERR_INVALID;

@@ -1,0 +1,127 @@
+// A sequential f32 sum, evaluated in parallel without changing one bit of it.
+//
+// BVHTree::from folds `sum = sum + p.position` over the node's slice in slice order (/root/reference
+// src/bvh_tree.rs:58-61) and splits at `sum / len` (:67): the split, hence the whole tree, depends on every rounding of
+// that chain.  The chain cannot be re-associated, but it can be scanned:
+//
+//   while the running sum s stays inside one binade, s = S * ulp with S an integer in [2^23, 2^24), and
+//   fl(s + x) = (S + r(x)) * ulp, where r(x) is x/ulp rounded to nearest; the only way the result depends on S is the
+//   tie rule (x/ulp exactly half-way: round so that the new S is even), i.e. through the PARITY of S.
+//
+// So one addend is a map {parity of S} -> {integer increment}: a pair (a0, a1).  Maps compose associatively
+// ((f then g)_p = f_p + g_[(p + f_p) & 1]), so a prefix scan of the addends gives every intermediate S exactly.  The scan
+// is only valid while every intermediate stays strictly inside (2^23, 2^24); the first addend that leaves the binade
+// (or is not finite, or is larger than the binade) is found by the same scan, added with a real f32 add, and the scan
+// restarts in the new binade.  For sums of same-signed numbers that happens once per binade (~20 times per node).
+//
+// Host + device: the device fold (bvh_build.hip) and the CPU emulation used by the tests (`nbody_selftest_exact_sum`,
+// capi.hip) run the very same functions.
+#pragma once
+#include <stdint.h>
+#include <string.h>
+
+#if defined(__HIPCC__)
+#define NB_HD __host__ __device__ __forceinline__
+#else
+#define NB_HD inline
+#endif
+
+namespace nbody {
+namespace xsum {
+
+NB_HD uint32_t f2u(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  return u;
+}
+NB_HD float u2f(uint32_t u) {
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+constexpr uint32_t kLo = 1u << 23, kHi = 1u << 24;
+constexpr uint32_t kPoison = 1u << 30;  // an increment no valid S survives
+
+// Running sum s = (-1)^sign * S * 2^(E - 150).  Usable iff s is normal (E >= 3 keeps the step's limit normal) and
+// S > 2^23 (at S == 2^23 a subtraction would land in the finer binade below without S leaving the range).
+struct Chain {
+  uint32_t sign, E, S;
+};
+NB_HD bool chain_open(float s, Chain& c) {
+  const uint32_t b = f2u(s), e = (b >> 23) & 255u;
+  c.sign = b >> 31;
+  c.E = e;
+  c.S = (b & 0x7fffffu) | kLo;
+  return e >= 3u && e != 255u && c.S != kLo;
+}
+NB_HD float chain_value(const Chain& c, uint32_t S) { return u2f((c.sign << 31) | (c.E << 23) | (S & 0x7fffffu)); }
+NB_HD bool in_binade(uint32_t S) { return S > kLo && S < kHi; }
+
+// Increment of S caused by adding x, for S even (a0) / odd (a1).  Wrapping u32 arithmetic.
+// The FPU does the rounding: with C0 = 1.5 * 2^E (integer part 0xC00000, even) and C1 = C0 + ulp (odd), and
+// |x| < 2^(E-2), C + x stays inside the binade, so fl(C + x) - C is x rounded to a multiple of ulp with ties going
+// to the even/odd side exactly as they would from any S of the same parity; the difference of the bit patterns is
+// that multiple as an integer.
+struct Step {
+  uint32_t a0, a1;
+};
+NB_HD Step step_of(float x, uint32_t chain_sign, uint32_t E) {
+  const uint32_t c0 = (E << 23) | 0x400000u;
+  const float xs = u2f(f2u(x) ^ (chain_sign << 31));
+  const float lim = u2f((E - 2u) << 23);  // chain_open guarantees E >= 3
+  const float ax = u2f(f2u(x) & 0x7fffffffu);
+  if (!(ax < lim)) return {kPoison, kPoison};  // too large for this binade, inf or NaN: a real add decides
+  const float r0 = u2f(c0) + xs, r1 = u2f(c0 + 1u) + xs;
+  return {f2u(r0) - c0, f2u(r1) - (c0 + 1u)};
+}
+NB_HD uint32_t apply(uint32_t S, Step f) { return S + ((S & 1u) ? f.a1 : f.a0); }
+// f first, then g
+NB_HD Step compose(Step f, Step g) {
+  Step h;
+  h.a0 = f.a0 + ((f.a0 & 1u) ? g.a1 : g.a0);
+  h.a1 = f.a1 + (((f.a1 + 1u) & 1u) ? g.a1 : g.a0);
+  return h;
+}
+
+// CPU emulation of the device fold's control flow (tile = `tile` addends scanned at once, `seq_run` real adds after a
+// stop), used to check the functions above against the plain loop.  Returns the sum; *stops counts the restarts.
+inline float emulate_fold(const float* x, int64_t n, int tile, int seq_run, int64_t* stops) {
+  float s = 0.0f;
+  int64_t pos = 0, nstop = 0;
+  while (pos < n) {
+    Chain c;
+    if (!chain_open(s, c)) {
+      const int64_t cnt = (n - pos < seq_run) ? n - pos : seq_run;
+      for (int64_t k = 0; k < cnt; ++k) s = s + x[pos + k];
+      pos += cnt;
+      ++nstop;
+      continue;
+    }
+    const int64_t cnt = (n - pos < tile) ? n - pos : tile;
+    // "scan": prefix compositions, then every element checks its own intermediate
+    Step acc{0u, 0u};
+    uint32_t S = c.S;
+    int64_t bad = -1;
+    for (int64_t k = 0; k < cnt; ++k) {
+      const Step f = step_of(x[pos + k], c.sign, c.E);
+      const uint32_t before = apply(c.S, acc);  // what the scan hands to element k
+      const uint32_t after = apply(before, f);
+      if (!in_binade(after)) { bad = k; S = before; break; }
+      acc = compose(acc, f);
+      S = after;
+    }
+    s = chain_value(c, S);
+    if (bad < 0) { pos += cnt; continue; }
+    ++nstop;
+    pos += bad;
+    const int64_t run = (n - pos < seq_run) ? n - pos : seq_run;
+    for (int64_t k = 0; k < run; ++k) s = s + x[pos + k];
+    pos += run;
+  }
+  if (stops) *stops = nstop;
+  return s;
+}
+
+}  // namespace xsum
+}  // namespace nbody

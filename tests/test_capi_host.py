@@ -114,3 +114,75 @@ def test_host_quad_points_outside_root_cell(nb, orc):
     assert not t["overflow"] and not o.overflow
     for k in ("geom", "mass", "is_leaf", "first", "count", "skip", "order"):
         assert np.array_equal(t[k], getattr(o, k)), k
+
+
+# ------------------------------------------------------------------ exact sequential-sum scan (csrc/exact_sum.h)
+def _seq_sum_f32(x):
+    """The chain `sum = sum + x[i]` of bvh_tree.rs:58-61 in f32 (np.cumsum accumulates left to right in the dtype)."""
+    x = np.asarray(x, np.float32)
+    if x.size == 0:
+        return np.float32(0)
+    with np.errstate(all="ignore"):
+        return np.cumsum(x, dtype=np.float32)[-1]
+
+
+def _bits(v):
+    return np.asarray(v, np.float32).view(np.uint32)
+
+
+@pytest.mark.parametrize("tile,seq_run", [(4096, 64), (1024, 64), (256, 64), (4, 1), (7, 3)])
+def test_exact_sum_scan_reproduces_the_sequential_chain(nb, tile, seq_run):
+    """The parallel formulation the device BVH build uses for `sum / len` must round exactly like the plain loop:
+    same-signed data, mixed signs (chains through zero), ties, subnormals, huge dynamic range, inf/NaN, overflow."""
+    C = nb._capi
+    rng = np.random.default_rng(99)
+    cases = {}
+    for n in (0, 1, 2, 63, 64, 65, 1000, 151405):
+        cases[f"uniform{n}"] = rng.random(n) * 1e5
+        cases[f"negative{n}"] = -rng.random(n) * 1e5
+        cases[f"centred{n}"] = rng.standard_normal(n) * 3e4
+        cases[f"halves{n}"] = rng.integers(0, 2000, n) * 0.5
+        cases[f"halves_pm{n}"] = rng.integers(-1000, 1000, n) * 0.5
+        cases[f"wide{n}"] = 10.0 ** rng.uniform(-12, 12, n) * rng.choice([-1.0, 1.0], n)
+        cases[f"ones{n}"] = np.ones(n)
+        cases[f"pow2{n}"] = 2.0 ** rng.integers(-30, 30, n)
+    x = rng.random(5000) * 1e5
+    x[::97] = 1e-40
+    cases["subnormals"] = x
+    for name, bad in (("inf", np.inf), ("nan", np.nan), ("big", 3e38)):
+        x = rng.random(5000) * 1e5
+        x[2500] = bad
+        x[2501] = bad
+        cases[name] = x
+    for name, x in cases.items():
+        x = np.asarray(x, np.float32)
+        got, _ = C.selftest_exact_sum(x, tile, seq_run)
+        want = _seq_sum_f32(x)
+        assert _bits(got) == _bits(want) or (np.isnan(got) and np.isnan(want)), (name, got, want)
+
+
+def test_exact_sum_scan_random_bit_patterns(nb):
+    C = nb._capi
+    rng = np.random.default_rng(3)
+    for it in range(3000):
+        n = int(rng.integers(1, 48))
+        b = rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32)
+        mode = it % 3
+        if mode == 1:   # exponents clustered so that chains stay inside a few binades
+            b = (b & np.uint32(0x807FFFFF)) | (rng.integers(110, 150, n).astype(np.uint32) << np.uint32(23))
+        elif mode == 2:  # few mantissa bits: many exact ties
+            b &= np.uint32(0xFFF80000)
+        x = b.view(np.float32)
+        got, _ = C.selftest_exact_sum(x, 4 if it % 2 else 64, 1 + it % 3)
+        want = _seq_sum_f32(x)
+        assert _bits(got) == _bits(want) or (np.isnan(got) and np.isnan(want)), (it, x, got, want)
+
+
+def test_exact_sum_scan_restarts_are_rare_on_scene_data(nb):
+    """Same-signed coordinates leave a binade about once per doubling of the sum: the scan restarts O(log) times."""
+    C = nb._capi
+    pos, _, _ = nb.scenes.galaxy()
+    for col in (0, 1):
+        got, restarts = C.selftest_exact_sum(pos[:, col], 4096, 64)
+        assert _bits(got) == _bits(_seq_sum_f32(pos[:, col]))
+        assert restarts <= 40

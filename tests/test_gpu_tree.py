@@ -249,3 +249,105 @@ def test_fast_walk_is_within_tolerance_of_the_exact_walk(nb, orc, ctx, dtype, ki
     err = np.abs(fast[::50].astype(np.float64) - exact[::50]).sum(axis=1)
     tol = 2e-5 if dtype == np.float32 else 1e-12
     assert np.all(err <= tol * norm), float((err / norm).max())
+
+
+# ------------------------------------------------------------------ device-side BVH build (bvh_build.hip)
+def _bvh_export_equal(a, b):
+    for k in ("mass", "is_leaf", "first", "count", "skip", "order"):
+        assert np.array_equal(a[k], b[k]), k
+    assert np.array_equal(a["geom"], b["geom"], equal_nan=True)
+    assert a["max_depth"] == b["max_depth"]
+
+
+def _bvh_scenes(nb):
+    rng = np.random.default_rng(17)
+    out = {}
+    for n in (1, 2, 3, 64, 65, 66, 129, 1000, 4097, 20000, 300000):
+        p, _, _ = nb.scenes.plummer(n, seed=300 + n)
+        out[f"plummer{n}"] = (p, (np.arange(n) % 7 + 1).astype(np.uint32))
+    g = nb.scenes.galaxy()
+    out["galaxy"] = (g[0], g[2])
+    # coordinates of both signs: the running sums wander through zero and many binades
+    out["centred"] = ((rng.standard_normal((50000, 2)) * 3e4).astype(F32), np.ones(50000, np.uint32))
+    # everything negative: the max fold starts from 0.0 (bvh_tree.rs:59) and the chain carries a sign
+    out["negative"] = ((-rng.random((30000, 2)) * 1e5).astype(F32), np.ones(30000, np.uint32))
+    # half-integers on a small lattice: ties in almost every add, thousands of equal coordinates
+    out["ties"] = ((rng.integers(0, 400, (40000, 2)) * 0.5).astype(F32), np.ones(40000, np.uint32))
+    # 16 decades of magnitudes
+    out["wide"] = ((10.0 ** rng.uniform(-8, 8, (20000, 2))).astype(F32), np.ones(20000, np.uint32))
+    # u32 masses that wrap
+    out["wrap"] = ((rng.random((5000, 2)) * 1e5).astype(F32), np.full(5000, 0x7FFFFFFF, np.uint32))
+    return out
+
+
+@pytest.mark.parametrize("leaf", [64, 8, 1])
+def test_device_bvh_build_equals_oracle_tree(nb, orc, ctx, leaf):
+    """The tree built on the device (exact-sum scan, rank-list partition, path-key numbering) is the reference's tree:
+    boxes, split order, leaf ranges, permutation, masses and centres of gravity, bit for bit."""
+    C = nb._capi
+    for name, (pos, w) in _bvh_scenes(nb).items():
+        if leaf < 8 and pos.shape[0] > 50000:
+            continue
+        if leaf == 1 and name == "ties":
+            continue   # coincident points can never be split below 2 per leaf: degenerate by definition
+        ctx.set_params(theta=50.0, leaf_size=leaf)
+        ctx.upload(pos, np.zeros_like(pos), w)
+        ctx.accel_tree(C.TREE_BVH, pos[:4])
+        assert ctx.last_build_on_device(), name
+        t = ctx.tree_export()
+        o = orc.BVH(pos, w, leaf_size=leaf).flat()
+        for k in ("mass", "is_leaf", "first", "count", "skip"):
+            assert np.array_equal(t[k], getattr(o, k)), (name, k)
+        assert np.array_equal(t["geom"], o.geom, equal_nan=True), name
+        assert np.array_equal(t["order"], o.ids), name
+        p, _, w2, ids = ctx.download()
+        assert np.array_equal(ids, o.ids) and np.array_equal(p, o.pos_perm) and np.array_equal(w2, w[o.ids]), name
+
+
+def test_device_and_host_bvh_builds_agree_over_steps(nb, monkeypatch):
+    """20 full steps of the reference scene with the device build against 20 with the host build: same rows."""
+    pos, vel, w = nb.scenes.galaxy()
+    res = []
+    for host in ("0", "1"):
+        monkeypatch.setenv("NBODY_BVH_BUILD_HOST", host)
+        world = nb.World(pos, vel, w, method="bvh")
+        cnt = nb.Counting()
+        for _ in range(20):
+            world.update(0.1, cnt)
+        assert world.ctx.last_build_on_device() == (host == "0")
+        res.append(world.particles())
+        world.close()
+    for a, b in zip(*res):
+        assert np.array_equal(a, b)
+
+
+def test_device_bvh_build_then_host_build_keeps_weights_in_row_order(nb, orc, ctx, monkeypatch):
+    """A host build after device builds has to see the weights in the permuted row order."""
+    C = nb._capi
+    pos, vel, _ = nb.scenes.plummer(3000, seed=77)
+    w = (np.arange(3000) % 11 + 1).astype(np.uint32)
+    ctx.set_params(theta=0.5, leaf_size=64)
+    ctx.upload(pos, vel, w)
+    ctx.update_tree(C.TREE_BVH, 0.1, 2)
+    assert ctx.last_build_on_device()
+    monkeypatch.setenv("NBODY_BVH_BUILD_HOST", "1")
+    ctx.update_tree(C.TREE_BVH, 0.1, 1)
+    assert not ctx.last_build_on_device()
+    p, v, w2, ids = ctx.download()
+    rp, rv, rw, rids, _ = orc.update_bvh(pos, vel, w, delta=0.1, theta=0.5, mode=orc.AS_WRITTEN, nsteps=3, nthreads=8)
+    assert np.array_equal(ids, rids) and np.array_equal(p, rp) and np.array_equal(v, rv) and np.array_equal(w2, rw)
+
+
+def test_device_bvh_build_declines_nan_positions(nb, orc, ctx):
+    """minps/maxps are order-dependent on NaN: the device build hands such input to the host builder."""
+    C = nb._capi
+    pos, vel, w = nb.scenes.plummer(2000, seed=5)
+    pos = pos.copy()
+    pos[777, 0] = np.nan
+    ctx.set_params(theta=50.0, leaf_size=64)
+    ctx.upload(pos, vel, w)
+    ctx.accel_tree(C.TREE_BVH, pos[:4])
+    assert not ctx.last_build_on_device()
+    o = orc.BVH(pos, w).flat()
+    t = ctx.tree_export()
+    assert np.array_equal(t["geom"], o.geom, equal_nan=True) and np.array_equal(t["order"], o.ids)
