@@ -6,18 +6,23 @@
 // and the two-pointer partition of crate `partition` 0.1.2 (predicate-true side first).  The order of the particles
 // inside each side feeds the next level's sum, so the permutation has to be exact, not just the split.
 //
-//   * min / max / counts are order-independent: plain block reductions.
+//   * min / max / counts are order-independent: plain reductions.
 //   * the sum is a rounding chain: exact_sum.h scans it (addend = map parity -> increment inside one binade; a real
 //     f32 add whenever the chain leaves its binade).
 //   * the two-pointer partition swaps the k-th misplaced element from the left with the k-th misplaced element from
 //     the right (the pointers only ever stop at misplaced elements): two rank lists from one prefix count, then
 //     independent swaps.
 //
-// Breadth-first, one work-group per node and level; three group sizes (1024 / 256 / 64 threads) by node length, each
-// with its own queue.  Nodes get breadth-first ids; the pre-order index the walk needs is the rank of the node's
-// root-to-node path (left-aligned, depth as tie-break) after one radix sort; `skip` is a binary search for the end of
-// the path's sub-range.  Leaves (unweighted mean in slice order, u32 wrapping mass, :98-131) and the upward pass
-// (:133-158) run bottom-up with one arrival counter per internal node.
+// Two phases.  Nodes longer than kSub points are processed breadth-first, a level at a time, with the node's points
+// spread over many work-groups: bvh_big_fold (the chain: one 1024-thread group per node, the only serial part),
+// bvh_big_count (per-chunk counts; the last chunk to finish picks the axis, the split and creates the children),
+// bvh_big_ranks (rank lists), bvh_big_swap.  Every node of at most kSub points is the root of a subtree that ONE
+// work-group builds completely out of LDS (bvh_subtrees): long nodes by the whole group, short ones a wave each.
+//
+// Nodes get breadth-first ids; the pre-order index the walk needs is the rank of the node's root-to-node path
+// (left-aligned, depth as tie-break) after one radix sort; `skip` is a binary search for the end of the path's
+// sub-range.  Leaves (unweighted mean in slice order, u32 wrapping mass, :98-131) and the upward pass (:133-158) run
+// bottom-up, a wave per leaf, with one arrival counter per internal node.
 //
 // Anything this cannot express (NaN positions — pathfinder's minps/maxps are order-dependent there —, a node deeper than
 // the 56-bit path, more nodes than the buffers hold) raises a flag and the caller uses the host builder instead.
@@ -33,14 +38,25 @@ namespace nbody {
 
 namespace {
 
-constexpr int kEPT = 4;      // consecutive addends per thread and scan
-constexpr int kSeqRun = 64;  // real adds after the scan stops
+constexpr int kEPT = 4;          // consecutive points per thread in the rank-list passes
+constexpr int kSeqRun = 16;      // real adds after every stop of the scan
+constexpr int kChainStart = 256; // real adds at the start of a long node's chain (the sum doubles too often there)
+constexpr int kSub = 4096;       // nodes up to this long are built, subtree and all, by one work-group in LDS
+constexpr int kSubWaves = 8;     // waves of a subtree work-group
+constexpr int kChunk = 2048;     // points per work-group in the multi-group passes over a long node
 constexpr float kMaxF = 3.402823466e+38f;
 
 struct BvhPtrs {
   int* flags;
-  int* qcount;  // [class][level]
-  int* queue;   // [class][level & 1][cap]
+  int* bigcount;    // [level]: long nodes queued for the level
+  int* chunkcount;  // [level]
+  int* bigq;        // [level & 1][cap_big]
+  int* subq;        // subtree roots
+  int* ch_node;     // chunk -> node
+  int* ch_index;    // chunk -> index inside the node
+  int* ch_cx;
+  int* ch_cy;
+  int* ch_before;   // predicate-true points of the node before the chunk
   float2* P;
   uint32_t* ID;
   int* lidx;
@@ -56,14 +72,26 @@ struct BvhPtrs {
   float2* ncog;
   uint32_t* nmass;
   int* narrive;
-  int cap;
+  float2* nmean;
+  int* nsplit;   // long nodes: m | axis << 31
+  int* nchunk0;
+  int* ndone;
+  int* nbad;
+  int cap, cap_big, cap_chunk;
 };
 
 BvhPtrs make_ptrs(char* s, const BvhBuildLayout& L) {
   BvhPtrs a;
   a.flags = (int*)(s + L.flags);
-  a.qcount = (int*)(s + L.qcount);
-  a.queue = (int*)(s + L.queue);
+  a.bigcount = (int*)(s + L.bigcount);
+  a.chunkcount = (int*)(s + L.chunkcount);
+  a.bigq = (int*)(s + L.bigq);
+  a.subq = (int*)(s + L.subq);
+  a.ch_node = (int*)(s + L.ch_node);
+  a.ch_index = (int*)(s + L.ch_index);
+  a.ch_cx = (int*)(s + L.ch_cx);
+  a.ch_cy = (int*)(s + L.ch_cy);
+  a.ch_before = (int*)(s + L.ch_before);
   a.P = (float2*)(s + L.pts);
   a.ID = (uint32_t*)(s + L.ids);
   a.lidx = (int*)(s + L.lidx);
@@ -79,11 +107,16 @@ BvhPtrs make_ptrs(char* s, const BvhBuildLayout& L) {
   a.ncog = (float2*)(s + L.ncog);
   a.nmass = (uint32_t*)(s + L.nmass);
   a.narrive = (int*)(s + L.narrive);
+  a.nmean = (float2*)(s + L.nmean);
+  a.nsplit = (int*)(s + L.nsplit);
+  a.nchunk0 = (int*)(s + L.nchunk0);
+  a.ndone = (int*)(s + L.ndone);
+  a.nbad = (int*)(s + L.nbad);
   a.cap = L.node_cap;
+  a.cap_big = L.big_cap;
+  a.cap_chunk = L.chunk_cap;
   return a;
 }
-
-__host__ __device__ inline int class_of(int len) { return len > 16384 ? 0 : (len > 1024 ? 1 : 2); }
 
 // pathfinder_simd min/max on SSE: `a < b ? a : b` (second operand when unordered); NaNs never get here
 __device__ __forceinline__ float sse_min(float a, float b) { return a < b ? a : b; }
@@ -95,26 +128,325 @@ __device__ __forceinline__ xsum::Step shfl_up_step(xsum::Step v, int d) {
   r.a1 = (uint32_t)__shfl_up((int)v.a1, d, 64);
   return r;
 }
+__device__ __forceinline__ float lane_value(float v, int k) {  // k uniform
+  return xsum::u2f((uint32_t)__builtin_amdgcn_readlane((int)xsum::f2u(v), k));
+}
 
-template <int BLOCK> struct Shared {
-  static constexpr int W = BLOCK / 64;
-  xsum::Step wx[W], wy[W];
-  unsigned wcnt[W];
-  float redf[4][W];
-  unsigned redu[2][W];
+// written by another compute unit in this very kernel: read past the local L1
+__device__ __forceinline__ uint32_t load_agent(const uint32_t* p) {
+  return __hip_atomic_load(const_cast<uint32_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int load_agent(const int* p) { return (int)load_agent(reinterpret_cast<const uint32_t*>(p)); }
+
+// ---- the chain, one add after the other -----------------------------------------------------------------------------
+// s += v[lane K of this row of 16], in every lane: one instruction per add (DPP row_newbcast), no scalar round trip.
+template <int K> __device__ __forceinline__ void add_row_lane(float& s, float v) {
+  asm volatile("v_add_f32_dpp %0, %1, %0 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(s) : "v"(v), "n"(K));
+}
+// Every row of 16 lanes holds the same 16 addends (lane & 15 picks): all 64 lanes carry the same running sums.
+__device__ __forceinline__ void chain_add16(float& sx, float& sy, float2 q) {
+  asm volatile("s_nop 1" ::: "memory");  // q may have just been written by a VALU move: DPP read needs 2 wait states
+#define NB_ADD(K) add_row_lane<K>(sx, q.x); add_row_lane<K>(sy, q.y);
+  NB_ADD(0) NB_ADD(1) NB_ADD(2) NB_ADD(3) NB_ADD(4) NB_ADD(5) NB_ADD(6) NB_ADD(7)
+  NB_ADD(8) NB_ADD(9) NB_ADD(10) NB_ADD(11) NB_ADD(12) NB_ADD(13) NB_ADD(14) NB_ADD(15)
+#undef NB_ADD
+}
+__device__ __forceinline__ void chain_add_some(float& sx, float& sy, float2 q, int cnt) {  // cnt < 16, uniform
+  asm volatile("s_nop 1" ::: "memory");
+#define NB_ADD(K) if (K < cnt) { add_row_lane<K>(sx, q.x); add_row_lane<K>(sy, q.y); }
+  NB_ADD(0) NB_ADD(1) NB_ADD(2) NB_ADD(3) NB_ADD(4) NB_ADD(5) NB_ADD(6) NB_ADD(7)
+  NB_ADD(8) NB_ADD(9) NB_ADD(10) NB_ADD(11) NB_ADD(12) NB_ADD(13) NB_ADD(14)
+#undef NB_ADD
+}
+struct Box {
+  float mnx = kMaxF, mny = kMaxF, mxx = 0.f, mxy = 0.f;  // the fold's start values, bvh_tree.rs:42, :59
+  __device__ __forceinline__ void add(float2 q) {
+    mnx = sse_min(mnx, q.x); mny = sse_min(mny, q.y);
+    mxx = sse_max(mxx, q.x); mxy = sse_max(mxy, q.y);
+  }
+  __device__ __forceinline__ void reduce_wave() {
+    for (int d = 32; d >= 1; d >>= 1) {
+      mnx = sse_min(mnx, __shfl_xor(mnx, d, 64)); mny = sse_min(mny, __shfl_xor(mny, d, 64));
+      mxx = sse_max(mxx, __shfl_xor(mxx, d, 64)); mxy = sse_max(mxy, __shfl_xor(mxy, d, 64));
+    }
+  }
+};
+// sum += P[begin .. begin+count) in order, by one wave; box takes the same points.  The next 16 addends are fetched
+// while the current 16 are added.
+template <class PosPtr>
+__device__ __forceinline__ void chain_run(PosPtr P, int begin, int count, int lane, float& sx, float& sy, Box& box) {
+  const int sub = lane & 15;
+  const int end = begin + count;
+  float2 q = make_float2(0.f, 0.f);
+  if (begin + sub < end) q = P[begin + sub];
+  for (int p = begin; p < end; p += 16) {
+    float2 nq = make_float2(0.f, 0.f);
+    if (p + 16 + sub < end) nq = P[p + 16 + sub];
+    const int cnt = end - p;
+    if (cnt >= 16) {
+      box.add(q);
+      chain_add16(sx, sy, q);
+    } else {
+      if (sub < cnt) box.add(q);
+      chain_add_some(sx, sy, q, cnt);
+    }
+    q = nq;
+  }
+}
+
+// ---- NW waves working on one node --------------------------------------------------------------------------------
+// NW == 1 needs no barrier and no LDS (a wave runs in lock-step); NW > 1 is a whole work-group.
+template <int NW> struct Scratch {
+  xsum::Step wx[NW], wy[NW];
+  unsigned wcnt[NW];
+  float redf[4][NW];
+  unsigned redu[2][NW];
   int bad;
   uint32_t bad_sx, bad_sy;
 };
 
-template <int BLOCK> __device__ __forceinline__ unsigned block_sum(unsigned v, unsigned* slot, int tid) {
+template <int NW> __device__ __forceinline__ void group_sync() {
+  if constexpr (NW > 1) {
+    __syncthreads();
+  } else {  // LDS written by one lane, read by another lane of the same wave
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+}
+
+template <int NW> __device__ __forceinline__ unsigned group_sum(unsigned v, unsigned* slot, int tid) {
   for (int d = 32; d >= 1; d >>= 1) v += (unsigned)__shfl_xor((int)v, d, 64);
-  if constexpr (BLOCK == 64) return v;
-  if ((tid & 63) == 0) slot[tid >> 6] = v;
-  __syncthreads();
-  unsigned t = 0;
-  for (int w = 0; w < BLOCK / 64; ++w) t += slot[w];
-  __syncthreads();
-  return t;
+  if constexpr (NW == 1) {
+    return v;
+  } else {
+    if ((tid & 63) == 0) slot[tid >> 6] = v;
+    __syncthreads();
+    unsigned t = 0;
+    for (int w = 0; w < NW; ++w) t += slot[w];
+    __syncthreads();
+    return t;
+  }
+}
+
+// The fold of bvh_tree.rs:58-61 over P[0, len): min, max, and the sum exactly as the sequential chain rounds it.
+// Every thread of the group returns the same values.
+// EPT: consecutive addends per thread and scan (the scan's fixed cost is per thread: more addends each = cheaper).
+template <int NW, int EPT, class PosPtr>
+__device__ __forceinline__ void exact_fold(PosPtr P, int len, int tid, Scratch<NW>* sh, float& out_sx, float& out_sy,
+                                           float4& out_box, int& stops) {
+  constexpr int TILE = NW * 64 * EPT;
+  const int lane = tid & 63, wave = tid >> 6;
+  float s_x = 0.f, s_y = 0.f;  // uniform across the group
+  float mnx = kMaxF, mny = kMaxF, mxx = 0.f, mxy = 0.f;
+  int pos = 0;
+  bool seq = true;  // the chain starts at 0.0: not in any binade yet
+  while (pos < len) {
+    xsum::Chain cx, cy;
+    if (!seq) {
+      const bool okx = xsum::chain_open(s_x, cx), oky = xsum::chain_open(s_y, cy);
+      seq = !(okx && oky);
+    }
+    if (seq) {  // real adds by ONE wave; the others wait for the result
+      int cnt = pos == 0 ? kChainStart : kSeqRun;
+      cnt = len - pos < cnt ? len - pos : cnt;
+      if (wave == 0) {
+        Box bx;
+        chain_run(P, pos, cnt, lane, s_x, s_y, bx);
+        mnx = sse_min(mnx, bx.mnx); mny = sse_min(mny, bx.mny);
+        mxx = sse_max(mxx, bx.mxx); mxy = sse_max(mxy, bx.mxy);
+      }
+      if constexpr (NW > 1) {
+        if (tid == 0) { sh->bad_sx = xsum::f2u(s_x); sh->bad_sy = xsum::f2u(s_y); }
+        __syncthreads();
+        s_x = xsum::u2f(sh->bad_sx);
+        s_y = xsum::u2f(sh->bad_sy);
+      }
+      pos += cnt;
+      seq = false;
+      continue;
+    }
+    // A chain of same-signed addends leaves its binade about every time the number of addends doubles: near the
+    // start of the chain short scans lose less work to the restart than full ones.
+    int span = pos > 64 ? pos : 64;
+    span = span < TILE ? span : TILE;
+    const int limit = pos + span < len ? pos + span : len;
+    const int base = pos + tid * EPT;
+    xsum::Step fx[EPT], fy[EPT];
+    xsum::Step tx{0u, 0u}, ty{0u, 0u};
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) {
+      fx[j] = xsum::Step{0u, 0u};
+      fy[j] = xsum::Step{0u, 0u};
+    }
+    if (base < limit) {
+#pragma unroll
+      for (int j = 0; j < EPT; ++j) {
+        if (base + j < limit) {
+          const float2 q = P[base + j];
+          fx[j] = xsum::step_of(q.x, cx.sign, cx.E);
+          fy[j] = xsum::step_of(q.y, cy.sign, cy.E);
+          mnx = sse_min(mnx, q.x); mny = sse_min(mny, q.y);
+          mxx = sse_max(mxx, q.x); mxy = sse_max(mxy, q.y);
+        }
+        tx = xsum::compose(tx, fx[j]);
+        ty = xsum::compose(ty, fy[j]);
+      }
+    }
+    xsum::Step ix = tx, iy = ty;  // inclusive scan inside the wave
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const xsum::Step ox = shfl_up_step(ix, d), oy = shfl_up_step(iy, d);
+      if (lane >= d) {
+        ix = xsum::compose(ox, ix);
+        iy = xsum::compose(oy, iy);
+      }
+    }
+    xsum::Step ex = shfl_up_step(ix, 1), ey = shfl_up_step(iy, 1);  // exclusive: everything before my addends
+    if (lane == 0) { ex = xsum::Step{0u, 0u}; ey = xsum::Step{0u, 0u}; }
+    xsum::Step totx, toty;
+    if constexpr (NW > 1) {
+      if (lane == 63) { sh->wx[wave] = ix; sh->wy[wave] = iy; }
+      if (tid == 0) sh->bad = INT_MAX;
+      __syncthreads();
+      // every wave scans the NW wave totals for itself (lanes 0..NW-1): no second barrier
+      xsum::Step wix{0u, 0u}, wiy{0u, 0u};
+      if (lane < NW) { wix = sh->wx[lane]; wiy = sh->wy[lane]; }
+#pragma unroll
+      for (int d = 1; d < NW; d <<= 1) {
+        const xsum::Step ox = shfl_up_step(wix, d), oy = shfl_up_step(wiy, d);
+        if (lane >= d) {
+          wix = xsum::compose(ox, wix);
+          wiy = xsum::compose(oy, wiy);
+        }
+      }
+      totx.a0 = (uint32_t)__builtin_amdgcn_readlane((int)wix.a0, NW - 1);
+      totx.a1 = (uint32_t)__builtin_amdgcn_readlane((int)wix.a1, NW - 1);
+      toty.a0 = (uint32_t)__builtin_amdgcn_readlane((int)wiy.a0, NW - 1);
+      toty.a1 = (uint32_t)__builtin_amdgcn_readlane((int)wiy.a1, NW - 1);
+      if (wave > 0) {
+        xsum::Step px, py;  // all the waves before mine
+        px.a0 = (uint32_t)__builtin_amdgcn_readlane((int)wix.a0, wave - 1);
+        px.a1 = (uint32_t)__builtin_amdgcn_readlane((int)wix.a1, wave - 1);
+        py.a0 = (uint32_t)__builtin_amdgcn_readlane((int)wiy.a0, wave - 1);
+        py.a1 = (uint32_t)__builtin_amdgcn_readlane((int)wiy.a1, wave - 1);
+        ex = xsum::compose(px, ex);
+        ey = xsum::compose(py, ey);
+      }
+    } else {
+      totx.a0 = (uint32_t)__builtin_amdgcn_readlane((int)ix.a0, 63);
+      totx.a1 = (uint32_t)__builtin_amdgcn_readlane((int)ix.a1, 63);
+      toty.a0 = (uint32_t)__builtin_amdgcn_readlane((int)iy.a0, 63);
+      toty.a1 = (uint32_t)__builtin_amdgcn_readlane((int)iy.a1, 63);
+    }
+    uint32_t Sx = xsum::apply(cx.S, ex), Sy = xsum::apply(cy.S, ey);
+    int bad = INT_MAX;
+    uint32_t bsx = 0u, bsy = 0u;
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) {
+      if (base + j < limit && bad == INT_MAX) {
+        const uint32_t nx = xsum::apply(Sx, fx[j]), ny = xsum::apply(Sy, fy[j]);
+        if (!xsum::in_binade(nx) || !xsum::in_binade(ny)) {
+          bad = tid * EPT + j;
+          bsx = Sx;
+          bsy = Sy;
+        } else {
+          Sx = nx;
+          Sy = ny;
+        }
+      }
+    }
+    int first_bad = bad;
+    for (int d = 32; d >= 1; d >>= 1) {
+      const int o = __shfl_xor(first_bad, d, 64);
+      first_bad = o < first_bad ? o : first_bad;
+    }
+    if constexpr (NW > 1) {
+      if (lane == 0 && first_bad != INT_MAX) atomicMin(&sh->bad, first_bad);
+      __syncthreads();
+      first_bad = sh->bad;
+    }
+    if (first_bad == INT_MAX) {
+      s_x = xsum::chain_value(cx, xsum::apply(cx.S, totx));
+      s_y = xsum::chain_value(cy, xsum::apply(cy.S, toty));
+      pos += span;
+    } else {  // the chain is exact up to the addend before first_bad; that addend takes a real add
+      uint32_t vx, vy;
+      if constexpr (NW > 1) {
+        if (bad == first_bad) { sh->bad_sx = bsx; sh->bad_sy = bsy; }
+        __syncthreads();
+        vx = sh->bad_sx;
+        vy = sh->bad_sy;
+      } else {
+        const int owner = first_bad / EPT;
+        vx = (uint32_t)__builtin_amdgcn_readlane((int)bsx, owner);
+        vy = (uint32_t)__builtin_amdgcn_readlane((int)bsy, owner);
+      }
+      s_x = xsum::chain_value(cx, vx);
+      s_y = xsum::chain_value(cy, vy);
+      pos += first_bad;
+      seq = true;
+      ++stops;
+    }
+    if constexpr (NW > 1) __syncthreads();  // sh is rewritten by the next round
+  }
+  for (int d = 32; d >= 1; d >>= 1) {
+    mnx = sse_min(mnx, __shfl_xor(mnx, d, 64)); mny = sse_min(mny, __shfl_xor(mny, d, 64));
+    mxx = sse_max(mxx, __shfl_xor(mxx, d, 64)); mxy = sse_max(mxy, __shfl_xor(mxy, d, 64));
+  }
+  if constexpr (NW > 1) {
+    if (lane == 0) { sh->redf[0][wave] = mnx; sh->redf[1][wave] = mny; sh->redf[2][wave] = mxx; sh->redf[3][wave] = mxy; }
+    __syncthreads();
+    for (int w = 0; w < NW; ++w) {
+      mnx = sse_min(mnx, sh->redf[0][w]); mny = sse_min(mny, sh->redf[1][w]);
+      mxx = sse_max(mxx, sh->redf[2][w]); mxy = sse_max(mxy, sh->redf[3][w]);
+    }
+    __syncthreads();
+  }
+  out_sx = s_x;
+  out_sy = s_y;
+  out_box = make_float4(mnx, mny, mxx, mxy);
+}
+
+// :70-73 — which axis splits closer to the middle; returns the split point m (predicate-true side comes first)
+__device__ __forceinline__ int choose_axis(int len, int cxs, int cys, bool& on_x) {
+  const int half = len / 2;
+  const int hori = half > cxs ? half - cxs : cxs - half;
+  const int vert = half > cys ? half - cys : cys - half;
+  on_x = vert > hori;
+  return on_x ? cxs : cys;
+}
+
+// Children of `node` ([b, b+m) and [b+m, b+len)): records, ids, keys.  One thread.  Returns the first child's id or
+// -1 (buffers full: the fallback flag is up).  leaf[] says which children need no further splitting.
+__device__ __forceinline__ int make_children(const BvhPtrs& a, int node, int b, int len, int m, int leaf_size, bool leaf[2]) {
+  const int d = a.ndepth[node];
+  const int first = atomicAdd(&a.flags[kBvhNodeCount], 2);
+  if (first + 2 > a.cap) {
+    a.flags[kBvhFallback] = 1;
+    return -1;
+  }
+  a.nchild[node] = first;
+  const uint64_t path = a.nkey[node] & ~63ull;
+  for (int side = 0; side < 2; ++side) {
+    const int id = first + side;
+    const int cl = side ? len - m : m;
+    a.nbegin[id] = side ? b + m : b;
+    a.nlen[id] = cl;
+    a.nparent[id] = node;
+    a.nchild[id] = -1;
+    a.ndepth[id] = d + 1;
+    bool lf = !(cl > leaf_size);  // :78-88
+    if (!lf && d + 1 >= kBvhKeyDepth) { a.flags[kBvhFallback] = 1; lf = true; }
+    leaf[side] = lf;
+    a.nleaf[id] = lf ? 1 : 0;
+    const int dc = d + 1 > kBvhKeyDepth ? kBvhKeyDepth : d + 1;
+    a.nkey[id] = (path | (side ? (1ull << (64 - dc)) : 0ull)) | (uint64_t)dc;
+    a.ndone[id] = 0;
+    a.nbad[id] = 0;
+  }
+  atomicMax(&a.flags[kBvhMaxDepth], d + 1);
+  return first;
 }
 
 // ---- init --------------------------------------------------------------------------------------------------------
@@ -134,250 +466,47 @@ __global__ __launch_bounds__(256) void bvh_init(BvhPtrs a, const float2* __restr
     a.ndepth[0] = 0;
     a.nleaf[0] = 0;
     a.nkey[0] = 0ull;
+    a.ndone[0] = 0;
+    a.nbad[0] = 0;
     a.flags[kBvhNodeCount] = 1;
-    const int cls = class_of(n);
-    a.qcount[cls * kBvhLevels] = 1;
-    a.queue[(size_t)(cls * 2) * a.cap] = 0;
+    if (n > kSub) {
+      a.bigcount[0] = 1;
+      a.bigq[0] = 0;
+    } else {
+      a.flags[kBvhSubCount] = 1;
+      a.subq[0] = 0;
+    }
   }
 }
 
-// ---- one level ---------------------------------------------------------------------------------------------------
-template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void bvh_level(BvhPtrs a, int level, int leaf_size) {
-  constexpr int cls = BLOCK == 1024 ? 0 : (BLOCK == 256 ? 1 : 2);
-  constexpr int TILE = BLOCK * kEPT;
-  constexpr int W = BLOCK / 64;
-  __shared__ Shared<BLOCK> sh;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int nq = a.qcount[cls * kBvhLevels + level];
-  const int* queue = a.queue + (size_t)(cls * 2 + (level & 1)) * a.cap;
+// ---- long nodes, one level: fold ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void bvh_big_fold(BvhPtrs a, int level) {
+  __shared__ Scratch<8> sh;
+  const int tid = threadIdx.x;
+  const int nq = a.bigcount[level];
+  const int* queue = a.bigq + (size_t)(level & 1) * a.cap_big;
   int stops = 0;
   for (int qi = blockIdx.x; qi < nq; qi += gridDim.x) {
     const int node = queue[qi];
     const int b = a.nbegin[node], len = a.nlen[node];
-    float2* P = a.P + b;
-    uint32_t* ID = a.ID + b;
-    int* lidx = a.lidx + b;
-    int* ridx = a.ridx + b;
-
-    // -- the fold of bvh_tree.rs:58-61: min, max, and the sum as the sequential chain would round it
-    float s_x = 0.f, s_y = 0.f;  // uniform across the group
-    float mnx = kMaxF, mny = kMaxF, mxx = 0.f, mxy = 0.f;
-    int pos = 0;
-    bool seq = true;  // the chain starts at 0.0: not in any binade yet
-    while (pos < len) {
-      xsum::Chain cx, cy;
-      if (!seq) {
-        const bool okx = xsum::chain_open(s_x, cx), oky = xsum::chain_open(s_y, cy);
-        seq = !(okx && oky);
-      }
-      if (seq) {  // real adds, the same ones in every thread
-        const int cnt = len - pos < kSeqRun ? len - pos : kSeqRun;
-        for (int k = 0; k < cnt; ++k) {
-          const float2 q = P[pos + k];
-          s_x = s_x + q.x;
-          s_y = s_y + q.y;
-          mnx = sse_min(mnx, q.x); mny = sse_min(mny, q.y);
-          mxx = sse_max(mxx, q.x); mxy = sse_max(mxy, q.y);
-        }
-        pos += cnt;
-        seq = false;
-        continue;
-      }
-      const int base = pos + tid * kEPT;
-      xsum::Step fx[kEPT], fy[kEPT];
-      xsum::Step tx{0u, 0u}, ty{0u, 0u};
-#pragma unroll
-      for (int j = 0; j < kEPT; ++j) {
-        fx[j] = xsum::Step{0u, 0u};
-        fy[j] = xsum::Step{0u, 0u};
-        if (base + j < len) {
-          const float2 q = P[base + j];
-          fx[j] = xsum::step_of(q.x, cx.sign, cx.E);
-          fy[j] = xsum::step_of(q.y, cy.sign, cy.E);
-          mnx = sse_min(mnx, q.x); mny = sse_min(mny, q.y);
-          mxx = sse_max(mxx, q.x); mxy = sse_max(mxy, q.y);
-        }
-        tx = xsum::compose(tx, fx[j]);
-        ty = xsum::compose(ty, fy[j]);
-      }
-      xsum::Step ix = tx, iy = ty;  // inclusive scan inside the wave
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const xsum::Step ox = shfl_up_step(ix, d), oy = shfl_up_step(iy, d);
-        if (lane >= d) {
-          ix = xsum::compose(ox, ix);
-          iy = xsum::compose(oy, iy);
-        }
-      }
-      if (lane == 63) { sh.wx[wave] = ix; sh.wy[wave] = iy; }
-      if (tid == 0) sh.bad = INT_MAX;
-      __syncthreads();
-      xsum::Step ex = shfl_up_step(ix, 1), ey = shfl_up_step(iy, 1);  // exclusive: everything before my addends
-      if (lane == 0) { ex = xsum::Step{0u, 0u}; ey = xsum::Step{0u, 0u}; }
-      xsum::Step px{0u, 0u}, py{0u, 0u};
-      for (int w = 0; w < wave; ++w) {
-        px = xsum::compose(px, sh.wx[w]);
-        py = xsum::compose(py, sh.wy[w]);
-      }
-      ex = xsum::compose(px, ex);
-      ey = xsum::compose(py, ey);
-      uint32_t Sx = xsum::apply(cx.S, ex), Sy = xsum::apply(cy.S, ey);
-      int bad = INT_MAX;
-      uint32_t bsx = 0u, bsy = 0u;
-#pragma unroll
-      for (int j = 0; j < kEPT; ++j) {
-        if (base + j < len && bad == INT_MAX) {
-          const uint32_t nx = xsum::apply(Sx, fx[j]), ny = xsum::apply(Sy, fy[j]);
-          if (!xsum::in_binade(nx) || !xsum::in_binade(ny)) {
-            bad = tid * kEPT + j;
-            bsx = Sx;
-            bsy = Sy;
-          } else {
-            Sx = nx;
-            Sy = ny;
-          }
-        }
-      }
-      if (bad != INT_MAX) atomicMin(&sh.bad, bad);
-      __syncthreads();
-      const int first_bad = sh.bad;
-      if (first_bad == INT_MAX) {
-        xsum::Step totx{0u, 0u}, toty{0u, 0u};
-        for (int w = 0; w < W; ++w) {
-          totx = xsum::compose(totx, sh.wx[w]);
-          toty = xsum::compose(toty, sh.wy[w]);
-        }
-        s_x = xsum::chain_value(cx, xsum::apply(cx.S, totx));
-        s_y = xsum::chain_value(cy, xsum::apply(cy.S, toty));
-        pos += TILE;
-      } else {  // the chain is exact up to the addend before first_bad; that addend takes a real add
-        if (bad == first_bad) { sh.bad_sx = bsx; sh.bad_sy = bsy; }
-        __syncthreads();
-        s_x = xsum::chain_value(cx, sh.bad_sx);
-        s_y = xsum::chain_value(cy, sh.bad_sy);
-        pos += first_bad;
-        seq = true;
-        ++stops;
-      }
-      __syncthreads();  // sh is rewritten by the next round
-    }
-    // group-wide min / max
-    for (int d = 32; d >= 1; d >>= 1) {
-      mnx = sse_min(mnx, __shfl_xor(mnx, d, 64)); mny = sse_min(mny, __shfl_xor(mny, d, 64));
-      mxx = sse_max(mxx, __shfl_xor(mxx, d, 64)); mxy = sse_max(mxy, __shfl_xor(mxy, d, 64));
-    }
-    if constexpr (W > 1) {
-      if (lane == 0) { sh.redf[0][wave] = mnx; sh.redf[1][wave] = mny; sh.redf[2][wave] = mxx; sh.redf[3][wave] = mxy; }
-      __syncthreads();
-      for (int w = 0; w < W; ++w) {
-        mnx = sse_min(mnx, sh.redf[0][w]); mny = sse_min(mny, sh.redf[1][w]);
-        mxx = sse_max(mxx, sh.redf[2][w]); mxy = sse_max(mxy, sh.redf[3][w]);
-      }
-      __syncthreads();
-    }
-    const float hx = s_x / (float)len, hy = s_y / (float)len;  // :67
-
-    // -- :70-73: which axis splits closer to the middle
-    unsigned cx_ = 0u, cy_ = 0u;
-    for (int i = tid; i < len; i += BLOCK) {
-      const float2 q = P[i];
-      cx_ += q.x > hx;
-      cy_ += q.y > hy;
-    }
-    const int cxs = (int)block_sum<BLOCK>(cx_, sh.redu[0], tid);
-    const int cys = (int)block_sum<BLOCK>(cy_, sh.redu[1], tid);
-    const int half = len / 2;
-    const int hori = half > cxs ? half - cxs : cxs - half;
-    const int vert = half > cys ? half - cys : cys - half;
-    const bool on_x = vert > hori;
-    const int m = on_x ? cxs : cys;  // predicate-true ("greater") side comes first: the split point
-
-    // -- the two-pointer partition (:74-77) as two rank lists
-    unsigned carry = 0u, nbad_ = 0u;
-    for (int p0 = 0; p0 < len; p0 += TILE) {
-      const int base = p0 + tid * kEPT;
-      bool pr[kEPT];
-      unsigned mine = 0u;
-#pragma unroll
-      for (int j = 0; j < kEPT; ++j) {
-        pr[j] = false;
-        if (base + j < len) {
-          const float2 q = P[base + j];
-          pr[j] = on_x ? q.x > hx : q.y > hy;
-          mine += pr[j];
-        }
-      }
-      unsigned inc = mine;
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const unsigned o = (unsigned)__shfl_up((int)inc, d, 64);
-        if (lane >= d) inc += o;
-      }
-      unsigned before = carry, total;
-      if constexpr (W > 1) {
-        if (lane == 63) sh.wcnt[wave] = inc;
-        __syncthreads();
-        total = 0u;
-        for (int w = 0; w < W; ++w) {
-          if (w < wave) before += sh.wcnt[w];
-          total += sh.wcnt[w];
-        }
-      } else {
-        total = (unsigned)__shfl((int)inc, 63, 64);
-      }
-      unsigned t = before + inc - mine;  // predicate-true elements before my first one
-#pragma unroll
-      for (int j = 0; j < kEPT; ++j) {
-        const int i = base + j;
-        if (i < len) {
-          if (i < m && !pr[j]) { lidx[i - (int)t] = i; ++nbad_; }   // k-th misplaced from the left
-          else if (i >= m && pr[j]) ridx[m - (int)t - 1] = i;       // k-th misplaced from the right
-          t += pr[j];
-        }
-      }
-      carry += total;
-      if constexpr (W > 1) __syncthreads();
-    }
-    const int nbad = (int)block_sum<BLOCK>(nbad_, sh.redu[0], tid);
-    __syncthreads();
-    for (int k = tid; k < nbad; k += BLOCK) {
-      const int l = lidx[k], r = ridx[k];
-      const float2 pl = P[l], pr2 = P[r];
-      P[l] = pr2; P[r] = pl;
-      const uint32_t il = ID[l], ir = ID[r];
-      ID[l] = ir; ID[r] = il;
-    }
-
+    float sx, sy;
+    float4 box;
+    exact_fold<8, 8>((const float2*)(a.P + b), len, tid, &sh, sx, sy, box, stops);
+    const int nch = (len + kChunk - 1) / kChunk;
     if (tid == 0) {
-      a.nbox[node] = make_float4(mnx, mny, mxx, mxy);
-      const int d = a.ndepth[node];
-      const int first = atomicAdd(&a.flags[kBvhNodeCount], 2);
-      if (first + 2 > a.cap) {
-        a.flags[kBvhFallback] = 1;
-      } else {
-        a.nchild[node] = first;
-        const uint64_t path = a.nkey[node] & ~63ull;
-        for (int side = 0; side < 2; ++side) {
-          const int id = first + side;
-          const int cl = side ? len - m : m;
-          a.nbegin[id] = side ? b + m : b;
-          a.nlen[id] = cl;
-          a.nparent[id] = node;
-          a.nchild[id] = -1;
-          a.ndepth[id] = d + 1;
-          bool leaf = !(cl > leaf_size);  // :78-88
-          if (!leaf && d + 1 >= kBvhKeyDepth) { a.flags[kBvhFallback] = 1; leaf = true; }
-          a.nleaf[id] = leaf ? 1 : 0;
-          const int dc = d + 1 > kBvhKeyDepth ? kBvhKeyDepth : d + 1;
-          a.nkey[id] = (path | (side ? (1ull << (64 - dc)) : 0ull)) | (uint64_t)dc;
-          if (!leaf) {
-            const int c2 = class_of(cl);
-            const int slot = atomicAdd(&a.qcount[c2 * kBvhLevels + level + 1], 1);
-            a.queue[(size_t)(c2 * 2 + ((level + 1) & 1)) * a.cap + slot] = id;
-          }
-        }
-        atomicMax(&a.flags[kBvhMaxDepth], d + 1);
+      a.nbox[node] = box;
+      a.nmean[node] = make_float2(sx / (float)len, sy / (float)len);  // :67
+      sh.bad = atomicAdd(&a.chunkcount[level], nch);
+    }
+    __syncthreads();
+    const int c0 = sh.bad;
+    if (tid == 0) a.nchunk0[node] = c0;
+    if (c0 + nch > a.cap_chunk) {
+      if (tid == 0) a.flags[kBvhFallback] = 1;
+    } else {
+      for (int i = tid; i < nch; i += 512) {
+        a.ch_node[c0 + i] = node;
+        a.ch_index[c0 + i] = i;
       }
     }
     __syncthreads();
@@ -385,69 +514,419 @@ __global__ __launch_bounds__(BLOCK) void bvh_level(BvhPtrs a, int level, int lea
   if (tid == 0 && stops) atomicAdd(&a.flags[kBvhStops], stops);
 }
 
-// ---- numbering, leaves, upward pass ------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bvh_keys(BvhPtrs a, int m, uint32_t* __restrict__ vals) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < m) vals[i] = (uint32_t)i;
+// ---- long nodes: counts per chunk; the chunk that finishes last plans the split ------------------------------------
+__global__ __launch_bounds__(256) void bvh_big_count(BvhPtrs a, int level, int leaf_size) {
+  __shared__ unsigned red[2][4];
+  __shared__ int last_flag;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nc = a.chunkcount[level];
+  for (int c = blockIdx.x; c < nc; c += gridDim.x) {
+    const int node = a.ch_node[c], ci = a.ch_index[c];
+    const int b = a.nbegin[node], len = a.nlen[node];
+    const float2 h = a.nmean[node];
+    const int lo = ci * kChunk, hi = lo + kChunk < len ? lo + kChunk : len;
+    unsigned cx = 0u, cy = 0u;
+    for (int i = lo + tid; i < hi; i += 256) {
+      const float2 q = a.P[b + i];
+      cx += q.x > h.x;
+      cy += q.y > h.y;
+    }
+    cx = group_sum<4>(cx, red[0], tid);
+    cy = group_sum<4>(cy, red[1], tid);
+    const int nch = (len + kChunk - 1) / kChunk;
+    if (tid == 0) {
+      a.ch_cx[c] = (int)cx;
+      a.ch_cy[c] = (int)cy;
+      __threadfence();
+      last_flag = atomicAdd(&a.ndone[node], 1) == nch - 1;
+    }
+    __syncthreads();
+    const bool last = last_flag != 0;
+    __syncthreads();
+    if (!last) continue;
+    __threadfence();
+    const int c0 = a.nchunk0[node];
+    unsigned tx = 0u, ty = 0u;
+    for (int i = tid; i < nch; i += 256) {
+      tx += (unsigned)load_agent(a.ch_cx + c0 + i);
+      ty += (unsigned)load_agent(a.ch_cy + c0 + i);
+    }
+    tx = group_sum<4>(tx, red[0], tid);
+    ty = group_sum<4>(ty, red[1], tid);
+    bool on_x;
+    const int m = choose_axis(len, (int)tx, (int)ty, on_x);
+    // exclusive prefix of the chosen axis' counts over the node's chunks
+    unsigned carry = 0u;
+    for (int i0 = 0; i0 < nch; i0 += 256) {
+      const int i = i0 + tid;
+      const unsigned v = i < nch ? (unsigned)load_agent((on_x ? a.ch_cx : a.ch_cy) + c0 + i) : 0u;
+      unsigned inc = v;
+      for (int d = 1; d < 64; d <<= 1) {
+        const unsigned o = (unsigned)__shfl_up((int)inc, d, 64);
+        if (lane >= d) inc += o;
+      }
+      if (lane == 63) red[0][wave] = inc;
+      __syncthreads();
+      unsigned before = carry, total = 0u;
+      for (int w = 0; w < 4; ++w) {
+        if (w < wave) before += red[0][w];
+        total += red[0][w];
+      }
+      if (i < nch) a.ch_before[c0 + i] = (int)(before + inc - v);
+      carry += total;
+      __syncthreads();
+    }
+    if (tid == 0) {
+      a.nsplit[node] = m | (on_x ? (int)0x80000000 : 0);
+      bool leaf[2];
+      const int first = make_children(a, node, b, len, m, leaf_size, leaf);
+      if (first >= 0) {
+        for (int side = 0; side < 2; ++side) {
+          if (leaf[side]) continue;
+          const int cl = side ? len - m : m;
+          if (cl > kSub) {
+            const int slot = atomicAdd(&a.bigcount[level + 1], 1);
+            if (slot < a.cap_big) a.bigq[(size_t)((level + 1) & 1) * a.cap_big + slot] = first + side;
+            else a.flags[kBvhFallback] = 1;
+          } else {
+            const int slot = atomicAdd(&a.flags[kBvhSubCount], 1);
+            a.subq[slot] = first + side;  // at most one entry per node: cap entries
+          }
+        }
+      }
+    }
+  }
 }
-__global__ __launch_bounds__(256) void bvh_rank(const uint32_t* __restrict__ vals_sorted, int m, int* __restrict__ rank) {
+
+// ---- long nodes: the two rank lists of the partition ---------------------------------------------------------------
+__global__ __launch_bounds__(256) void bvh_big_ranks(BvhPtrs a, int level) {
+  __shared__ unsigned wcnt[4];
+  __shared__ unsigned red[4];
+  constexpr int PER = kChunk / 256;  // consecutive points per thread
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nc = a.chunkcount[level];
+  for (int c = blockIdx.x; c < nc; c += gridDim.x) {
+    const int node = a.ch_node[c], ci = a.ch_index[c];
+    const int b = a.nbegin[node], len = a.nlen[node];
+    const float2 h = a.nmean[node];
+    const int sp = a.nsplit[node];
+    const bool on_x = sp < 0;
+    const int m = sp & 0x7fffffff;
+    const int base = ci * kChunk + tid * PER;
+    bool pr[PER];
+    unsigned mine = 0u;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      pr[j] = false;
+      if (base + j < len) {
+        const float2 q = a.P[b + base + j];
+        pr[j] = on_x ? q.x > h.x : q.y > h.y;
+        mine += pr[j];
+      }
+    }
+    unsigned inc = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const unsigned o = (unsigned)__shfl_up((int)inc, d, 64);
+      if (lane >= d) inc += o;
+    }
+    if (lane == 63) wcnt[wave] = inc;
+    __syncthreads();
+    unsigned t = (unsigned)a.ch_before[c] + inc - mine;  // predicate-true points of the node before my first one
+    for (int w = 0; w < wave; ++w) t += wcnt[w];
+    unsigned nbad = 0u;
+    int* lidx = a.lidx + b;
+    int* ridx = a.ridx + b;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const int i = base + j;
+      if (i < len) {
+        if (i < m && !pr[j]) { lidx[i - (int)t] = i; ++nbad; }   // k-th misplaced from the left
+        else if (i >= m && pr[j]) ridx[m - (int)t - 1] = i;      // k-th misplaced from the right
+        t += pr[j];
+      }
+    }
+    nbad = group_sum<4>(nbad, red, tid);
+    if (tid == 0 && nbad) atomicAdd(&a.nbad[node], (int)nbad);
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void bvh_big_swap(BvhPtrs a, int level) {
+  const int nc = a.chunkcount[level];
+  for (int c = blockIdx.x; c < nc; c += gridDim.x) {
+    const int node = a.ch_node[c], ci = a.ch_index[c];
+    const int b = a.nbegin[node];
+    const int nbad = a.nbad[node];
+    float2* P = a.P + b;
+    uint32_t* ID = a.ID + b;
+    const int* lidx = a.lidx + b;
+    const int* ridx = a.ridx + b;
+    const int hi = (ci + 1) * kChunk < nbad ? (ci + 1) * kChunk : nbad;
+    for (int k = ci * kChunk + (int)threadIdx.x; k < hi; k += 256) {
+      const int l = lidx[k], r = ridx[k];
+      const float2 pl = P[l], pr = P[r];
+      P[l] = pr; P[r] = pl;
+      const uint32_t il = ID[l], ir = ID[r];
+      ID[l] = ir; ID[r] = il;
+    }
+  }
+}
+
+// ---- subtrees of at most kSub points, entirely in LDS -----------------------------------------------------------------
+struct SubLds {
+  float2 P[kSub];
+  uint16_t I[kSub];  // which of the subtree's points (as loaded) sits here now
+  uint16_t L[kSub], R[kSub];
+  uint16_t lb[2][kSub / 2], ll[2][kSub / 2];  // node lists of two consecutive levels: begin, length (subtree-relative)
+  int lg[2][kSub / 2];                        // ... and breadth-first id
+  int lcount[2];
+  int loff[kBvhKeyDepth + 2];  // where each level of the subtree starts in its list of internal nodes
+};
+
+// One node whose points are s.P[lb, lb+len): fold, axis, partition, children — by ONE wave.  Up to kSub points the
+// chain is simply added in order (a scan would restart at every doubling of the sum and lose).
+__device__ __forceinline__ void node_in_lds(const BvhPtrs& a, SubLds& s, int gbegin, int lb, int len, int gid, int lane, int nxt,
+                                            int leaf_size) {
+  constexpr int TILE = 64 * kEPT;
+  float2* P = s.P + lb;
+  uint16_t* I = s.I + lb;
+  uint16_t* L = s.L + lb;
+  uint16_t* R = s.R + lb;
+  float sx = 0.f, sy = 0.f;
+  Box box;
+  chain_run((const float2*)P, 0, len, lane, sx, sy, box);
+  box.reduce_wave();
+  const float hx = sx / (float)len, hy = sy / (float)len;  // :67
+  unsigned cx = 0u, cy = 0u;
+  for (int i = lane; i < len; i += 64) {
+    const float2 q = P[i];
+    cx += q.x > hx;
+    cy += q.y > hy;
+  }
+  cx = group_sum<1>(cx, nullptr, lane);
+  cy = group_sum<1>(cy, nullptr, lane);
+  bool on_x;
+  const int m = choose_axis(len, (int)cx, (int)cy, on_x);
+  unsigned carry = 0u, nbad = 0u;
+  for (int p0 = 0; p0 < len; p0 += TILE) {
+    const int base = p0 + lane * kEPT;
+    bool pr[kEPT];
+    unsigned mine = 0u;
+#pragma unroll
+    for (int j = 0; j < kEPT; ++j) {
+      pr[j] = false;
+      if (base + j < len) {
+        const float2 q = P[base + j];
+        pr[j] = on_x ? q.x > hx : q.y > hy;
+        mine += pr[j];
+      }
+    }
+    unsigned inc = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const unsigned o = (unsigned)__shfl_up((int)inc, d, 64);
+      if (lane >= d) inc += o;
+    }
+    const unsigned total = (unsigned)__builtin_amdgcn_readlane((int)inc, 63);
+    unsigned t = carry + inc - mine;
+#pragma unroll
+    for (int j = 0; j < kEPT; ++j) {
+      const int i = base + j;
+      if (i < len) {
+        if (i < m && !pr[j]) { L[i - (int)t] = (uint16_t)i; ++nbad; }
+        else if (i >= m && pr[j]) R[m - (int)t - 1] = (uint16_t)i;
+        t += pr[j];
+      }
+    }
+    carry += total;
+  }
+  nbad = group_sum<1>(nbad, nullptr, lane);
+  group_sync<1>();
+  for (int k = lane; k < (int)nbad; k += 64) {
+    const int l = L[k], r = R[k];
+    const float2 pl = P[l], pr = P[r];
+    P[l] = pr; P[r] = pl;
+    const uint16_t il = I[l], ir = I[r];
+    I[l] = ir; I[r] = il;
+  }
+  if (lane == 0) {
+    a.nbox[gid] = make_float4(box.mnx, box.mny, box.mxx, box.mxy);
+    bool leaf[2];
+    const int first = make_children(a, gid, gbegin + lb, len, m, leaf_size, leaf);
+    if (first >= 0) {
+      for (int side = 0; side < 2; ++side) {
+        if (leaf[side]) continue;
+        const int slot = atomicAdd(&s.lcount[nxt], 1);
+        s.lb[nxt][slot] = (uint16_t)(side ? lb + m : lb);
+        s.ll[nxt][slot] = (uint16_t)(side ? len - m : m);
+        s.lg[nxt][slot] = first + side;
+      }
+    }
+  }
+  group_sync<1>();
+}
+
+// Centre and mass of an internal node from its two children (bvh_tree.rs:133-158)
+__device__ __forceinline__ void combine_children(const BvhPtrs& a, int node) {
+  const int c0 = a.nchild[node];
+  if (c0 < 0) return;  // children were never made (buffers full; the fallback flag is up)
+  const float2 g0 = a.ncog[c0], g1 = a.ncog[c0 + 1];
+  const uint32_t m0 = a.nmass[c0], m1 = a.nmass[c0 + 1];
+  const uint32_t ms = m0 + m1;                                      // :148
+  const float bx = (g0.x * (float)m0) + (g1.x * (float)m1);         // :150-153
+  const float by = (g0.y * (float)m0) + (g1.y * (float)m1);
+  a.ncog[node] = make_float2(bx / (float)ms, by / (float)ms);       // :154
+  a.nmass[node] = ms;
+}
+
+// make_leaf (:40-54) + leaf mass and centre (:98-131) by one wave.  P: the leaf's points; wid(i): row of point i.
+template <class PosPtr, class RowOf>
+__device__ __forceinline__ void leaf_by_wave(const BvhPtrs& a, int leaf, PosPtr P, int len, int lane, const uint32_t* weight,
+                                             RowOf row_of) {
+  float mnx = kMaxF, mny = kMaxF, mxx = 0.f, mxy = 0.f, sx = 0.f, sy = 0.f;
+  uint32_t ms = 0u;
+  for (int k0 = 0; k0 < len; k0 += 64) {
+    const int cnt = len - k0 < 64 ? len - k0 : 64;
+    float2 q = make_float2(0.f, 0.f);
+    if (lane < cnt) {
+      q = P[k0 + lane];
+      mnx = sse_min(mnx, q.x); mny = sse_min(mny, q.y);
+      mxx = sse_max(mxx, q.x); mxy = sse_max(mxy, q.y);
+      ms += weight[row_of(k0 + lane)];  // u32, wraps like the release build; any order
+    }
+    for (int k = 0; k < cnt; ++k) {  // slice order
+      sx = sx + lane_value(q.x, k);
+      sy = sy + lane_value(q.y, k);
+    }
+  }
+  for (int d = 32; d >= 1; d >>= 1) {
+    mnx = sse_min(mnx, __shfl_xor(mnx, d, 64)); mny = sse_min(mny, __shfl_xor(mny, d, 64));
+    mxx = sse_max(mxx, __shfl_xor(mxx, d, 64)); mxy = sse_max(mxy, __shfl_xor(mxy, d, 64));
+    ms += (uint32_t)__shfl_xor((int)ms, d, 64);
+  }
+  if (lane == 0) {
+    a.nbox[leaf] = make_float4(mnx, mny, mxx, mxy);
+    a.ncog[leaf] = make_float2(sx / (float)len, sy / (float)len);  // NaN for an empty leaf, as upstream
+    a.nmass[leaf] = ms;
+  }
+}
+
+__global__ __launch_bounds__(kSubWaves * 64) void bvh_subtrees(BvhPtrs a, const uint32_t* __restrict__ weight, int leaf_size) {
+  __shared__ SubLds s;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nsub = a.flags[kBvhSubCount];
+  for (int si = blockIdx.x; si < nsub; si += gridDim.x) {
+    const int root = a.subq[si];
+    const int b = a.nbegin[root], len = a.nlen[root];
+    int* list = a.lidx + b;  // the subtree's internal nodes, level after level (the global rank lists are free now)
+    for (int i = tid; i < len; i += kSubWaves * 64) {
+      s.P[i] = a.P[b + i];
+      s.I[i] = (uint16_t)i;
+    }
+    if (tid == 0) {
+      s.lb[0][0] = 0;
+      s.ll[0][0] = (uint16_t)len;  // kSub = 4096 fits
+      s.lg[0][0] = root;
+      s.lcount[0] = 1;
+      s.lcount[1] = 0;
+    }
+    __syncthreads();
+    int cur = 0, nlev = 0, nint = 0;
+    for (;;) {
+      const int nc = s.lcount[cur];
+      if (nc == 0) break;
+      if (nint + nc > len || nlev > kBvhKeyDepth) {  // only degenerate input gets here
+        if (tid == 0) a.flags[kBvhFallback] = 1;
+        break;
+      }
+      for (int e = tid; e < nc; e += kSubWaves * 64) list[nint + e] = s.lg[cur][e];
+      if (tid == 0) s.loff[nlev] = nint;
+      nint += nc;
+      ++nlev;
+      for (int e = wave; e < nc; e += kSubWaves)  // a wave per node
+        node_in_lds(a, s, b, s.lb[cur][e], s.ll[cur][e], s.lg[cur][e], lane, cur ^ 1, leaf_size);
+      __syncthreads();
+      if (tid == 0) s.lcount[cur] = 0;
+      cur ^= 1;
+      __syncthreads();
+    }
+    if (tid == 0) s.loff[nlev] = nint;
+    __syncthreads();
+    // leaves: children of the listed nodes that were not split further; a wave each, points still in LDS
+    for (int task = wave; task < 2 * nint; task += kSubWaves) {
+      const int c0 = a.nchild[list[task >> 1]];
+      if (c0 < 0) continue;
+      const int c = c0 + (task & 1);
+      if (!a.nleaf[c]) continue;
+      const int lb = a.nbegin[c] - b;
+      const uint32_t* ids = a.ID + b;
+      const uint16_t* I = s.I + lb;
+      leaf_by_wave(a, c, (const float2*)(s.P + lb), a.nlen[c], lane, weight, [&](int i) { return ids[I[i]]; });
+    }
+    __syncthreads();
+    // upward pass inside the subtree: deepest level first
+    for (int lev = nlev - 1; lev >= 0; --lev) {
+      for (int e = s.loff[lev] + tid; e < s.loff[lev + 1]; e += kSubWaves * 64) combine_children(a, list[e]);
+      __syncthreads();
+    }
+    // the subtree's rows go back in their final order
+    uint32_t ids[kSub / (kSubWaves * 64)];
+#pragma unroll
+    for (int j = 0; j < kSub / (kSubWaves * 64); ++j) {
+      const int i = tid + j * kSubWaves * 64;
+      ids[j] = i < len ? a.ID[b + s.I[i]] : 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kSub / (kSubWaves * 64); ++j) {
+      const int i = tid + j * kSubWaves * 64;
+      if (i < len) {
+        a.ID[b + i] = ids[j];
+        a.P[b + i] = s.P[i];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// The nodes above the subtrees (ids below n_top, made level by level): leaves hanging directly off a long node, then
+// the long nodes themselves, deepest level first.  One work-group: a few hundred nodes.
+__global__ __launch_bounds__(256) void bvh_top_upward(BvhPtrs a, const uint32_t* __restrict__ weight, int n_top) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int id = wave; id < n_top; id += 4) {
+    if (!a.nleaf[id]) continue;
+    const int b = a.nbegin[id];
+    const uint32_t* ids = a.ID + b;
+    leaf_by_wave(a, id, (const float2*)(a.P + b), a.nlen[id], lane, weight, [&](int i) { return ids[i]; });
+  }
+  __syncthreads();
+  for (int d = a.flags[kBvhMaxDepth]; d >= 0; --d) {
+    for (int id = tid; id < n_top; id += 256)
+      if (a.ndepth[id] == d && !a.nleaf[id] && a.nlen[id] > kSub) combine_children(a, id);
+    __syncthreads();
+  }
+}
+
+// ---- numbering, leaves, upward pass ------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bvh_keys(BvhPtrs a, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.cap) return;
+  const int m = a.flags[kBvhNodeCount] < a.cap ? a.flags[kBvhNodeCount] : a.cap;
+  keys[i] = i < m ? a.nkey[i] : ~0ull;  // unused slots sort last
+  vals[i] = (uint32_t)i;
+}
+__global__ __launch_bounds__(256) void bvh_rank(BvhPtrs a, const uint32_t* __restrict__ vals_sorted, int* __restrict__ rank) {
   const int r = blockIdx.x * 256 + threadIdx.x;
+  const int m = a.flags[kBvhNodeCount] < a.cap ? a.flags[kBvhNodeCount] : a.cap;
   if (r < m) rank[vals_sorted[r]] = r;
 }
 
-// written by another compute unit in this very kernel: read past the local L1
-__device__ __forceinline__ uint32_t load_agent(const uint32_t* p) {
-  return __hip_atomic_load(const_cast<uint32_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ float load_agent(const float* p) {
-  return xsum::u2f(load_agent(reinterpret_cast<const uint32_t*>(p)));
-}
-
-// One thread per leaf: make_leaf (:40-54), leaf mass and centre (:98-131), then up the parent chain; the second child
-// to arrive at a node computes it (:133-158).
-__global__ __launch_bounds__(64) void bvh_upward(BvhPtrs a, const uint32_t* __restrict__ weight, int m) {
-  const int i = blockIdx.x * 64 + threadIdx.x;
-  if (i >= m || !a.nleaf[i]) return;
-  const int b = a.nbegin[i], len = a.nlen[i];
-  float mnx = kMaxF, mny = kMaxF, mxx = 0.f, mxy = 0.f, sx = 0.f, sy = 0.f;
-  uint32_t ms = 0u;
-  for (int k = 0; k < len; ++k) {
-    const float2 q = a.P[b + k];
-    mnx = sse_min(mnx, q.x); mny = sse_min(mny, q.y);
-    mxx = sse_max(mxx, q.x); mxy = sse_max(mxy, q.y);
-    sx = sx + q.x;
-    sy = sy + q.y;
-    ms += weight[a.ID[b + k]];  // u32, wraps like the release build
-  }
-  a.nbox[i] = make_float4(mnx, mny, mxx, mxy);
-  float cgx = sx / (float)len, cgy = sy / (float)len;  // NaN for an empty leaf, as upstream
-  int cur = i;
-  for (;;) {
-    a.ncog[cur] = make_float2(cgx, cgy);
-    a.nmass[cur] = ms;
-    const int p = a.nparent[cur];
-    if (p < 0) break;
-    __threadfence();
-    if (atomicAdd(&a.narrive[p], 1) == 0) break;  // the sibling finishes this parent
-    __threadfence();
-    const int c0 = a.nchild[p], c1 = c0 + 1;
-    const float* cog = (const float*)a.ncog;
-    const float x0 = load_agent(cog + 2 * c0), y0 = load_agent(cog + 2 * c0 + 1);
-    const float x1 = load_agent(cog + 2 * c1), y1 = load_agent(cog + 2 * c1 + 1);
-    const uint32_t m0 = load_agent(a.nmass + c0), m1 = load_agent(a.nmass + c1);
-    ms = m0 + m1;                                                   // :148
-    const float bx = (x0 * (float)m0) + (x1 * (float)m1);           // :150-153
-    const float by = (y0 * (float)m0) + (y1 * (float)m1);
-    cgx = bx / (float)ms;                                           // :154
-    cgy = by / (float)ms;
-    cur = p;
-  }
-}
-
-__global__ __launch_bounds__(256) void bvh_emit(BvhPtrs a, int m, const int* __restrict__ rank,
-                                                const uint64_t* __restrict__ keys_sorted, float4* __restrict__ geom0,
-                                                float4* __restrict__ geom1, int4* __restrict__ link, int* __restrict__ depth_out,
-                                                uint32_t* __restrict__ mass_out, float2* __restrict__ size_out) {
+__global__ __launch_bounds__(256) void bvh_emit(BvhPtrs a, const int* __restrict__ rank, const uint64_t* __restrict__ keys_sorted,
+                                                float4* __restrict__ geom0, float4* __restrict__ geom1, int4* __restrict__ link,
+                                                int* __restrict__ depth_out, uint32_t* __restrict__ mass_out,
+                                                float2* __restrict__ size_out) {
+  const int m = a.flags[kBvhNodeCount] < a.cap ? a.flags[kBvhNodeCount] : a.cap;
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= m) return;
   const int idx = rank[i];
@@ -493,12 +972,24 @@ BvhBuildLayout bvh_build_layout(int64_t n, int leaf_size) {
   // leaves end up between half full and full: ~2.7 N / leaf_size nodes.  More than this -> host builder
   const size_t lf = (size_t)(leaf_size > 0 ? leaf_size : 1);
   const size_t C = (4 * N / lf < 2 * N ? 4 * N / lf : 2 * N) + 4096;
+  const size_t CB = N / (size_t)(kSub + 1) + 2;      // long nodes of one level
+  const size_t CC = N / (size_t)kChunk + CB + 2;     // their chunks
   L.node_cap = (int)C;
+  L.big_cap = (int)CB;
+  L.chunk_cap = (int)CC;
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes); return o; };
   L.flags = take(sizeof(int) * kBvhFlagWords);
-  L.qcount = take(sizeof(int) * kBvhClasses * kBvhLevels);
-  L.queue = take(sizeof(int) * kBvhClasses * 2 * C);
+  L.bigcount = take(sizeof(int) * kBvhLevels);
+  L.chunkcount = take(sizeof(int) * kBvhLevels);
+  L.zero_end = off;
+  L.bigq = take(4 * 2 * CB);
+  L.subq = take(4 * C);
+  L.ch_node = take(4 * CC);
+  L.ch_index = take(4 * CC);
+  L.ch_cx = take(4 * CC);
+  L.ch_cy = take(4 * CC);
+  L.ch_before = take(4 * CC);
   L.pts = take(sizeof(float2) * N);
   L.ids = take(4 * N);
   L.lidx = take(4 * N);
@@ -514,6 +1005,12 @@ BvhBuildLayout bvh_build_layout(int64_t n, int leaf_size) {
   L.ncog = take(8 * C);
   L.nmass = take(4 * C);
   L.narrive = take(4 * C);
+  L.nmean = take(8 * C);
+  L.nsplit = take(4 * C);
+  L.nchunk0 = take(4 * C);
+  L.ndone = take(4 * C);
+  L.nbad = take(4 * C);
+  L.keys = take(8 * C);
   L.keys_sorted = take(8 * C);
   L.vals = take(4 * C);
   L.vals_sorted = take(4 * C);
@@ -527,8 +1024,14 @@ BvhBuildLayout bvh_build_layout(int64_t n, int leaf_size) {
   return L;
 }
 
+int bvh_build_first_levels(int64_t n) {
+  int lv = 0;
+  for (int64_t k = kSub; k < n; k *= 2) ++lv;  // a balanced tree's long levels
+  return lv;
+}
+
 hipError_t bvh_build_begin(hipStream_t s, const void* pos, int n, char* scratch, const BvhBuildLayout& L) {
-  hipError_t e = hipMemsetAsync(scratch + L.flags, 0, L.queue - L.flags, s);  // flags + level counters
+  hipError_t e = hipMemsetAsync(scratch + L.flags, 0, L.zero_end - L.flags, s);  // flags + level counters
   if (e != hipSuccess) return e;
   BvhPtrs a = make_ptrs(scratch, L);
   bvh_init<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>(a, (const float2*)pos, n);
@@ -540,40 +1043,40 @@ hipError_t bvh_build_levels(hipStream_t s, int n, int leaf_size, int level_begin
   BvhPtrs a = make_ptrs(scratch, L);
   for (int level = level_begin; level < level_end && level < kBvhLevels - 1; ++level) {
     const int64_t width = level < 30 ? (int64_t)1 << level : (int64_t)1 << 30;  // a level never has more nodes than this
-    auto grid = [&](int64_t min_len, int64_t cap) {
-      int64_t g = n / min_len + 1;
-      if (g > width) g = width;
-      if (g > cap) g = cap;
-      return dim3((unsigned)(g < 1 ? 1 : g));
-    };
-    if (n > 16384) bvh_level<1024><<<grid(16385, 512), dim3(1024), 0, s>>>(a, level, leaf_size);
-    if (n > 1024) bvh_level<256><<<grid(1025, 2048), dim3(256), 0, s>>>(a, level, leaf_size);
-    bvh_level<64><<<grid(leaf_size > 0 ? leaf_size + 1 : 1, 8192), dim3(64), 0, s>>>(a, level, leaf_size);
+    int64_t gb = L.big_cap < width ? L.big_cap : width;
+    int64_t gc = L.chunk_cap;
+    if (gc > 4096) gc = 4096;
+    bvh_big_fold<<<dim3((unsigned)gb), dim3(512), 0, s>>>(a, level);
+    bvh_big_count<<<dim3((unsigned)gc), dim3(256), 0, s>>>(a, level, leaf_size);
+    bvh_big_ranks<<<dim3((unsigned)gc), dim3(256), 0, s>>>(a, level);
+    bvh_big_swap<<<dim3((unsigned)gc), dim3(256), 0, s>>>(a, level);
   }
   return hipGetLastError();
 }
 
-hipError_t bvh_build_finish(hipStream_t s, const uint32_t* weight, int n, int n_nodes, char* scratch, const BvhBuildLayout& L,
+hipError_t bvh_build_finish(hipStream_t s, const uint32_t* weight, int n, int leaf_size, int n_top, char* scratch,
+                            const BvhBuildLayout& L,
                             uint32_t* order_out, void* geom0, void* geom1, void* link, int* depth_out, uint32_t* mass_out,
                             float2* size_out) {
   BvhPtrs a = make_ptrs(scratch, L);
-  const int m = n_nodes;
+  const int C = L.node_cap;
+  uint64_t* keys = (uint64_t*)(scratch + L.keys);
   uint32_t* vals = (uint32_t*)(scratch + L.vals);
   uint32_t* vals_sorted = (uint32_t*)(scratch + L.vals_sorted);
   uint64_t* keys_sorted = (uint64_t*)(scratch + L.keys_sorted);
   int* rank = (int*)(scratch + L.rank);
-  const dim3 gm((unsigned)((m + 255) / 256));
-  hipError_t e = hipMemsetAsync(a.narrive, 0, sizeof(int) * (size_t)m, s);
-  if (e != hipSuccess) return e;
-  bvh_keys<<<gm, dim3(256), 0, s>>>(a, m, vals);
+  int64_t gs = (int64_t)n / 64 + 1;  // subtree roots
+  if (gs > 2048) gs = 2048;
+  bvh_subtrees<<<dim3((unsigned)gs), dim3(kSubWaves * 64), 0, s>>>(a, weight, leaf_size);
+  bvh_top_upward<<<dim3(1), dim3(256), 0, s>>>(a, weight, n_top);
+  const dim3 gm((unsigned)((C + 255) / 256));
+  bvh_keys<<<gm, dim3(256), 0, s>>>(a, keys, vals);
   size_t tb = L.cub_temp_bytes;
-  e = hipcub::DeviceRadixSort::SortPairs((void*)(scratch + L.cub_temp), tb, (const uint64_t*)a.nkey, keys_sorted,
-                                         (const uint32_t*)vals, vals_sorted, m, 0, 64, s);
+  hipError_t e = hipcub::DeviceRadixSort::SortPairs((void*)(scratch + L.cub_temp), tb, (const uint64_t*)keys, keys_sorted,
+                                                    (const uint32_t*)vals, vals_sorted, C, 0, 64, s);
   if (e != hipSuccess) return e;
-  bvh_rank<<<gm, dim3(256), 0, s>>>(vals_sorted, m, rank);
-  bvh_upward<<<dim3((unsigned)((m + 63) / 64)), dim3(64), 0, s>>>(a, weight, m);
-  bvh_emit<<<gm, dim3(256), 0, s>>>(a, m, rank, keys_sorted, (float4*)geom0, (float4*)geom1, (int4*)link, depth_out, mass_out,
-                                    size_out);
+  bvh_rank<<<gm, dim3(256), 0, s>>>(a, vals_sorted, rank);
+  bvh_emit<<<gm, dim3(256), 0, s>>>(a, rank, keys_sorted, (float4*)geom0, (float4*)geom1, (int4*)link, depth_out, mass_out, size_out);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
   return hipMemcpyAsync(order_out, a.ID, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToDevice, s);

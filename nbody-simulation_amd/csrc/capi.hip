@@ -480,34 +480,36 @@ template <class T> int bvh_build_device(nbody_ctx* c, State<T>& s) {
     auto& in = s.set[s.cur];
     auto& out = s.set[1 - s.cur];
     HIPCHK(c, bvh_build_begin(c->stream, in.pos, n, s.bb_scratch, L));
-    // levels are enqueued blind (an empty level costs a few microseconds, a round trip to ask costs more): first as
-    // many as a balanced tree needs plus slack, then four at a time while the next level still has work
-    int lv = 0, lv_end = 3;
-    for (int64_t k = leaf > 0 ? leaf : 1; k < n; k *= 2) ++lv_end;
-    std::vector<int> hostf(kBvhFlagWords + kBvhClasses * kBvhLevels);
-    for (;;) {
+    // long-node levels are enqueued blind (an empty level costs a few microseconds, asking costs a round trip): first
+    // as many as a balanced tree has, then two at a time while a next level still has long nodes
+    const int first_levels = bvh_build_first_levels(n);
+    int lv = 0, lv_end = first_levels > 0 ? first_levels + 1 : 0;
+    int hostf[kBvhFlagWords + kBvhLevels];
+    hostf[kBvhNodeCount] = 1;  // n <= subtree size: the root is all there is above the subtrees
+    while (lv_end > 0) {
       if (lv_end > kBvhKeyDepth + 1) lv_end = kBvhKeyDepth + 1;
       HIPCHK(c, bvh_build_levels(c->stream, n, leaf, lv, lv_end, s.bb_scratch, L));
-      HIPCHK(c, hipMemcpyAsync(hostf.data(), s.bb_scratch + L.flags, kBvhFlagWords * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(c, hipMemcpyAsync(hostf.data() + kBvhFlagWords, s.bb_scratch + L.qcount, kBvhClasses * kBvhLevels * sizeof(int),
-                               hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipMemcpyAsync(hostf, s.bb_scratch + L.flags, kBvhFlagWords * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipMemcpyAsync(hostf + kBvhFlagWords, s.bb_scratch + L.bigcount, kBvhLevels * sizeof(int), hipMemcpyDeviceToHost,
+                               c->stream));
       HIPCHK(c, hipStreamSynchronize(c->stream));
       if (hostf[kBvhFallback] != 0) return 1;
-      int pending = 0;
-      for (int k = 0; k < kBvhClasses; ++k) pending += hostf[kBvhFlagWords + k * kBvhLevels + lv_end];
-      if (!pending) break;
+      if (hostf[kBvhFlagWords + lv_end] == 0) break;
       if (lv_end >= kBvhKeyDepth + 1) return 1;
       lv = lv_end;
-      lv_end += 4;
+      lv_end += 2;
     }
-    const int m = hostf[kBvhNodeCount];
-    if (m <= 0) return 1;
-    int rc = ensure_node_buffers<T>(c, s, (size_t)m);
+    int rc = ensure_node_buffers<T>(c, s, (size_t)L.node_cap);
     if (rc) return rc;
-    rc = ensure_node_aux<T>(c, s, (size_t)m);
+    rc = ensure_node_aux<T>(c, s, (size_t)L.node_cap);
     if (rc) return rc;
-    HIPCHK(c, bvh_build_finish(c->stream, in.weight, n, m, s.bb_scratch, L, s.order_dev, s.geom0, s.geom1, s.link, s.node_depth,
+    HIPCHK(c, bvh_build_finish(c->stream, in.weight, n, leaf, hostf[kBvhNodeCount], s.bb_scratch, L, s.order_dev, s.geom0, s.geom1, s.link, s.node_depth,
                                s.node_mass, s.node_size));
+    HIPCHK(c, hipMemcpyAsync(hostf, s.bb_scratch + L.flags, kBvhFlagWords * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (hostf[kBvhFallback] != 0) return 1;
+    const int m = hostf[kBvhNodeCount];
+    if (m <= 0 || m > L.node_cap) return 1;
     GatherArgs<T> g{};  // rows into tree order, as the in-place partition leaves `self.particles` (bvh_tree.rs:73-77)
     g.perm = s.order_dev;
     g.n = n;
