@@ -16,7 +16,8 @@ enum : int {
   kBvhMaxDepth = 2,
   kBvhStops = 3,      // restarts of the exact-sum scan (diagnostic)
   kBvhSubCount = 4,   // subtree roots queued for bvh_subtrees
-  kBvhFlagWords = 8,
+  kBvhDebug = 8,      // 8 words of max-over-groups cycle counts per phase of bvh_subtrees (NB_BVH_TIMING builds)
+  kBvhFlagWords = 16,
 };
 
 struct BvhBuildLayout {

@@ -197,12 +197,10 @@ __device__ __forceinline__ void chain_run(PosPtr P, int begin, int count, int la
 // ---- NW waves working on one node --------------------------------------------------------------------------------
 // NW == 1 needs no barrier and no LDS (a wave runs in lock-step); NW > 1 is a whole work-group.
 template <int NW> struct Scratch {
-  xsum::Step wx[NW], wy[NW];
-  unsigned wcnt[NW];
-  float redf[4][NW];
-  unsigned redu[2][NW];
+  xsum::Step w[NW];
+  float redf[2][NW];
   int bad;
-  uint32_t bad_sx, bad_sy;
+  uint32_t bad_s;
 };
 
 template <int NW> __device__ __forceinline__ void group_sync() {
@@ -229,38 +227,37 @@ template <int NW> __device__ __forceinline__ unsigned group_sum(unsigned v, unsi
   }
 }
 
-// The fold of bvh_tree.rs:58-61 over P[0, len): min, max, and the sum exactly as the sequential chain rounds it.
-// Every thread of the group returns the same values.
+// One coordinate (comp 0: x, 1: y) of the fold of bvh_tree.rs:58-61 over P[0, len): min, max, and the sum exactly as
+// the sequential chain rounds it.  Every thread of the group returns the same values.  The two coordinates are
+// independent chains: they run on different work-groups.
 // EPT: consecutive addends per thread and scan (the scan's fixed cost is per thread: more addends each = cheaper).
-template <int NW, int EPT, class PosPtr>
-__device__ __forceinline__ void exact_fold(PosPtr P, int len, int tid, Scratch<NW>* sh, float& out_sx, float& out_sy,
-                                           float4& out_box, int& stops) {
+template <int NW, int EPT>
+__device__ __forceinline__ void exact_fold(const float2* P, int len, int comp, int tid, Scratch<NW>* sh, float& out_sum,
+                                           float& out_min, float& out_max, int& stops) {
   constexpr int TILE = NW * 64 * EPT;
   const int lane = tid & 63, wave = tid >> 6;
-  float s_x = 0.f, s_y = 0.f;  // uniform across the group
-  float mnx = kMaxF, mny = kMaxF, mxx = 0.f, mxy = 0.f;
+  float s = 0.f;  // uniform across the group
+  float mn = kMaxF, mx = 0.f;
   int pos = 0;
   bool seq = true;  // the chain starts at 0.0: not in any binade yet
   while (pos < len) {
-    xsum::Chain cx, cy;
-    if (!seq) {
-      const bool okx = xsum::chain_open(s_x, cx), oky = xsum::chain_open(s_y, cy);
-      seq = !(okx && oky);
-    }
+    xsum::Chain ch;
+    if (!seq) seq = !xsum::chain_open(s, ch);
     if (seq) {  // real adds by ONE wave; the others wait for the result
       int cnt = pos == 0 ? kChainStart : kSeqRun;
       cnt = len - pos < cnt ? len - pos : cnt;
       if (wave == 0) {
         Box bx;
-        chain_run(P, pos, cnt, lane, s_x, s_y, bx);
-        mnx = sse_min(mnx, bx.mnx); mny = sse_min(mny, bx.mny);
-        mxx = sse_max(mxx, bx.mxx); mxy = sse_max(mxy, bx.mxy);
+        float sx = s, sy = s;
+        chain_run(P, pos, cnt, lane, sx, sy, bx);
+        s = comp ? sy : sx;
+        mn = sse_min(mn, comp ? bx.mny : bx.mnx);
+        mx = sse_max(mx, comp ? bx.mxy : bx.mxx);
       }
       if constexpr (NW > 1) {
-        if (tid == 0) { sh->bad_sx = xsum::f2u(s_x); sh->bad_sy = xsum::f2u(s_y); }
+        if (tid == 0) sh->bad_s = xsum::f2u(s);
         __syncthreads();
-        s_x = xsum::u2f(sh->bad_sx);
-        s_y = xsum::u2f(sh->bad_sy);
+        s = xsum::u2f(sh->bad_s);
       }
       pos += cnt;
       seq = false;
@@ -272,87 +269,68 @@ __device__ __forceinline__ void exact_fold(PosPtr P, int len, int tid, Scratch<N
     span = span < TILE ? span : TILE;
     const int limit = pos + span < len ? pos + span : len;
     const int base = pos + tid * EPT;
-    xsum::Step fx[EPT], fy[EPT];
-    xsum::Step tx{0u, 0u}, ty{0u, 0u};
+    xsum::Step f[EPT];
+    xsum::Step t{0u, 0u};
 #pragma unroll
-    for (int j = 0; j < EPT; ++j) {
-      fx[j] = xsum::Step{0u, 0u};
-      fy[j] = xsum::Step{0u, 0u};
-    }
+    for (int j = 0; j < EPT; ++j) f[j] = xsum::Step{0u, 0u};
     if (base < limit) {
 #pragma unroll
       for (int j = 0; j < EPT; ++j) {
         if (base + j < limit) {
           const float2 q = P[base + j];
-          fx[j] = xsum::step_of(q.x, cx.sign, cx.E);
-          fy[j] = xsum::step_of(q.y, cy.sign, cy.E);
-          mnx = sse_min(mnx, q.x); mny = sse_min(mny, q.y);
-          mxx = sse_max(mxx, q.x); mxy = sse_max(mxy, q.y);
+          const float v = comp ? q.y : q.x;
+          f[j] = xsum::step_of(v, ch.sign, ch.E);
+          mn = sse_min(mn, v);
+          mx = sse_max(mx, v);
         }
-        tx = xsum::compose(tx, fx[j]);
-        ty = xsum::compose(ty, fy[j]);
+        t = xsum::compose(t, f[j]);
       }
     }
-    xsum::Step ix = tx, iy = ty;  // inclusive scan inside the wave
+    xsum::Step inc = t;  // inclusive scan inside the wave
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
-      const xsum::Step ox = shfl_up_step(ix, d), oy = shfl_up_step(iy, d);
-      if (lane >= d) {
-        ix = xsum::compose(ox, ix);
-        iy = xsum::compose(oy, iy);
-      }
+      const xsum::Step o = shfl_up_step(inc, d);
+      if (lane >= d) inc = xsum::compose(o, inc);
     }
-    xsum::Step ex = shfl_up_step(ix, 1), ey = shfl_up_step(iy, 1);  // exclusive: everything before my addends
-    if (lane == 0) { ex = xsum::Step{0u, 0u}; ey = xsum::Step{0u, 0u}; }
-    xsum::Step totx, toty;
+    xsum::Step ex = shfl_up_step(inc, 1);  // exclusive: everything before my addends
+    if (lane == 0) ex = xsum::Step{0u, 0u};
+    xsum::Step tot;
     if constexpr (NW > 1) {
-      if (lane == 63) { sh->wx[wave] = ix; sh->wy[wave] = iy; }
+      if (lane == 63) sh->w[wave] = inc;
       if (tid == 0) sh->bad = INT_MAX;
       __syncthreads();
       // every wave scans the NW wave totals for itself (lanes 0..NW-1): no second barrier
-      xsum::Step wix{0u, 0u}, wiy{0u, 0u};
-      if (lane < NW) { wix = sh->wx[lane]; wiy = sh->wy[lane]; }
+      xsum::Step wi{0u, 0u};
+      if (lane < NW) wi = sh->w[lane];
 #pragma unroll
       for (int d = 1; d < NW; d <<= 1) {
-        const xsum::Step ox = shfl_up_step(wix, d), oy = shfl_up_step(wiy, d);
-        if (lane >= d) {
-          wix = xsum::compose(ox, wix);
-          wiy = xsum::compose(oy, wiy);
-        }
+        const xsum::Step o = shfl_up_step(wi, d);
+        if (lane >= d) wi = xsum::compose(o, wi);
       }
-      totx.a0 = (uint32_t)__builtin_amdgcn_readlane((int)wix.a0, NW - 1);
-      totx.a1 = (uint32_t)__builtin_amdgcn_readlane((int)wix.a1, NW - 1);
-      toty.a0 = (uint32_t)__builtin_amdgcn_readlane((int)wiy.a0, NW - 1);
-      toty.a1 = (uint32_t)__builtin_amdgcn_readlane((int)wiy.a1, NW - 1);
+      tot.a0 = (uint32_t)__builtin_amdgcn_readlane((int)wi.a0, NW - 1);
+      tot.a1 = (uint32_t)__builtin_amdgcn_readlane((int)wi.a1, NW - 1);
       if (wave > 0) {
-        xsum::Step px, py;  // all the waves before mine
-        px.a0 = (uint32_t)__builtin_amdgcn_readlane((int)wix.a0, wave - 1);
-        px.a1 = (uint32_t)__builtin_amdgcn_readlane((int)wix.a1, wave - 1);
-        py.a0 = (uint32_t)__builtin_amdgcn_readlane((int)wiy.a0, wave - 1);
-        py.a1 = (uint32_t)__builtin_amdgcn_readlane((int)wiy.a1, wave - 1);
-        ex = xsum::compose(px, ex);
-        ey = xsum::compose(py, ey);
+        xsum::Step pw;  // all the waves before mine
+        pw.a0 = (uint32_t)__builtin_amdgcn_readlane((int)wi.a0, wave - 1);
+        pw.a1 = (uint32_t)__builtin_amdgcn_readlane((int)wi.a1, wave - 1);
+        ex = xsum::compose(pw, ex);
       }
     } else {
-      totx.a0 = (uint32_t)__builtin_amdgcn_readlane((int)ix.a0, 63);
-      totx.a1 = (uint32_t)__builtin_amdgcn_readlane((int)ix.a1, 63);
-      toty.a0 = (uint32_t)__builtin_amdgcn_readlane((int)iy.a0, 63);
-      toty.a1 = (uint32_t)__builtin_amdgcn_readlane((int)iy.a1, 63);
+      tot.a0 = (uint32_t)__builtin_amdgcn_readlane((int)inc.a0, 63);
+      tot.a1 = (uint32_t)__builtin_amdgcn_readlane((int)inc.a1, 63);
     }
-    uint32_t Sx = xsum::apply(cx.S, ex), Sy = xsum::apply(cy.S, ey);
+    uint32_t S = xsum::apply(ch.S, ex);
     int bad = INT_MAX;
-    uint32_t bsx = 0u, bsy = 0u;
+    uint32_t bs = 0u;
 #pragma unroll
     for (int j = 0; j < EPT; ++j) {
       if (base + j < limit && bad == INT_MAX) {
-        const uint32_t nx = xsum::apply(Sx, fx[j]), ny = xsum::apply(Sy, fy[j]);
-        if (!xsum::in_binade(nx) || !xsum::in_binade(ny)) {
+        const uint32_t nx = xsum::apply(S, f[j]);
+        if (!xsum::in_binade(nx)) {
           bad = tid * EPT + j;
-          bsx = Sx;
-          bsy = Sy;
+          bs = S;
         } else {
-          Sx = nx;
-          Sy = ny;
+          S = nx;
         }
       }
     }
@@ -367,23 +345,18 @@ __device__ __forceinline__ void exact_fold(PosPtr P, int len, int tid, Scratch<N
       first_bad = sh->bad;
     }
     if (first_bad == INT_MAX) {
-      s_x = xsum::chain_value(cx, xsum::apply(cx.S, totx));
-      s_y = xsum::chain_value(cy, xsum::apply(cy.S, toty));
+      s = xsum::chain_value(ch, xsum::apply(ch.S, tot));
       pos += span;
     } else {  // the chain is exact up to the addend before first_bad; that addend takes a real add
-      uint32_t vx, vy;
+      uint32_t v;
       if constexpr (NW > 1) {
-        if (bad == first_bad) { sh->bad_sx = bsx; sh->bad_sy = bsy; }
+        if (bad == first_bad) sh->bad_s = bs;
         __syncthreads();
-        vx = sh->bad_sx;
-        vy = sh->bad_sy;
+        v = sh->bad_s;
       } else {
-        const int owner = first_bad / EPT;
-        vx = (uint32_t)__builtin_amdgcn_readlane((int)bsx, owner);
-        vy = (uint32_t)__builtin_amdgcn_readlane((int)bsy, owner);
+        v = (uint32_t)__builtin_amdgcn_readlane((int)bs, first_bad / EPT);
       }
-      s_x = xsum::chain_value(cx, vx);
-      s_y = xsum::chain_value(cy, vy);
+      s = xsum::chain_value(ch, v);
       pos += first_bad;
       seq = true;
       ++stops;
@@ -391,21 +364,21 @@ __device__ __forceinline__ void exact_fold(PosPtr P, int len, int tid, Scratch<N
     if constexpr (NW > 1) __syncthreads();  // sh is rewritten by the next round
   }
   for (int d = 32; d >= 1; d >>= 1) {
-    mnx = sse_min(mnx, __shfl_xor(mnx, d, 64)); mny = sse_min(mny, __shfl_xor(mny, d, 64));
-    mxx = sse_max(mxx, __shfl_xor(mxx, d, 64)); mxy = sse_max(mxy, __shfl_xor(mxy, d, 64));
+    mn = sse_min(mn, __shfl_xor(mn, d, 64));
+    mx = sse_max(mx, __shfl_xor(mx, d, 64));
   }
   if constexpr (NW > 1) {
-    if (lane == 0) { sh->redf[0][wave] = mnx; sh->redf[1][wave] = mny; sh->redf[2][wave] = mxx; sh->redf[3][wave] = mxy; }
+    if (lane == 0) { sh->redf[0][wave] = mn; sh->redf[1][wave] = mx; }
     __syncthreads();
     for (int w = 0; w < NW; ++w) {
-      mnx = sse_min(mnx, sh->redf[0][w]); mny = sse_min(mny, sh->redf[1][w]);
-      mxx = sse_max(mxx, sh->redf[2][w]); mxy = sse_max(mxy, sh->redf[3][w]);
+      mn = sse_min(mn, sh->redf[0][w]);
+      mx = sse_max(mx, sh->redf[1][w]);
     }
     __syncthreads();
   }
-  out_sx = s_x;
-  out_sy = s_y;
-  out_box = make_float4(mnx, mny, mxx, mxy);
+  out_sum = s;
+  out_min = mn;
+  out_max = mx;
 }
 
 // :70-73 — which axis splits closer to the middle; returns the split point m (predicate-true side comes first)
@@ -417,15 +390,11 @@ __device__ __forceinline__ int choose_axis(int len, int cxs, int cys, bool& on_x
   return on_x ? cxs : cys;
 }
 
-// Children of `node` ([b, b+m) and [b+m, b+len)): records, ids, keys.  One thread.  Returns the first child's id or
-// -1 (buffers full: the fallback flag is up).  leaf[] says which children need no further splitting.
-__device__ __forceinline__ int make_children(const BvhPtrs& a, int node, int b, int len, int m, int leaf_size, bool leaf[2]) {
+// Children of `node` ([b, b+m) and [b+m, b+len)) with the ids first, first + 1: records and keys.  One thread.
+// leaf[] says which children need no further splitting.
+__device__ __forceinline__ void make_children(const BvhPtrs& a, int node, int first, int b, int len, int m, int leaf_size,
+                                              bool leaf[2]) {
   const int d = a.ndepth[node];
-  const int first = atomicAdd(&a.flags[kBvhNodeCount], 2);
-  if (first + 2 > a.cap) {
-    a.flags[kBvhFallback] = 1;
-    return -1;
-  }
   a.nchild[node] = first;
   const uint64_t path = a.nkey[node] & ~63ull;
   for (int side = 0; side < 2; ++side) {
@@ -446,6 +415,14 @@ __device__ __forceinline__ int make_children(const BvhPtrs& a, int node, int b, 
     a.nbad[id] = 0;
   }
   atomicMax(&a.flags[kBvhMaxDepth], d + 1);
+}
+// two fresh node ids, or -1 with the fallback flag up when the buffers are full
+__device__ __forceinline__ int alloc_nodes(const BvhPtrs& a, int count) {
+  const int first = atomicAdd(&a.flags[kBvhNodeCount], count);
+  if (first + count > a.cap) {
+    a.flags[kBvhFallback] = 1;
+    return -1;
+  }
   return first;
 }
 
@@ -483,33 +460,37 @@ __global__ __launch_bounds__(256) void bvh_init(BvhPtrs a, const float2* __restr
 __global__ __launch_bounds__(512) void bvh_big_fold(BvhPtrs a, int level) {
   __shared__ Scratch<8> sh;
   const int tid = threadIdx.x;
+  const int comp = blockIdx.y;  // 0: x, 1: y
   const int nq = a.bigcount[level];
   const int* queue = a.bigq + (size_t)(level & 1) * a.cap_big;
   int stops = 0;
   for (int qi = blockIdx.x; qi < nq; qi += gridDim.x) {
     const int node = queue[qi];
     const int b = a.nbegin[node], len = a.nlen[node];
-    float sx, sy;
-    float4 box;
-    exact_fold<8, 8>((const float2*)(a.P + b), len, tid, &sh, sx, sy, box, stops);
-    const int nch = (len + kChunk - 1) / kChunk;
+    float sum, mn, mx;
+    exact_fold<8, 8>((const float2*)(a.P + b), len, comp, tid, &sh, sum, mn, mx, stops);
     if (tid == 0) {
-      a.nbox[node] = box;
-      a.nmean[node] = make_float2(sx / (float)len, sy / (float)len);  // :67
-      sh.bad = atomicAdd(&a.chunkcount[level], nch);
+      float* box = (float*)&a.nbox[node];
+      box[comp] = mn;
+      box[2 + comp] = mx;
+      ((float*)&a.nmean[node])[comp] = sum / (float)len;  // :67
     }
-    __syncthreads();
-    const int c0 = sh.bad;
-    if (tid == 0) a.nchunk0[node] = c0;
-    if (c0 + nch > a.cap_chunk) {
-      if (tid == 0) a.flags[kBvhFallback] = 1;
-    } else {
-      for (int i = tid; i < nch; i += 512) {
-        a.ch_node[c0 + i] = node;
-        a.ch_index[c0 + i] = i;
+    if (comp == 0) {  // the node's chunks for the passes that follow
+      const int nch = (len + kChunk - 1) / kChunk;
+      if (tid == 0) sh.bad = atomicAdd(&a.chunkcount[level], nch);
+      __syncthreads();
+      const int c0 = sh.bad;
+      if (tid == 0) a.nchunk0[node] = c0;
+      if (c0 + nch > a.cap_chunk) {
+        if (tid == 0) a.flags[kBvhFallback] = 1;
+      } else {
+        for (int i = tid; i < nch; i += 512) {
+          a.ch_node[c0 + i] = node;
+          a.ch_index[c0 + i] = i;
+        }
       }
+      __syncthreads();
     }
-    __syncthreads();
   }
   if (tid == 0 && stops) atomicAdd(&a.flags[kBvhStops], stops);
 }
@@ -579,8 +560,9 @@ __global__ __launch_bounds__(256) void bvh_big_count(BvhPtrs a, int level, int l
     if (tid == 0) {
       a.nsplit[node] = m | (on_x ? (int)0x80000000 : 0);
       bool leaf[2];
-      const int first = make_children(a, node, b, len, m, leaf_size, leaf);
+      const int first = alloc_nodes(a, 2);
       if (first >= 0) {
+        make_children(a, node, first, b, len, m, leaf_size, leaf);
         for (int side = 0; side < 2; ++side) {
           if (leaf[side]) continue;
           const int cl = side ? len - m : m;
@@ -677,17 +659,19 @@ __global__ __launch_bounds__(256) void bvh_big_swap(BvhPtrs a, int level) {
 struct SubLds {
   float2 P[kSub];
   uint16_t I[kSub];  // which of the subtree's points (as loaded) sits here now
+  uint32_t W[kSub];  // weights of the points as loaded
   uint16_t L[kSub], R[kSub];
   uint16_t lb[2][kSub / 2], ll[2][kSub / 2];  // node lists of two consecutive levels: begin, length (subtree-relative)
   int lg[2][kSub / 2];                        // ... and breadth-first id
   int lcount[2];
+  int idbase;  // first id of the children made at this level (one allocation per level)
   int loff[kBvhKeyDepth + 2];  // where each level of the subtree starts in its list of internal nodes
 };
 
 // One node whose points are s.P[lb, lb+len): fold, axis, partition, children — by ONE wave.  Up to kSub points the
 // chain is simply added in order (a scan would restart at every doubling of the sum and lose).
-__device__ __forceinline__ void node_in_lds(const BvhPtrs& a, SubLds& s, int gbegin, int lb, int len, int gid, int lane, int nxt,
-                                            int leaf_size) {
+__device__ __forceinline__ void node_in_lds(const BvhPtrs& a, SubLds& s, int gbegin, int lb, int len, int gid, int first, int lane,
+                                            int nxt, int leaf_size) {
   constexpr int TILE = 64 * kEPT;
   float2* P = s.P + lb;
   uint16_t* I = s.I + lb;
@@ -753,15 +737,13 @@ __device__ __forceinline__ void node_in_lds(const BvhPtrs& a, SubLds& s, int gbe
   if (lane == 0) {
     a.nbox[gid] = make_float4(box.mnx, box.mny, box.mxx, box.mxy);
     bool leaf[2];
-    const int first = make_children(a, gid, gbegin + lb, len, m, leaf_size, leaf);
-    if (first >= 0) {
-      for (int side = 0; side < 2; ++side) {
-        if (leaf[side]) continue;
-        const int slot = atomicAdd(&s.lcount[nxt], 1);
-        s.lb[nxt][slot] = (uint16_t)(side ? lb + m : lb);
-        s.ll[nxt][slot] = (uint16_t)(side ? len - m : m);
-        s.lg[nxt][slot] = first + side;
-      }
+    make_children(a, gid, first, gbegin + lb, len, m, leaf_size, leaf);
+    for (int side = 0; side < 2; ++side) {
+      if (leaf[side]) continue;
+      const int slot = atomicAdd(&s.lcount[nxt], 1);
+      s.lb[nxt][slot] = (uint16_t)(side ? lb + m : lb);
+      s.ll[nxt][slot] = (uint16_t)(side ? len - m : m);
+      s.lg[nxt][slot] = first + side;
     }
   }
   group_sync<1>();
@@ -816,13 +798,22 @@ __global__ __launch_bounds__(kSubWaves * 64) void bvh_subtrees(BvhPtrs a, const 
   __shared__ SubLds s;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nsub = a.flags[kBvhSubCount];
+#ifdef NB_BVH_TIMING
+#define NB_STAMP(k) { const long long t_ = wall_clock64(); if (tid == 0) atomicMax(&a.flags[kBvhDebug + k], (int)(t_ - t_prev)); t_prev = t_; }
+#else
+#define NB_STAMP(k) {}
+#endif
   for (int si = blockIdx.x; si < nsub; si += gridDim.x) {
+#ifdef NB_BVH_TIMING
+    long long t_prev = wall_clock64();
+#endif
     const int root = a.subq[si];
     const int b = a.nbegin[root], len = a.nlen[root];
     int* list = a.lidx + b;  // the subtree's internal nodes, level after level (the global rank lists are free now)
     for (int i = tid; i < len; i += kSubWaves * 64) {
       s.P[i] = a.P[b + i];
       s.I[i] = (uint16_t)i;
+      s.W[i] = weight[a.ID[b + i]];
     }
     if (tid == 0) {
       s.lb[0][0] = 0;
@@ -832,6 +823,7 @@ __global__ __launch_bounds__(kSubWaves * 64) void bvh_subtrees(BvhPtrs a, const 
       s.lcount[1] = 0;
     }
     __syncthreads();
+    NB_STAMP(0)
     int cur = 0, nlev = 0, nint = 0;
     for (;;) {
       const int nc = s.lcount[cur];
@@ -841,35 +833,58 @@ __global__ __launch_bounds__(kSubWaves * 64) void bvh_subtrees(BvhPtrs a, const 
         break;
       }
       for (int e = tid; e < nc; e += kSubWaves * 64) list[nint + e] = s.lg[cur][e];
-      if (tid == 0) s.loff[nlev] = nint;
+      if (tid == 0) {
+        s.loff[nlev] = nint;
+        s.idbase = alloc_nodes(a, 2 * nc);
+      }
+      __syncthreads();
+      const int idbase = s.idbase;
+      if (idbase < 0) break;
       nint += nc;
       ++nlev;
       for (int e = wave; e < nc; e += kSubWaves)  // a wave per node
-        node_in_lds(a, s, b, s.lb[cur][e], s.ll[cur][e], s.lg[cur][e], lane, cur ^ 1, leaf_size);
+        node_in_lds(a, s, b, s.lb[cur][e], s.ll[cur][e], s.lg[cur][e], idbase + 2 * e, lane, cur ^ 1, leaf_size);
       __syncthreads();
       if (tid == 0) s.lcount[cur] = 0;
       cur ^= 1;
       __syncthreads();
+      if (nlev == 1) NB_STAMP(1)
+      if (nlev == 2) NB_STAMP(2)
+      if (nlev == 3) NB_STAMP(3)
     }
     if (tid == 0) s.loff[nlev] = nint;
     __syncthreads();
-    // leaves: children of the listed nodes that were not split further; a wave each, points still in LDS
-    for (int task = wave; task < 2 * nint; task += kSubWaves) {
+    NB_STAMP(4)
+    // leaves: children of the listed nodes that were not split further; a lane each, points still in LDS
+    // (make_leaf :40-54, leaf mass and centre :98-131)
+    for (int task = tid; task < 2 * nint; task += kSubWaves * 64) {
       const int c0 = a.nchild[list[task >> 1]];
       if (c0 < 0) continue;
       const int c = c0 + (task & 1);
       if (!a.nleaf[c]) continue;
-      const int lb = a.nbegin[c] - b;
-      const uint32_t* ids = a.ID + b;
-      const uint16_t* I = s.I + lb;
-      leaf_by_wave(a, c, (const float2*)(s.P + lb), a.nlen[c], lane, weight, [&](int i) { return ids[I[i]]; });
+      const int lb = a.nbegin[c] - b, ln = a.nlen[c];
+      Box box;
+      float sx = 0.f, sy = 0.f;
+      uint32_t ms = 0u;
+      for (int k = 0; k < ln; ++k) {  // slice order
+        const float2 q = s.P[lb + k];
+        box.add(q);
+        sx = sx + q.x;
+        sy = sy + q.y;
+        ms += s.W[s.I[lb + k]];  // u32, wraps like the release build
+      }
+      a.nbox[c] = make_float4(box.mnx, box.mny, box.mxx, box.mxy);
+      a.ncog[c] = make_float2(sx / (float)ln, sy / (float)ln);  // NaN for an empty leaf, as upstream
+      a.nmass[c] = ms;
     }
     __syncthreads();
+    NB_STAMP(5)
     // upward pass inside the subtree: deepest level first
     for (int lev = nlev - 1; lev >= 0; --lev) {
       for (int e = s.loff[lev] + tid; e < s.loff[lev + 1]; e += kSubWaves * 64) combine_children(a, list[e]);
       __syncthreads();
     }
+    NB_STAMP(6)
     // the subtree's rows go back in their final order
     uint32_t ids[kSub / (kSubWaves * 64)];
 #pragma unroll
@@ -887,6 +902,7 @@ __global__ __launch_bounds__(kSubWaves * 64) void bvh_subtrees(BvhPtrs a, const 
       }
     }
     __syncthreads();
+    NB_STAMP(7)
   }
 }
 
@@ -1046,7 +1062,7 @@ hipError_t bvh_build_levels(hipStream_t s, int n, int leaf_size, int level_begin
     int64_t gb = L.big_cap < width ? L.big_cap : width;
     int64_t gc = L.chunk_cap;
     if (gc > 4096) gc = 4096;
-    bvh_big_fold<<<dim3((unsigned)gb), dim3(512), 0, s>>>(a, level);
+    bvh_big_fold<<<dim3((unsigned)gb, 2), dim3(512), 0, s>>>(a, level);
     bvh_big_count<<<dim3((unsigned)gc), dim3(256), 0, s>>>(a, level, leaf_size);
     bvh_big_ranks<<<dim3((unsigned)gc), dim3(256), 0, s>>>(a, level);
     bvh_big_swap<<<dim3((unsigned)gc), dim3(256), 0, s>>>(a, level);

@@ -508,6 +508,10 @@ template <class T> int bvh_build_device(nbody_ctx* c, State<T>& s) {
     HIPCHK(c, hipMemcpyAsync(hostf, s.bb_scratch + L.flags, kBvhFlagWords * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (hostf[kBvhFallback] != 0) return 1;
+    if (env_int("NBODY_TRACE", 0) != 0)
+      std::fprintf(stderr, "[nbody] device bvh build: %d nodes, depth %d, %d subtrees, %d scan restarts; subtree phases (max 100 MHz ticks) %d %d %d %d %d %d %d %d\n",
+                   hostf[kBvhNodeCount], hostf[kBvhMaxDepth], hostf[kBvhSubCount], hostf[kBvhStops], hostf[kBvhDebug], hostf[kBvhDebug + 1],
+                   hostf[kBvhDebug + 2], hostf[kBvhDebug + 3], hostf[kBvhDebug + 4], hostf[kBvhDebug + 5], hostf[kBvhDebug + 6], hostf[kBvhDebug + 7]);
     const int m = hostf[kBvhNodeCount];
     if (m <= 0 || m > L.node_cap) return 1;
     GatherArgs<T> g{};  // rows into tree order, as the in-place partition leaves `self.particles` (bvh_tree.rs:73-77)
