@@ -16,13 +16,14 @@ enum : int {
   kBvhMaxDepth = 2,
   kBvhStops = 3,      // restarts of the exact-sum scan (diagnostic)
   kBvhSubCount = 4,   // subtree roots queued for bvh_subtrees
+  kBvhTopCount = 5,   // nodes made by the long-node levels (they sit above the subtrees)
   kBvhDebug = 8,      // 8 words of max-over-groups cycle counts per phase of bvh_subtrees (NB_BVH_TIMING builds)
   kBvhFlagWords = 16,
 };
 
 struct BvhBuildLayout {
   int node_cap, big_cap, chunk_cap;
-  size_t flags, bigcount, chunkcount, zero_end, bigq, subq, ch_node, ch_index, ch_cx, ch_cy, ch_before, pts, ids, lidx, ridx;
+  size_t flags, bigcount, chunkcount, zero_end, bigq, subq, topq, ch_node, ch_index, ch_cx, ch_cy, ch_before, pts, ids, lidx, ridx;
   size_t nbegin, nlen, nparent, nchild, ndepth, nleaf, nkey, nbox, ncog, nmass, narrive, nmean, nsplit, nchunk0, ndone, nbad;
   size_t keys, keys_sorted, vals, vals_sorted, rank, cub_temp, cub_temp_bytes, total;
 };
@@ -37,8 +38,9 @@ hipError_t bvh_build_levels(hipStream_t s, int n, int leaf_size, int level_begin
                             const BvhBuildLayout& L);
 // Subtrees, pre-order numbering, leaves + upward pass, final arrays (sized for L.node_cap nodes; the node count is in
 // the flags afterwards).
-// n_top: node count when the last long-node level was done (those nodes sit above the subtrees).
-hipError_t bvh_build_finish(hipStream_t s, const uint32_t* weight, int n, int leaf_size, int n_top, char* scratch,
+// sub_start: subtree roots already built by an earlier call (the caller enqueues this blind after the levels it
+// expects and calls again, after more levels, if long nodes were left).
+hipError_t bvh_build_finish(hipStream_t s, const uint32_t* weight, int n, int leaf_size, int sub_start, char* scratch,
                             const BvhBuildLayout& L,
                             uint32_t* order_out, void* geom0, void* geom1, void* link, int* depth_out, uint32_t* mass_out,
                             float2* size_out);

@@ -41,7 +41,7 @@ namespace {
 constexpr int kEPT = 4;          // consecutive points per thread in the rank-list passes
 constexpr int kSeqRun = 16;      // real adds after every stop of the scan
 constexpr int kChainStart = 256; // real adds at the start of a long node's chain (the sum doubles too often there)
-constexpr int kSub = 4096;       // nodes up to this long are built, subtree and all, by one work-group in LDS
+constexpr int kSub = 2048;       // nodes up to this long are built, subtree and all, by one work-group in LDS
 constexpr int kSubWaves = 8;     // waves of a subtree work-group
 constexpr int kChunk = 2048;     // points per work-group in the multi-group passes over a long node
 constexpr float kMaxF = 3.402823466e+38f;
@@ -52,6 +52,7 @@ struct BvhPtrs {
   int* chunkcount;  // [level]
   int* bigq;        // [level & 1][cap_big]
   int* subq;        // subtree roots
+  int* topq;        // nodes made by the long-node levels (the ones above the subtrees)
   int* ch_node;     // chunk -> node
   int* ch_index;    // chunk -> index inside the node
   int* ch_cx;
@@ -87,6 +88,7 @@ BvhPtrs make_ptrs(char* s, const BvhBuildLayout& L) {
   a.chunkcount = (int*)(s + L.chunkcount);
   a.bigq = (int*)(s + L.bigq);
   a.subq = (int*)(s + L.subq);
+  a.topq = (int*)(s + L.topq);
   a.ch_node = (int*)(s + L.ch_node);
   a.ch_index = (int*)(s + L.ch_index);
   a.ch_cx = (int*)(s + L.ch_cx);
@@ -446,6 +448,8 @@ __global__ __launch_bounds__(256) void bvh_init(BvhPtrs a, const float2* __restr
     a.ndone[0] = 0;
     a.nbad[0] = 0;
     a.flags[kBvhNodeCount] = 1;
+    a.flags[kBvhTopCount] = 1;
+    a.topq[0] = 0;
     if (n > kSub) {
       a.bigcount[0] = 1;
       a.bigq[0] = 0;
@@ -563,6 +567,9 @@ __global__ __launch_bounds__(256) void bvh_big_count(BvhPtrs a, int level, int l
       const int first = alloc_nodes(a, 2);
       if (first >= 0) {
         make_children(a, node, first, b, len, m, leaf_size, leaf);
+        const int tslot = atomicAdd(&a.flags[kBvhTopCount], 2);  // node ids: at most cap of them
+        a.topq[tslot] = first;
+        a.topq[tslot + 1] = first + 1;
         for (int side = 0; side < 2; ++side) {
           if (leaf[side]) continue;
           const int cl = side ? len - m : m;
@@ -794,7 +801,8 @@ __device__ __forceinline__ void leaf_by_wave(const BvhPtrs& a, int leaf, PosPtr 
   }
 }
 
-__global__ __launch_bounds__(kSubWaves * 64) void bvh_subtrees(BvhPtrs a, const uint32_t* __restrict__ weight, int leaf_size) {
+__global__ __launch_bounds__(kSubWaves * 64) void bvh_subtrees(BvhPtrs a, const uint32_t* __restrict__ weight, int leaf_size,
+                                                              int sub_start) {
   __shared__ SubLds s;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nsub = a.flags[kBvhSubCount];
@@ -803,7 +811,7 @@ __global__ __launch_bounds__(kSubWaves * 64) void bvh_subtrees(BvhPtrs a, const 
 #else
 #define NB_STAMP(k) {}
 #endif
-  for (int si = blockIdx.x; si < nsub; si += gridDim.x) {
+  for (int si = sub_start + blockIdx.x; si < nsub; si += gridDim.x) {
 #ifdef NB_BVH_TIMING
     long long t_prev = wall_clock64();
 #endif
@@ -906,11 +914,13 @@ __global__ __launch_bounds__(kSubWaves * 64) void bvh_subtrees(BvhPtrs a, const 
   }
 }
 
-// The nodes above the subtrees (ids below n_top, made level by level): leaves hanging directly off a long node, then
-// the long nodes themselves, deepest level first.  One work-group: a few hundred nodes.
-__global__ __launch_bounds__(256) void bvh_top_upward(BvhPtrs a, const uint32_t* __restrict__ weight, int n_top) {
+// The nodes above the subtrees (topq): leaves hanging directly off a long node, then the long nodes themselves,
+// deepest level first.  One work-group: a few hundred nodes (a few thousand at N = 4M).
+__global__ __launch_bounds__(256) void bvh_top_upward(BvhPtrs a, const uint32_t* __restrict__ weight) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int id = wave; id < n_top; id += 4) {
+  const int n_top = a.flags[kBvhTopCount];
+  for (int e = wave; e < n_top; e += 4) {
+    const int id = a.topq[e];
     if (!a.nleaf[id]) continue;
     const int b = a.nbegin[id];
     const uint32_t* ids = a.ID + b;
@@ -918,13 +928,15 @@ __global__ __launch_bounds__(256) void bvh_top_upward(BvhPtrs a, const uint32_t*
   }
   __syncthreads();
   for (int d = a.flags[kBvhMaxDepth]; d >= 0; --d) {
-    for (int id = tid; id < n_top; id += 256)
+    for (int e = tid; e < n_top; e += 256) {
+      const int id = a.topq[e];
       if (a.ndepth[id] == d && !a.nleaf[id] && a.nlen[id] > kSub) combine_children(a, id);
+    }
     __syncthreads();
   }
 }
 
-// ---- numbering, leaves, upward pass ------------------------------------------------------------------------------
+// ---- numbering -----------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void bvh_keys(BvhPtrs a, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= a.cap) return;
@@ -1001,6 +1013,7 @@ BvhBuildLayout bvh_build_layout(int64_t n, int leaf_size) {
   L.zero_end = off;
   L.bigq = take(4 * 2 * CB);
   L.subq = take(4 * C);
+  L.topq = take(4 * C);
   L.ch_node = take(4 * CC);
   L.ch_index = take(4 * CC);
   L.ch_cx = take(4 * CC);
@@ -1061,7 +1074,7 @@ hipError_t bvh_build_levels(hipStream_t s, int n, int leaf_size, int level_begin
     const int64_t width = level < 30 ? (int64_t)1 << level : (int64_t)1 << 30;  // a level never has more nodes than this
     int64_t gb = L.big_cap < width ? L.big_cap : width;
     int64_t gc = L.chunk_cap;
-    if (gc > 4096) gc = 4096;
+    if (gc > 1024) gc = 1024;
     bvh_big_fold<<<dim3((unsigned)gb, 2), dim3(512), 0, s>>>(a, level);
     bvh_big_count<<<dim3((unsigned)gc), dim3(256), 0, s>>>(a, level, leaf_size);
     bvh_big_ranks<<<dim3((unsigned)gc), dim3(256), 0, s>>>(a, level);
@@ -1070,7 +1083,7 @@ hipError_t bvh_build_levels(hipStream_t s, int n, int leaf_size, int level_begin
   return hipGetLastError();
 }
 
-hipError_t bvh_build_finish(hipStream_t s, const uint32_t* weight, int n, int leaf_size, int n_top, char* scratch,
+hipError_t bvh_build_finish(hipStream_t s, const uint32_t* weight, int n, int leaf_size, int sub_start, char* scratch,
                             const BvhBuildLayout& L,
                             uint32_t* order_out, void* geom0, void* geom1, void* link, int* depth_out, uint32_t* mass_out,
                             float2* size_out) {
@@ -1083,8 +1096,8 @@ hipError_t bvh_build_finish(hipStream_t s, const uint32_t* weight, int n, int le
   int* rank = (int*)(scratch + L.rank);
   int64_t gs = (int64_t)n / 64 + 1;  // subtree roots
   if (gs > 2048) gs = 2048;
-  bvh_subtrees<<<dim3((unsigned)gs), dim3(kSubWaves * 64), 0, s>>>(a, weight, leaf_size);
-  bvh_top_upward<<<dim3(1), dim3(256), 0, s>>>(a, weight, n_top);
+  bvh_subtrees<<<dim3((unsigned)gs), dim3(kSubWaves * 64), 0, s>>>(a, weight, leaf_size, sub_start);
+  bvh_top_upward<<<dim3(1), dim3(256), 0, s>>>(a, weight);
   const dim3 gm((unsigned)((C + 255) / 256));
   bvh_keys<<<gm, dim3(256), 0, s>>>(a, keys, vals);
   size_t tb = L.cub_temp_bytes;

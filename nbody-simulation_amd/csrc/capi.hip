@@ -7,6 +7,7 @@
 // sequence (bvh_tree.rs:56-96); forces and integration always run on the GPU.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -480,50 +481,69 @@ template <class T> int bvh_build_device(nbody_ctx* c, State<T>& s) {
     auto& in = s.set[s.cur];
     auto& out = s.set[1 - s.cur];
     HIPCHK(c, bvh_build_begin(c->stream, in.pos, n, s.bb_scratch, L));
-    // long-node levels are enqueued blind (an empty level costs a few microseconds, asking costs a round trip): first
-    // as many as a balanced tree has, then two at a time while a next level still has long nodes
-    const int first_levels = bvh_build_first_levels(n);
-    int lv = 0, lv_end = first_levels > 0 ? first_levels + 1 : 0;
-    int hostf[kBvhFlagWords + kBvhLevels];
-    hostf[kBvhNodeCount] = 1;  // n <= subtree size: the root is all there is above the subtrees
-    while (lv_end > 0) {
-      if (lv_end > kBvhKeyDepth + 1) lv_end = kBvhKeyDepth + 1;
-      HIPCHK(c, bvh_build_levels(c->stream, n, leaf, lv, lv_end, s.bb_scratch, L));
-      HIPCHK(c, hipMemcpyAsync(hostf, s.bb_scratch + L.flags, kBvhFlagWords * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(c, hipMemcpyAsync(hostf + kBvhFlagWords, s.bb_scratch + L.bigcount, kBvhLevels * sizeof(int), hipMemcpyDeviceToHost,
-                               c->stream));
-      HIPCHK(c, hipStreamSynchronize(c->stream));
-      if (hostf[kBvhFallback] != 0) return 1;
-      if (hostf[kBvhFlagWords + lv_end] == 0) break;
-      if (lv_end >= kBvhKeyDepth + 1) return 1;
-      lv = lv_end;
-      lv_end += 2;
-    }
     int rc = ensure_node_buffers<T>(c, s, (size_t)L.node_cap);
     if (rc) return rc;
     rc = ensure_node_aux<T>(c, s, (size_t)L.node_cap);
     if (rc) return rc;
-    HIPCHK(c, bvh_build_finish(c->stream, in.weight, n, leaf, hostf[kBvhNodeCount], s.bb_scratch, L, s.order_dev, s.geom0, s.geom1, s.link, s.node_depth,
-                               s.node_mass, s.node_size));
-    HIPCHK(c, hipMemcpyAsync(hostf, s.bb_scratch + L.flags, kBvhFlagWords * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    // Everything is enqueued blind — the long-node levels a balanced tree has (plus two), the subtrees, the numbering,
+    // the row gather — and checked once at the end: asking in between costs a round trip per question, an empty level
+    // a few microseconds.  A lopsided tree still has long nodes then: levels two at a time (asking after each pair)
+    // until none is left, then the tail once more for the subtrees that were not there the first time.
+    const int first_levels = bvh_build_first_levels(n);
+    int lv_end = first_levels > 0 ? first_levels + 2 : 0;
+    if (lv_end > 0) lv_end = std::max(1, env_int("NBODY_BVH_BLIND_LEVELS", lv_end));  // tests force the lopsided path
+    if (lv_end > kBvhKeyDepth + 1) lv_end = kBvhKeyDepth + 1;
+    int hostf[kBvhFlagWords + kBvhLevels];
+    auto tail = [&](int sub_start) -> int {
+      HIPCHK(c, bvh_build_finish(c->stream, in.weight, n, leaf, sub_start, s.bb_scratch, L, s.order_dev, s.geom0, s.geom1, s.link,
+                                 s.node_depth, s.node_mass, s.node_size));
+      GatherArgs<T> g{};  // rows into tree order, as the in-place partition leaves `self.particles` (bvh_tree.rs:73-77)
+      g.perm = s.order_dev;
+      g.n = n;
+      g.pos_in = in.pos; g.pos_out = out.pos;
+      g.weight_in = in.weight;
+      g.mass_out = out.mass;
+      g.vel_in = in.vel; g.vel_out = out.vel;
+      g.weight_out = out.weight;
+      g.ids_in = in.ids; g.ids_out = out.ids;
+      HIPCHK(c, launch_gather<T>(c->stream, g));
+      return NBODY_OK;
+    };
+    auto ask = [&]() -> int {
+      HIPCHK(c, hipMemcpyAsync(hostf, s.bb_scratch + L.flags, kBvhFlagWords * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipMemcpyAsync(hostf + kBvhFlagWords, s.bb_scratch + L.bigcount, kBvhLevels * sizeof(int), hipMemcpyDeviceToHost,
+                               c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      return NBODY_OK;
+    };
+    if (lv_end > 0) HIPCHK(c, bvh_build_levels(c->stream, n, leaf, 0, lv_end, s.bb_scratch, L));
+    rc = tail(0);
+    if (rc) return rc;
+    rc = ask();
+    if (rc) return rc;
     if (hostf[kBvhFallback] != 0) return 1;
+    if (lv_end > 0 && hostf[kBvhFlagWords + lv_end] != 0) {  // long nodes were left behind
+      const int sub_start = hostf[kBvhSubCount];
+      while (hostf[kBvhFlagWords + lv_end] != 0) {
+        if (lv_end >= kBvhKeyDepth + 1) return 1;
+        const int lv = lv_end;
+        lv_end = lv_end + 2 > kBvhKeyDepth + 1 ? kBvhKeyDepth + 1 : lv_end + 2;
+        HIPCHK(c, bvh_build_levels(c->stream, n, leaf, lv, lv_end, s.bb_scratch, L));
+        rc = ask();
+        if (rc) return rc;
+        if (hostf[kBvhFallback] != 0) return 1;
+      }
+      rc = tail(sub_start);
+      if (rc) return rc;
+      rc = ask();
+      if (rc) return rc;
+      if (hostf[kBvhFallback] != 0) return 1;
+    }
     if (env_int("NBODY_TRACE", 0) != 0)
-      std::fprintf(stderr, "[nbody] device bvh build: %d nodes, depth %d, %d subtrees, %d scan restarts; subtree phases (max 100 MHz ticks) %d %d %d %d %d %d %d %d\n",
-                   hostf[kBvhNodeCount], hostf[kBvhMaxDepth], hostf[kBvhSubCount], hostf[kBvhStops], hostf[kBvhDebug], hostf[kBvhDebug + 1],
-                   hostf[kBvhDebug + 2], hostf[kBvhDebug + 3], hostf[kBvhDebug + 4], hostf[kBvhDebug + 5], hostf[kBvhDebug + 6], hostf[kBvhDebug + 7]);
+      std::fprintf(stderr, "[nbody] device bvh build: %d nodes, depth %d, %d subtrees, %d long-node levels, %d scan restarts\n",
+                   hostf[kBvhNodeCount], hostf[kBvhMaxDepth], hostf[kBvhSubCount], lv_end, hostf[kBvhStops]);
     const int m = hostf[kBvhNodeCount];
     if (m <= 0 || m > L.node_cap) return 1;
-    GatherArgs<T> g{};  // rows into tree order, as the in-place partition leaves `self.particles` (bvh_tree.rs:73-77)
-    g.perm = s.order_dev;
-    g.n = n;
-    g.pos_in = in.pos; g.pos_out = out.pos;
-    g.weight_in = in.weight;
-    g.mass_out = out.mass;
-    g.vel_in = in.vel; g.vel_out = out.vel;
-    g.weight_out = out.weight;
-    g.ids_in = in.ids; g.ids_out = out.ids;
-    HIPCHK(c, launch_gather<T>(c->stream, g));
     s.cur = 1 - s.cur;
     s.h_weight_stale = true;
     s.n_nodes = m;

@@ -354,3 +354,25 @@ def test_device_bvh_build_declines_nan_positions(nb, orc, ctx):
     o = orc.BVH(pos, w).flat()
     t = ctx.tree_export()
     assert np.array_equal(t["geom"], o.geom, equal_nan=True) and np.array_equal(t["order"], o.ids)
+
+
+@pytest.mark.parametrize("blind", ["1", "3"])
+def test_device_bvh_build_with_long_nodes_left_after_the_blind_levels(nb, orc, ctx, monkeypatch, blind):
+    """The build enqueues the levels a balanced tree needs and checks once; a lopsided tree (or, here, too few blind
+    levels) must go on level by level and still end in the same tree."""
+    C = nb._capi
+    monkeypatch.setenv("NBODY_BVH_BLIND_LEVELS", blind)
+    rng = np.random.default_rng(23)
+    scenes = {"galaxy": nb.scenes.galaxy()[::2],
+              "wide": ((10.0 ** rng.uniform(-8, 8, (60000, 2))).astype(F32), np.ones(60000, np.uint32))}
+    for name, (pos, w) in scenes.items():
+        ctx.set_params(theta=50.0, leaf_size=64)
+        ctx.upload(pos, np.zeros_like(pos), w)
+        ctx.accel_tree(C.TREE_BVH, pos[:4])
+        assert ctx.last_build_on_device(), name
+        t = ctx.tree_export()
+        o = orc.BVH(pos, w).flat()
+        for k in ("mass", "is_leaf", "first", "count", "skip"):
+            assert np.array_equal(t[k], getattr(o, k)), (name, k)
+        assert np.array_equal(t["geom"], o.geom, equal_nan=True), name
+        assert np.array_equal(t["order"], o.ids), name
