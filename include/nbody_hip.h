@@ -201,6 +201,19 @@ int nbody_direct_workspace_peek(void* stream, const void* workspace, int32_t out
 /* u32 weights -> f32 masses on device (the `as f32` of main.rs:360). */
 int nbody_weights_to_mass_dev(void* stream, int64_t n, const void* weight_u32, void* mass_f32);
 
+/* ---- frame raster: the reference's draw() (main.rs:41-72) ---------------------------------------------- */
+/* A render_px x render_px RGBA8 frame of the current rows, exactly as draw() paints `world.particles` (row order
+ * = the order nbody_download returns): rows inside [0, height)^2 land on pixel (y as u32 / cell) * render_px +
+ * (x as u32 / cell), cell = height / render_px (HEIGHT = 100000, RENDER_HEIGHT = 1250 upstream, main.rs:31-32);
+ * weight > 10 paints (0,255,0,255); lighter rows paint R = 255, G = B = 255 - (0x10 + min(((|vx|+|vy|)*10) as u8,
+ * 0xef)) of the LAST such row on the pixel, alpha = min(10 * rows, 250).  rgba_out: host, render_px^2 * 4 bytes.
+ * render_px must divide height (upstream indexes out of range otherwise). */
+int nbody_render_rgba(nbody_ctx* ctx, uint32_t height, uint32_t render_px, uint8_t* rgba_out);
+/* Same on caller-owned device arrays and stream (n <= 2^24 rows; work_u32: 2 * render_px^2 u32 scratch;
+ * rgba_dev: render_px^2 * 4 bytes).  Asynchronous. */
+int nbody_render_rgba_dev(void* stream, int64_t n, int is_f64, const void* pos_xy, const void* vel_xy, const void* weight_u32,
+                          uint32_t height, uint32_t render_px, void* work_u32, void* rgba_dev);
+
 /* ---- self-test hooks (host only, no device needed) --------------------------------------------------- */
 /* The device BVH build reproduces the sequential f32 sum of bvh_tree.rs:58-61 with a parallel scan
  * (csrc/exact_sum.h).  This runs the same scan functions on the CPU, `tile` addends per scan and `seq_run` plain

@@ -84,6 +84,8 @@ _SIGS = {
     "nbody_direct_step_dev": (C.c_int, [_vp, _i64, _vp, _vp, _f32, _i64, _i64, _vp, _vp, _vp, _f32, _f32, _i32, _vp, _sz, _vp]),
     "nbody_direct_workspace_peek": (C.c_int, [_vp, _vp, C.POINTER(C.c_int32 * 4)]),
     "nbody_weights_to_mass_dev": (C.c_int, [_vp, _i64, _vp, _vp]),
+    "nbody_render_rgba": (C.c_int, [_vp, C.c_uint32, C.c_uint32, _vp]),
+    "nbody_render_rgba_dev": (C.c_int, [_vp, C.c_int64, C.c_int, _vp, _vp, _vp, C.c_uint32, C.c_uint32, _vp, _vp]),
     "nbody_selftest_exact_sum": (C.c_int, [_vp, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int64)]),
     "nbody_bvh_build_restarts": (C.c_int, [_vp]),
     "nbody_last_build_on_device": (C.c_int, [_vp]),
@@ -331,6 +333,12 @@ class Context:
         acc = np.zeros_like(tg)
         check(self.h, f(self.h, int(kind), tg.shape[0], _ptr(tg), _ptr(acc)))
         return acc
+
+    def render(self, height=100_000, render_px=1250):
+        """The reference's draw() of the current rows -> uint8 array (render_px, render_px, 4), RGBA."""
+        out = np.zeros((render_px, render_px, 4), np.uint8)
+        check(self.h, self.lib.nbody_render_rgba(self.h, int(height), int(render_px), _ptr(out)))
+        return out
 
     def last_build_on_device(self) -> bool:
         return bool(self.lib.nbody_last_build_on_device(self.h))

@@ -21,6 +21,7 @@
 #include "bvh_build.h"
 #include "exact_sum.h"
 #include "quad_build.h"
+#include "render.h"
 #include "tree_build.hpp"
 #include "tree_kernels.h"
 
@@ -162,6 +163,9 @@ struct nbody_ctx {
   bool last_build_device = false;
   size_t workspace_bytes = 0;
   unsigned long long* stats_dev = nullptr;
+  uint32_t* frame_work = nullptr;  // render: per-pixel counters
+  uint8_t* frame_rgba = nullptr;
+  uint32_t frame_px = 0;
   unsigned long long last_stats[3] = {0, 0, 0};
   bool want_stats = false;
 };
@@ -979,6 +983,8 @@ NB_API void nbody_destroy(nbody_ctx* c) {
   free_state(c->sd);
   free_dev(c->workspace);
   free_dev(c->stats_dev);
+  free_dev(c->frame_work);
+  free_dev(c->frame_rgba);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -1011,6 +1017,45 @@ NB_API int nbody_download_f32(nbody_ctx* c, float* pos, float* vel, uint32_t* w,
 NB_API int nbody_download_f64(nbody_ctx* c, double* pos, double* vel, uint32_t* w, uint32_t* ids) {
   return download<double>(c, pos, vel, w, ids);
 }
+template <class T> int render_rows(nbody_ctx* c, State<T>& s, uint32_t height, uint32_t render_px, uint8_t* rgba_out) {
+  auto& st = s.set[s.cur];
+  HIPCHK(c, launch_render<T>(c->stream, s.n, st.pos, st.vel, st.weight, height, render_px, c->frame_work, c->frame_rgba));
+  HIPCHK(c, hipMemcpyAsync(rgba_out, c->frame_rgba, (size_t)render_px * render_px * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return NBODY_OK;
+}
+NB_API int nbody_render_rgba(nbody_ctx* c, uint32_t height, uint32_t render_px, uint8_t* rgba_out) {
+  if (!c) return NBODY_ERR_INVALID;
+  if (!rgba_out) return fail(c, NBODY_ERR_INVALID, "render: null output");
+  if (!c->has_f32 && !c->has_f64) return fail(c, NBODY_ERR_INVALID, "render: no particles uploaded");
+  // main.rs:51-52 divide by HEIGHT / RENDER_HEIGHT: a cell of 0 world units or a last cell past the frame is an
+  // out-of-range index upstream (a panic): refuse instead
+  if (render_px == 0 || render_px > 16384 || height == 0 || height % render_px != 0 || height > (1u << 24))
+    return fail(c, NBODY_ERR_INVALID, "render: render_px must divide height (both > 0, height <= 2^24, render_px <= 16384)");
+  const int64_t n = c->has_f32 ? c->sf.n : c->sd.n;
+  if (n > (1 << 24)) return fail(c, NBODY_ERR_INVALID, "render: more than 2^24 rows");
+  HIPCHK(c, hipSetDevice(c->device));
+  if (c->frame_px != render_px) {
+    free_dev(c->frame_work); free_dev(c->frame_rgba);
+    c->frame_px = 0;
+    HIPCHK(c, hipMalloc((void**)&c->frame_work, sizeof(uint32_t) * 2 * (size_t)render_px * render_px));
+    HIPCHK(c, hipMalloc((void**)&c->frame_rgba, (size_t)render_px * render_px * 4));
+    c->frame_px = render_px;
+  }
+  return c->has_f32 ? render_rows<float>(c, c->sf, height, render_px, rgba_out) : render_rows<double>(c, c->sd, height, render_px, rgba_out);
+}
+NB_API int nbody_render_rgba_dev(void* stream, int64_t n, int is_f64, const void* pos_xy, const void* vel_xy, const void* weight_u32,
+                                 uint32_t height, uint32_t render_px, void* work_u32, void* rgba_dev) {
+  if (n < 0 || n > (1 << 24) || render_px == 0 || height == 0 || height % render_px != 0 || height > (1u << 24) || !work_u32 || !rgba_dev ||
+      (n > 0 && (!pos_xy || !vel_xy || !weight_u32)))
+    return NBODY_ERR_INVALID;
+  hipError_t e = is_f64 ? launch_render<double>((hipStream_t)stream, n, pos_xy, vel_xy, (const uint32_t*)weight_u32, height, render_px,
+                                                (uint32_t*)work_u32, (uint8_t*)rgba_dev)
+                        : launch_render<float>((hipStream_t)stream, n, pos_xy, vel_xy, (const uint32_t*)weight_u32, height, render_px,
+                                               (uint32_t*)work_u32, (uint8_t*)rgba_dev);
+  return e == hipSuccess ? NBODY_OK : NBODY_ERR_HIP;
+}
+
 NB_API int64_t nbody_num_particles(const nbody_ctx* c) {
   if (!c) return NBODY_ERR_INVALID;
   return c->has_f32 ? c->sf.n : (c->has_f64 ? c->sd.n : 0);

@@ -52,5 +52,10 @@ class World:
         `self.particles` would be in (permuted by every BVH build); ids give each row's original index."""
         return self.ctx.download()
 
+    def frame(self, height=100_000, render_px=1250):
+        """The frame the reference's render thread would draw from these particles (`draw`, main.rs:41-72):
+        uint8 array (render_px, render_px, 4), RGBA."""
+        return self.ctx.render(height, render_px)
+
     def close(self):
         self.ctx.close()

@@ -360,3 +360,53 @@ ORC_API void orc_pair_f64(double p1x, double p1y, double p2x, double p2y, double
 
 ORC_INSTANTIATE(f32, float)
 ORC_INSTANTIATE(f64, double)
+
+
+// ---- draw(), /root/reference src/main.rs:41-72, with within_bounds :224-226 — restated line by line -------------
+namespace {
+template <class T> static inline uint32_t as_u32(T v) {  // Rust `as u32`: saturating, NaN -> 0
+  if (!(v == v)) return 0u;
+  if (v <= (T)0) return 0u;
+  if (v >= (T)4294967295.0) return 4294967295u;
+  return (uint32_t)v;
+}
+template <class T> static inline uint8_t as_u8(T v) {  // Rust `as u8`
+  if (!(v == v)) return 0;
+  if (v <= (T)0) return 0;
+  if (v >= (T)255) return 255;
+  return (uint8_t)v;
+}
+template <class T>
+void draw_t(int64_t n, const T* pos, const T* vel, const uint32_t* weight, uint32_t HEIGHT, uint32_t RENDER_HEIGHT, uint8_t* frame) {
+  const size_t bytes = (size_t)RENDER_HEIGHT * RENDER_HEIGHT * 4;
+  for (size_t i = 0; i < bytes; ++i) frame[i] = 0;                                   // :43
+  for (int64_t i = 0; i < n; ++i) {                                                  // :46
+    const T x = pos[2 * i], y = pos[2 * i + 1];
+    if (!(y < (T)HEIGHT && x < (T)HEIGHT && y >= (T)0 && x >= (T)0)) continue;       // :47, :224-226
+    const size_t offset = ((size_t)(as_u32(y) / (HEIGHT / RENDER_HEIGHT)) * RENDER_HEIGHT +
+                           (size_t)(as_u32(x) / (HEIGHT / RENDER_HEIGHT))) * 4;       // :51-54
+    if (offset + 3 >= bytes) continue;  // upstream would panic; callers keep RENDER_HEIGHT | HEIGHT
+    if (weight[i] > 10) {                                                            // :55
+      frame[offset] = 0x00; frame[offset + 1] = 0xff; frame[offset + 2] = 0x00; frame[offset + 3] = 0xff;
+    } else if (frame[offset + 3] != 0xff) {                                          // :60
+      const T vx = vel[2 * i], vy = vel[2 * i + 1];
+      const T a = ((vx < 0 ? -vx : vx) + (vy < 0 ? -vy : vy)) * (T)10.0;             // :62
+      uint8_t b = as_u8(a);
+      if (b > 0xef) b = 0xef;                                                        // :63 .min(0xef)
+      const uint8_t velocity = (uint8_t)(0x10 + b);                                  // :61
+      frame[offset] = 0xff;
+      frame[offset + 1] = (uint8_t)(0xff - velocity);
+      frame[offset + 2] = (uint8_t)(0xff - velocity);
+      if (frame[offset + 3] <= 240) frame[offset + 3] = (uint8_t)(frame[offset + 3] + 10);  // :67-69
+    }
+  }
+}
+}  // namespace
+ORC_API void orc_draw_f32(int64_t n, const float* pos, const float* vel, const uint32_t* weight, uint32_t height, uint32_t render_px,
+                          uint8_t* frame) {
+  draw_t<float>(n, pos, vel, weight, height, render_px, frame);
+}
+ORC_API void orc_draw_f64(int64_t n, const double* pos, const double* vel, const uint32_t* weight, uint32_t height,
+                          uint32_t render_px, uint8_t* frame) {
+  draw_t<double>(n, pos, vel, weight, height, render_px, frame);
+}

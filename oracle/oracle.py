@@ -163,6 +163,22 @@ def update_quad(pos, vel, weight, delta=0.1, theta=50.0, clamp=0.001, root=(0.0,
     return pos, vel, cnt
 
 
+def draw(pos, vel, weight, height=100_000, render_px=1250):
+    """draw() of main.rs:41-72 over the rows in the order given -> uint8 (render_px, render_px, 4)."""
+    pos = np.asarray(pos)
+    dtype = np.float64 if pos.dtype == np.float64 else np.float32
+    ct = C.c_double if dtype == np.float64 else C.c_float
+    pos = _prep(pos, dtype)
+    vel = _prep(vel, dtype)
+    w = np.ascontiguousarray(weight, dtype=np.uint32)
+    out = np.zeros((render_px, render_px, 4), np.uint8)
+    f = getattr(lib(), "orc_draw_" + _sfx(dtype))
+    f.argtypes = [C.c_int64, C.POINTER(ct), C.POINTER(ct), C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32, C.POINTER(C.c_uint8)]
+    f.restype = None
+    f(pos.shape[0], _p(pos, ct), _p(vel, ct), _p(w, C.c_uint32), int(height), int(render_px), _p(out, C.c_uint8))
+    return out
+
+
 @dataclass
 class FlatBVH:
     geom: np.ndarray      # [n_nodes, 6] off_x off_y size_x size_y cog_x cog_y

@@ -277,3 +277,27 @@ class PyQuad:
             for k in node["kids"]:
                 if k is not None:
                     self._walk(p, k, acc, theta, clamp)
+
+
+def draw(pos, vel, weight, height=100_000, render_px=1250):
+    """draw() of main.rs:41-72, written independently of the C++ oracle: a plain Python loop over the rows."""
+    frame = np.zeros((render_px * render_px, 4), np.uint8)
+    cell = height // render_px
+    dt = pos.dtype.type
+    for i in range(pos.shape[0]):
+        x, y = pos[i]
+        if not (y < dt(height) and x < dt(height) and y >= 0 and x >= 0):
+            continue
+        off = (int(y) // cell) * render_px + int(x) // cell
+        if weight[i] > 10:
+            frame[off] = (0, 255, 0, 255)
+        elif frame[off, 3] != 255:
+            a = (abs(vel[i, 0]) + abs(vel[i, 1])) * dt(10.0)
+            b = 0 if np.isnan(a) else (255 if a >= 255 else int(a))
+            v = 0x10 + min(b, 0xEF)
+            frame[off, 0] = 255
+            frame[off, 1] = 255 - v
+            frame[off, 2] = 255 - v
+            if frame[off, 3] <= 240:
+                frame[off, 3] += 10
+    return frame.reshape(render_px, render_px, 4)

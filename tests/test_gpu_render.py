@@ -1,0 +1,54 @@
+"""The frame raster (render.hip) against the oracle's line-by-line draw() (main.rs:41-72).  Needs an MI355X."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+F32 = np.float32
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_render_equals_reference_draw_on_crowded_pixels(nb, orc, dtype):
+    C = nb._capi
+    rng = np.random.default_rng(31)
+    n = 200_000
+    pos = (rng.random((n, 2)) * 1.1e5 - 5e3).astype(dtype)                    # some rows outside [0, HEIGHT)^2
+    pos[:50_000] = (rng.random((50_000, 2)) * 2000 + 40_000).astype(dtype)    # ~80 rows per pixel: alpha saturates
+    pos[7] = (np.nan, 10)
+    vel = (rng.standard_normal((n, 2)) * 4).astype(dtype)
+    vel[11] = (np.inf, 0)
+    vel[12] = (np.nan, 0)
+    w = np.where(rng.random(n) < 0.001, 750_000, rng.integers(1, 12, n)).astype(np.uint32)   # weights 10 / 11 straddle "> 10"
+    with C.Context(0) as ctx:
+        ctx.upload(pos, vel, w)
+        for px in (1250, 100):
+            got = ctx.render(100_000, px)
+            want = orc.draw(pos, vel, w, 100_000, px)
+            assert np.array_equal(got, want), px
+        with pytest.raises(C.NBodyError):
+            ctx.render(100_000, 1251)          # does not divide HEIGHT: out-of-range index upstream
+
+
+def test_render_follows_the_row_order_of_the_bvh_permutation(nb, orc):
+    """draw() runs over `world.particles` as the in-place partition left them: the last light row on a pixel wins."""
+    pos, vel, w = nb.scenes.galaxy()
+    world = nb.World(pos, vel, w, method="bvh")
+    try:
+        cnt = nb.Counting()
+        for _ in range(3):
+            world.update(0.1, cnt)
+        p, v, w2, _ = world.particles()
+        frame = world.frame()
+        assert np.array_equal(frame, orc.draw(p, v, w2))
+        assert frame[..., 3].any() and (frame[..., 1] == 255).any()   # the two heavy bodies are green
+    finally:
+        world.close()
+
+
+def test_render_empty_and_single(nb, orc):
+    C = nb._capi
+    with C.Context(0) as ctx:
+        pos = np.array([[85, 170]], F32)
+        vel = np.array([[0.3, -0.4]], F32)
+        ctx.upload(pos, vel, np.ones(1, np.uint32))
+        f = ctx.render()
+        assert tuple(f[2, 1]) == (255, 232, 232, 10) and np.count_nonzero(f) == 4

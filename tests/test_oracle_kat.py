@@ -418,3 +418,50 @@ def test_oracle_quad_agrees_with_python_restatement(orc, nb, dtype, n, theta):
     got = np.array([py.walk(p, theta) for p in tg], dtype=dtype)
     assert np.array_equal(got, ref)
     assert int(py.root["mass"] if not py.root["leaf"] else 0) == int(q.flat().mass[0])
+
+
+# ---------------------------------------------------------------- draw()  (main.rs:41-72)
+def test_draw_known_answers(orc):
+    """Hand-derived pixels: cell = 100000 / 1250 = 80 world units."""
+    pos = np.array([[85, 170], [85.5, 171], [99999, 0], [-1, 5], [100000, 5], [500, 500], [500, 501], [np.nan, 3]], F32)
+    vel = np.array([[0.3, -0.4], [1, 1], [100, 0], [0, 0], [0, 0], [0, 0], [2, 2], [0, 0]], F32)
+    w = np.array([1, 1, 1, 1, 1, 75_000_000, 1, 1], np.uint32)
+    f = orc.draw(pos, vel, w)
+    assert f.shape == (1250, 1250, 4)
+    # rows 0 and 1 share pixel (x 1, y 2): the later row colours it, (|1|+|1|)*10 = 20 -> v = 0x10 + 20; alpha 2 * 10
+    assert tuple(f[2, 1]) == (255, 255 - 36, 255 - 36, 20)
+    # (|100|)*10 saturates `as u8`, then .min(0xef): v = 0xff
+    assert tuple(f[0, 1249]) == (255, 0, 0, 10)
+    # weight > 10 paints green and a later light row leaves it alone; out-of-bounds and NaN rows paint nothing
+    assert tuple(f[6, 6]) == (0, 255, 0, 255)
+    assert np.count_nonzero(f[..., 3]) == 3
+
+
+def test_draw_alpha_saturates_at_250_and_heavy_overrides(orc):
+    n = 40
+    pos = np.tile(np.array([[1000.5, 2000.5]], F32), (n, 1))
+    vel = np.zeros((n, 2), F32)
+    vel[-1] = (0.5, 0.25)
+    w = np.ones(n, np.uint32)
+    f = orc.draw(pos, vel, w)
+    assert tuple(f[25, 12]) == (255, 255 - (0x10 + 7), 255 - (0x10 + 7), 250)   # 25 increments of 10, then stuck
+    w[3] = 11                                                                     # one heavy row anywhere
+    assert tuple(orc.draw(pos, vel, w)[25, 12]) == (0, 255, 0, 255)
+    w[3] = 10                                                                     # "> 10" is strict
+    assert tuple(orc.draw(pos, vel, w)[25, 12])[3] == 250
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_draw_matches_independent_python_loop(orc, dtype):
+    rng = np.random.default_rng(12)
+    n = 4000
+    pos = (rng.random((n, 2)) * 1.2e5 - 1e4).astype(dtype)       # some outside the box
+    pos[:300] = (rng.integers(0, 40, (300, 2)) * 80.0 + 3).astype(dtype)   # crowded pixels
+    vel = (rng.standard_normal((n, 2)) * 3).astype(dtype)
+    vel[5] = (np.nan, 1)
+    vel[6] = (1e30, 0)
+    w = np.where(rng.random(n) < 0.02, 750_000, 1).astype(np.uint32)
+    got = orc.draw(pos, vel, w, 100_000, 1250)
+    want = npr.draw(pos, vel, w, 100_000, 1250)
+    assert np.array_equal(got, want)
+    assert np.array_equal(orc.draw(pos, vel, w, 100_000, 100), npr.draw(pos, vel, w, 100_000, 100))
