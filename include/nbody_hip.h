@@ -201,6 +201,19 @@ int nbody_direct_workspace_peek(void* stream, const void* workspace, int32_t out
 /* u32 weights -> f32 masses on device (the `as f32` of main.rs:360). */
 int nbody_weights_to_mass_dev(void* stream, int64_t n, const void* weight_u32, void* mass_f32);
 
+/* ---- snapshot hand-off (main.rs:136-139) ---------------------------------------------------------------- */
+/* The reference's sim thread clones `world.particles` for the render thread whenever the bounded channel has room
+ * (`if !tx.is_full() { tx.try_send((world.particles.clone(), updates, counter.clone())) }`) and keeps stepping.
+ * nbody_snapshot_begin copies the current rows aside on the device (ordered after the last step) and starts their
+ * transfer to pinned host memory on a second stream; steps issued afterwards run alongside that transfer.
+ * nbody_snapshot_end waits for it and hands the rows out (any pointer may be NULL) together with the number of steps
+ * the context had done when the snapshot was taken (`updates`).  One snapshot in flight per context: begin while one
+ * is pending fails with NBODY_ERR_INVALID — "channel full", skip it as the reference does (nbody_snapshot_pending). */
+int nbody_snapshot_begin(nbody_ctx* ctx);
+int nbody_snapshot_pending(const nbody_ctx* ctx);
+int nbody_snapshot_end_f32(nbody_ctx* ctx, float* pos_xy, float* vel_xy, uint32_t* weight, uint32_t* ids, uint64_t* step_out);
+int nbody_snapshot_end_f64(nbody_ctx* ctx, double* pos_xy, double* vel_xy, uint32_t* weight, uint32_t* ids, uint64_t* step_out);
+
 /* ---- frame raster: the reference's draw() (main.rs:41-72) ---------------------------------------------- */
 /* A render_px x render_px RGBA8 frame of the current rows, exactly as draw() paints `world.particles` (row order
  * = the order nbody_download returns): rows inside [0, height)^2 land on pixel (y as u32 / cell) * render_px +

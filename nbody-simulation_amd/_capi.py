@@ -84,6 +84,10 @@ _SIGS = {
     "nbody_direct_step_dev": (C.c_int, [_vp, _i64, _vp, _vp, _f32, _i64, _i64, _vp, _vp, _vp, _f32, _f32, _i32, _vp, _sz, _vp]),
     "nbody_direct_workspace_peek": (C.c_int, [_vp, _vp, C.POINTER(C.c_int32 * 4)]),
     "nbody_weights_to_mass_dev": (C.c_int, [_vp, _i64, _vp, _vp]),
+    "nbody_snapshot_begin": (C.c_int, [_vp]),
+    "nbody_snapshot_pending": (C.c_int, [_vp]),
+    "nbody_snapshot_end_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_uint64)]),
+    "nbody_snapshot_end_f64": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_uint64)]),
     "nbody_render_rgba": (C.c_int, [_vp, C.c_uint32, C.c_uint32, _vp]),
     "nbody_render_rgba_dev": (C.c_int, [_vp, C.c_int64, C.c_int, _vp, _vp, _vp, C.c_uint32, C.c_uint32, _vp, _vp]),
     "nbody_selftest_exact_sum": (C.c_int, [_vp, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int64)]),
@@ -333,6 +337,23 @@ class Context:
         acc = np.zeros_like(tg)
         check(self.h, f(self.h, int(kind), tg.shape[0], _ptr(tg), _ptr(acc)))
         return acc
+
+    def snapshot_begin(self):
+        """Start the asynchronous hand-off of the current rows (main.rs:136-139); steps may follow at once."""
+        check(self.h, self.lib.nbody_snapshot_begin(self.h))
+
+    def snapshot_pending(self) -> bool:
+        return bool(self.lib.nbody_snapshot_pending(self.h))
+
+    def snapshot_end(self):
+        """-> (position, velocity, weight, ids, steps done when the snapshot was taken)."""
+        n, dt = self.n, self.dtype
+        pos, vel = np.zeros((n, 2), dt), np.zeros((n, 2), dt)
+        w, ids = np.zeros(n, np.uint32), np.zeros(n, np.uint32)
+        step = C.c_uint64(0)
+        f = self.lib.nbody_snapshot_end_f64 if dt == np.float64 else self.lib.nbody_snapshot_end_f32
+        check(self.h, f(self.h, _ptr(pos), _ptr(vel), _ptr(w), _ptr(ids), C.byref(step)))
+        return pos, vel, w, ids, step.value
 
     def render(self, height=100_000, render_px=1250):
         """The reference's draw() of the current rows -> uint8 array (render_px, render_px, 4), RGBA."""

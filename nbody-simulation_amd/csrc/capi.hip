@@ -164,6 +164,16 @@ struct nbody_ctx {
   size_t workspace_bytes = 0;
   unsigned long long* stats_dev = nullptr;
   uint32_t* frame_work = nullptr;  // render: per-pixel counters
+  hipStream_t copy_stream = nullptr;  // snapshot transfers, concurrent with the steps on `stream`
+  hipEvent_t snap_event = nullptr;
+  bool snap_pending = false;
+  uint64_t steps_done = 0, snap_step = 0;
+  // snapshot staging: device copy of the rows, pinned host image
+  void *snap_pos = nullptr, *snap_vel = nullptr, *snap_hpos = nullptr, *snap_hvel = nullptr;
+  uint32_t *snap_w = nullptr, *snap_ids = nullptr, *snap_hw = nullptr, *snap_hids = nullptr;
+  size_t snap_bytes2 = 0;  // bytes of one position array the staging holds
+  int64_t snap_n = 0;
+  bool snap_f64 = false;
   uint8_t* frame_rgba = nullptr;
   uint32_t frame_px = 0;
   unsigned long long last_stats[3] = {0, 0, 0};
@@ -788,6 +798,7 @@ template <class T> int update_tree(nbody_ctx* c, int kind, T delta, int n_steps,
     c->counting.sum_gravity += t2 - t1;
     c->counting.post_calculations += t3 - t2;
     if (counter) { counter->build_bvh += t1 - t0; counter->sum_gravity += t2 - t1; counter->post_calculations += t3 - t2; }
+    ++c->steps_done;
   }
   return NBODY_OK;
 }
@@ -816,6 +827,7 @@ template <class T> int update_tree_shard(nbody_ctx* c, int kind, T delta, int64_
   c->counting.build_bvh += t1 - t0; c->counting.sum_gravity += t2 - t1; c->counting.post_calculations += t3 - t2;
   if (counter) { counter->build_bvh += t1 - t0; counter->sum_gravity += t2 - t1; counter->post_calculations += t3 - t2; }
   s.shard_kind = kind;
+  ++c->steps_done;
   return NBODY_OK;
 }
 template <class T>
@@ -964,6 +976,8 @@ NB_API int nbody_create(nbody_ctx** out, int device_id) {
   nbody_default_params(&c->params);
   e = hipSetDevice(device_id);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->snap_event, hipEventDisableTiming);
   if (e == hipSuccess) e = hipMalloc((void**)&c->stats_dev, 3 * sizeof(unsigned long long));
   if (e != hipSuccess) {
     int rc = fail_hip(nullptr, e, "nbody_create");
@@ -974,6 +988,7 @@ NB_API int nbody_create(nbody_ctx** out, int device_id) {
   return NBODY_OK;
 }
 
+static void free_snapshot(nbody_ctx* c);
 NB_API void nbody_destroy(nbody_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
@@ -985,6 +1000,10 @@ NB_API void nbody_destroy(nbody_ctx* c) {
   free_dev(c->stats_dev);
   free_dev(c->frame_work);
   free_dev(c->frame_rgba);
+  if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+  free_snapshot(c);
+  if (c->snap_event) (void)hipEventDestroy(c->snap_event);
+  if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -1017,6 +1036,89 @@ NB_API int nbody_download_f32(nbody_ctx* c, float* pos, float* vel, uint32_t* w,
 NB_API int nbody_download_f64(nbody_ctx* c, double* pos, double* vel, uint32_t* w, uint32_t* ids) {
   return download<double>(c, pos, vel, w, ids);
 }
+// ---- snapshot hand-off (main.rs:136-139) --------------------------------------------------------------------------
+static void free_snapshot(nbody_ctx* c) {
+  free_dev(c->snap_pos); free_dev(c->snap_vel); free_dev(c->snap_w); free_dev(c->snap_ids);
+  if (c->snap_hpos) (void)hipHostFree(c->snap_hpos);
+  if (c->snap_hvel) (void)hipHostFree(c->snap_hvel);
+  if (c->snap_hw) (void)hipHostFree(c->snap_hw);
+  if (c->snap_hids) (void)hipHostFree(c->snap_hids);
+  c->snap_hpos = c->snap_hvel = nullptr;
+  c->snap_hw = c->snap_hids = nullptr;
+  c->snap_bytes2 = 0;
+  c->snap_n = 0;
+  c->snap_pending = false;
+}
+template <class T> int snapshot_begin(nbody_ctx* c, State<T>& s) {
+  using T2 = typename State<T>::T2;
+  const size_t n = (size_t)s.n, b2 = n * sizeof(T2);
+  if (c->snap_n != s.n || c->snap_bytes2 != b2) {
+    free_snapshot(c);
+    if (n) {
+      HIPCHK(c, hipMalloc(&c->snap_pos, b2));
+      HIPCHK(c, hipMalloc(&c->snap_vel, b2));
+      HIPCHK(c, hipMalloc((void**)&c->snap_w, n * 4));
+      HIPCHK(c, hipMalloc((void**)&c->snap_ids, n * 4));
+      HIPCHK(c, hipHostMalloc(&c->snap_hpos, b2, hipHostMallocDefault));
+      HIPCHK(c, hipHostMalloc(&c->snap_hvel, b2, hipHostMallocDefault));
+      HIPCHK(c, hipHostMalloc((void**)&c->snap_hw, n * 4, hipHostMallocDefault));
+      HIPCHK(c, hipHostMalloc((void**)&c->snap_hids, n * 4, hipHostMallocDefault));
+    }
+    c->snap_n = s.n;
+    c->snap_bytes2 = b2;
+  }
+  c->snap_f64 = sizeof(T) == 8;
+  auto& st = s.set[s.cur];
+  if (n) {
+    // the rows are copied aside on the stream the steps run on (ordered after the last step, microseconds), so that
+    // later steps may overwrite them; the slow leg to the host runs on its own stream, alongside those steps
+    HIPCHK(c, hipMemcpyAsync(c->snap_pos, st.pos, b2, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->snap_vel, st.vel, b2, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->snap_w, st.weight, n * 4, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->snap_ids, st.ids, n * 4, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipEventRecord(c->snap_event, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->snap_event, 0));
+    HIPCHK(c, hipMemcpyAsync(c->snap_hpos, c->snap_pos, b2, hipMemcpyDeviceToHost, c->copy_stream));
+    HIPCHK(c, hipMemcpyAsync(c->snap_hvel, c->snap_vel, b2, hipMemcpyDeviceToHost, c->copy_stream));
+    HIPCHK(c, hipMemcpyAsync(c->snap_hw, c->snap_w, n * 4, hipMemcpyDeviceToHost, c->copy_stream));
+    HIPCHK(c, hipMemcpyAsync(c->snap_hids, c->snap_ids, n * 4, hipMemcpyDeviceToHost, c->copy_stream));
+  }
+  c->snap_step = c->steps_done;
+  c->snap_pending = true;
+  return NBODY_OK;
+}
+NB_API int nbody_snapshot_begin(nbody_ctx* c) {
+  if (!c) return NBODY_ERR_INVALID;
+  if (!c->has_f32 && !c->has_f64) return fail(c, NBODY_ERR_INVALID, "snapshot_begin: no particles uploaded");
+  if (c->snap_pending) return fail(c, NBODY_ERR_INVALID, "snapshot_begin: a snapshot is still pending (take it with nbody_snapshot_end)");
+  HIPCHK(c, hipSetDevice(c->device));
+  return c->has_f32 ? snapshot_begin<float>(c, c->sf) : snapshot_begin<double>(c, c->sd);
+}
+NB_API int nbody_snapshot_pending(const nbody_ctx* c) { return c && c->snap_pending ? 1 : 0; }
+static int snapshot_end(nbody_ctx* c, bool f64, void* pos, void* vel, uint32_t* w, uint32_t* ids, uint64_t* step) {
+  if (!c) return NBODY_ERR_INVALID;
+  if (!c->snap_pending) return fail(c, NBODY_ERR_INVALID, "snapshot_end: no snapshot pending");
+  if (c->snap_f64 != f64) return fail(c, NBODY_ERR_INVALID, "snapshot_end: the pending snapshot has the other precision");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->copy_stream));
+  const size_t n = (size_t)c->snap_n;
+  if (n) {
+    if (pos) std::memcpy(pos, c->snap_hpos, c->snap_bytes2);
+    if (vel) std::memcpy(vel, c->snap_hvel, c->snap_bytes2);
+    if (w) std::memcpy(w, c->snap_hw, n * 4);
+    if (ids) std::memcpy(ids, c->snap_hids, n * 4);
+  }
+  if (step) *step = c->snap_step;
+  c->snap_pending = false;
+  return NBODY_OK;
+}
+NB_API int nbody_snapshot_end_f32(nbody_ctx* c, float* pos, float* vel, uint32_t* w, uint32_t* ids, uint64_t* step) {
+  return snapshot_end(c, false, pos, vel, w, ids, step);
+}
+NB_API int nbody_snapshot_end_f64(nbody_ctx* c, double* pos, double* vel, uint32_t* w, uint32_t* ids, uint64_t* step) {
+  return snapshot_end(c, true, pos, vel, w, ids, step);
+}
+
 template <class T> int render_rows(nbody_ctx* c, State<T>& s, uint32_t height, uint32_t render_px, uint8_t* rgba_out) {
   auto& st = s.set[s.cur];
   HIPCHK(c, launch_render<T>(c->stream, s.n, st.pos, st.vel, st.weight, height, render_px, c->frame_work, c->frame_rgba));
@@ -1121,6 +1223,7 @@ NB_API int nbody_update_direct_f32(nbody_ctx* c, float delta, int n_steps, nbody
   c->counting.sum_gravity += dt;
   if (counter) counter->sum_gravity += dt;
   s.tree_valid = false;
+  c->steps_done += (uint64_t)n_steps;
   return NBODY_OK;
 }
 

@@ -52,6 +52,15 @@ class World:
         `self.particles` would be in (permuted by every BVH build); ids give each row's original index."""
         return self.ctx.download()
 
+    def snapshot_begin(self):
+        """Hand the current particles to a consumer without stopping the simulation (the `try_send` of
+        main.rs:136-139): returns at once, `update` may be called right away."""
+        self.ctx.snapshot_begin()
+
+    def snapshot_end(self):
+        """-> (position, velocity, weight, ids, updates) of the pending snapshot."""
+        return self.ctx.snapshot_end()
+
     def frame(self, height=100_000, render_px=1250):
         """The frame the reference's render thread would draw from these particles (`draw`, main.rs:41-72):
         uint8 array (render_px, render_px, 4), RGBA."""

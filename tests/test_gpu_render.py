@@ -52,3 +52,38 @@ def test_render_empty_and_single(nb, orc):
         ctx.upload(pos, vel, np.ones(1, np.uint32))
         f = ctx.render()
         assert tuple(f[2, 1]) == (255, 232, 232, 10) and np.count_nonzero(f) == 4
+
+
+# ------------------------------------------------------------------ snapshot hand-off (main.rs:136-139)
+@pytest.mark.parametrize("method,dtype", [("bvh", np.float32), ("quad", np.float64), ("direct", np.float32)])
+def test_snapshot_is_the_state_at_begin_even_if_steps_follow(nb, method, dtype):
+    C = nb._capi
+    pos, vel, w = nb.scenes.plummer(20000, seed=8, dtype=dtype)
+    w = (np.arange(20000) % 5 + 1).astype(np.uint32)
+    world = nb.World(pos, vel, w, method=method)
+    ref = nb.World(pos, vel, w, method=method)
+    try:
+        cnt = nb.Counting()
+        for _ in range(2):
+            world.update(0.1, cnt)
+            ref.update(0.1, cnt)
+        want = ref.particles()
+        world.snapshot_begin()
+        assert world.ctx.snapshot_pending()
+        with pytest.raises(C.NBodyError):
+            world.snapshot_begin()             # "channel full"
+        for _ in range(3):
+            world.update(0.1, cnt)             # overwrites the rows while the snapshot travels
+        p, v, w2, ids, updates = world.snapshot_end()
+        assert updates == 2 and not world.ctx.snapshot_pending()
+        for a, b in zip((p, v, w2, ids), want):
+            assert np.array_equal(a, b)
+        with pytest.raises(C.NBodyError):
+            world.snapshot_end()               # nothing pending
+        for _ in range(3):
+            ref.update(0.1, cnt)
+        for a, b in zip(world.particles(), ref.particles()):   # the snapshot did not disturb the run
+            assert np.array_equal(a, b)
+    finally:
+        world.close()
+        ref.close()
