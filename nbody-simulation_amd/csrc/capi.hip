@@ -24,6 +24,7 @@
 #include "render.h"
 #include "tree_build.hpp"
 #include "tree_kernels.h"
+#include "walk_split.h"
 
 using namespace nbody;
 
@@ -114,6 +115,12 @@ template <class T> struct State {
   char* bb_scratch = nullptr;    // device BVH build
   size_t bb_scratch_bytes = 0;
   bool h_weight_stale = false;   // a device BVH build permuted the rows without touching h_weight
+  // split walk (walk_split.hip): counts/offsets scratch and the term array
+  char* ws_scratch = nullptr;
+  size_t ws_scratch_bytes = 0;
+  void* ws_terms = nullptr;
+  int64_t ws_capacity = 0;       // terms
+  int ws_backoff = 0;            // steps for which the split walk is not tried (the last one needed too much memory)
   std::vector<T> h_pos;
   std::vector<uint32_t> h_weight;  // current row order
   std::vector<uint32_t> h_tmp;
@@ -208,8 +215,9 @@ template <class P> void free_dev(P*& p) {
 template <class T> void free_state(State<T>& s) {
   for (auto& st : s.set) { free_dev(st.pos); free_dev(st.vel); free_dev(st.weight); free_dev(st.ids); free_dev(st.mass); }
   free_dev(s.pos_next); free_dev(s.acc); free_dev(s.geom0); free_dev(s.geom1); free_dev(s.link); free_dev(s.order_dev);
-  free_dev(s.node_depth); free_dev(s.node_mass); free_dev(s.node_size); free_dev(s.qb_scratch); free_dev(s.bb_scratch);
+  free_dev(s.node_depth); free_dev(s.node_mass); free_dev(s.node_size); free_dev(s.qb_scratch); free_dev(s.bb_scratch); free_dev(s.ws_scratch); free_dev(s.ws_terms);
   s.node_aux_cap = 0; s.qb_scratch_bytes = 0; s.bb_scratch_bytes = 0; s.h_weight_stale = false;
+  s.ws_scratch_bytes = 0; s.ws_capacity = 0; s.ws_backoff = 0;
   s.tree_host_stale = false; s.n_nodes = 0;
   s.node_cap = 0; s.n = 0; s.tree_valid = false; s.tree.clear();
   s.h_pos.clear(); s.h_weight.clear();
@@ -765,7 +773,48 @@ int tree_walk_phase(nbody_ctx* c, State<T>& s, int kind, const void* tgt_pos, in
     else if (slice_count >= 0) { w.tgt_pos = s.set[s.cur].pos; w.n_tgt = slice_count; w.tgt_index = s.order_dev + slice_begin; }
     else { w.tgt_pos = s.set[s.cur].pos; w.n_tgt = s.n; w.tgt_index = s.order_dev; }
   }
-  {
+  bool done = false;
+  if constexpr (std::is_same<T, float>::value) {
+    // Big leaves and the reference's arithmetic: count / terms / ordered sum (walk_split.hip) unless it would need more
+    // memory than it is worth.  NBODY_WALK_SPLIT: 0 never, 1 when it pays (default), 2 whenever it is possible.
+    const int mode = env_int("NBODY_WALK_SPLIT", 1);
+    const bool eligible = w.big_leaves && !w.fast && !w.stats && w.n_tgt > 0 && w.n_nodes > 0 && env_int("NBODY_WALK_PER_THREAD", 0) == 0;
+    if (eligible && mode != 0 && (mode == 2 || (w.n_tgt >= 4096 && s.ws_backoff == 0))) {
+      const int64_t hard_cap = (int64_t)1 << 29;  // terms: 4 GB; past that the fused walk
+      const WalkSplitLayout L = walk_split_layout(w.n_tgt);
+      if (s.ws_scratch_bytes < L.total) {
+        free_dev(s.ws_scratch);
+        s.ws_scratch_bytes = 0;
+        HIPCHK(c, hipMalloc((void**)&s.ws_scratch, L.total));
+        s.ws_scratch_bytes = L.total;
+      }
+      for (int attempt = 0; attempt < 2 && !done; ++attempt) {
+        int info[4] = {0, 0, 0, 0};
+        {
+          TimerScope ts(c->timer, c->stream);
+          HIPCHK(c, launch_tree_walk_split(c->stream, w, s.ws_scratch, L, s.ws_terms, s.ws_capacity));
+        }
+        HIPCHK(c, hipMemcpyAsync(info, s.ws_scratch + L.info, sizeof(info), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (info[1] == 0) {
+          done = true;
+        } else if (info[2] != 0 || info[0] > hard_cap) {
+          s.ws_backoff = 64;  // too many terms for this tree: fused walk for a while
+          break;
+        } else {  // the term array was too small (or absent): half as much again, once
+          free_dev(s.ws_terms);
+          s.ws_capacity = 0;
+          int64_t want = (int64_t)info[0] + info[0] / 2 + 4096;
+          if (want > hard_cap) want = hard_cap;
+          HIPCHK(c, hipMalloc(&s.ws_terms, (size_t)want * sizeof(float2)));
+          s.ws_capacity = want;
+        }
+      }
+    } else if (s.ws_backoff > 0 && eligible) {
+      --s.ws_backoff;
+    }
+  }
+  if (!done) {
     TimerScope ts(c->timer, c->stream);
     HIPCHK(c, launch_tree_walk<T>(c->stream, w, env_int("NBODY_WALK_PER_THREAD", 0) == 0));
   }

@@ -173,7 +173,14 @@ __global__ __launch_bounds__(256) void tree_walk_wave(const WalkArgs<T> a) {
   int i = 0;
   int4 l = lk[0];
   T4 b = g0[0], c = g1[0];
+#ifdef NB_WALK_TIMING
+  long long tw0 = wall_clock64(), t_leaf = 0, t_node = 0, n_leaf = 0, n_node = 0;
+#endif
   while (i < n_nodes) {
+#ifdef NB_WALK_TIMING
+    const long long ts = wall_clock64();
+    const bool was_leaf = l.w != 0;
+#endif
     int4 ln = l;
     T4 bn = b, cn = c;
     if constexpr (PREFETCH) {  // speculative: node i+1
@@ -230,8 +237,20 @@ __global__ __launch_bounds__(256) void tree_walk_wave(const WalkArgs<T> a) {
       l = lk[next]; b = g0[next]; c = g1[next];
     }
     i = next;
+#ifdef NB_WALK_TIMING
+    { const long long te = wall_clock64(); if (was_leaf) { t_leaf += te - ts; ++n_leaf; } else { t_node += te - ts; ++n_node; } }
+#endif
   }
   if (live) reinterpret_cast<T2*>(a.acc)[row] = T2{ax, ay};
+#ifdef NB_WALK_TIMING
+  if (a.stats && (threadIdx.x & 63) == 0) {  // timing build: [0] longest wave (10 ns ticks) << 20 | its leaf steps, ...
+    const unsigned long long tot = (unsigned long long)(wall_clock64() - tw0);
+    atomicMax(&a.stats[0], (tot << 40) | ((unsigned long long)t_leaf << 20) | (unsigned long long)t_node);
+    atomicMax(&a.stats[1], (tot << 40) | ((unsigned long long)n_leaf << 20) | (unsigned long long)n_node);
+    atomicAdd(&a.stats[2], tot);
+  }
+  return;
+#endif
   if (a.stats && live) {
     atomicAdd(&a.stats[0], visits);
     atomicAdd(&a.stats[1], accepted);

@@ -1,0 +1,218 @@
+// The Barnes-Hut walk in three passes — same nodes, same pairs, same operations, same order of additions as the fused
+// walk (tree_kernels.hip) and the CPU recursion (/root/reference src/main.rs:348-386), so still bit-identical — for
+// trees with big leaves (the BVH: up to 64 particles per leaf), f32.
+//
+// Why: in the fused walk a wave that reaches a leaf evaluates the leaf's particles one after the other for all of
+// its lanes at once, ~56 instructions per particle (two IEEE divisions) whether 3 or 60 lanes take part; the targets
+// near the reference scene's heavy bodies visit 20x the median number of leaves, their waves run 1.2 ms while most of
+// the chip idles.  The only thing that has to be sequential is the ADDITION of a target's terms; their values do not
+// depend on one another.  So:
+//   1. walk_count: the traversal alone (node tests, no arithmetic): how many terms does each target have;
+//      an exclusive scan turns the counts into offsets into one big term array (HBM is 288 GB: ~250 MB here);
+//   2. walk_terms: the traversal again; an accepted node writes its term; at a leaf the wave takes its acting lanes
+//      one at a time and all 64 lanes evaluate that target against 64 particles of the leaf at once (lane = particle),
+//      so the cost of a leaf step is proportional to the lanes that want it, and nothing is summed;
+//      a pair the reference skips (|dx|+|dy| not normal, main.rs:241-243) writes -0.0, the identity of IEEE addition;
+//   3. walk_sum: per target, the terms are added in order from +0.0 — one v_add_f32_dpp per term and coordinate, a row of
+//      16 lanes per target.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+#include <stdint.h>
+
+#include "walk_split.h"
+
+namespace nbody {
+
+namespace {
+
+constexpr int kTPW = 32;  // targets per wave in the two traversals (the other lanes only help at the leaves)
+
+__device__ __forceinline__ float lane_f(float v, int k) {  // k uniform
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), k));
+}
+
+// calculate_gravity (main.rs:234-253) up to, but not including, the `+=`
+__device__ __forceinline__ float2 pair_term(float px, float py, float qx, float qy, float force, float clamp) {
+  const float dx = qx - px;                                        // :236
+  const float dy = qy - py;
+  const float sum = __builtin_fabsf(dx) + __builtin_fabsf(dy);     // :238
+  if (!__builtin_isnormal(sum)) return make_float2(-0.0f, -0.0f);  // :241-243: no addition at all == adding -0.0
+  float distance = dx * dx + dy * dy;                              // :245
+  if (distance < clamp) distance = clamp;                          // :247-249
+  const float den = sum * distance;
+  return make_float2((dx * force) / den, (dy * force) / den);      // :252
+}
+
+// The traversal both passes share.  F: what to do with an accepted node / a leaf.
+template <bool EMIT>
+__global__ __launch_bounds__(256) void walk_pass(const WalkArgs<float> a, uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off,
+                                                 float2* __restrict__ terms, const int* __restrict__ info, int64_t capacity) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t t = wave * kTPW + lane;
+  const bool live = lane < kTPW && t < a.n_tgt;
+  if (EMIT && (info[1] != 0)) return;  // the term array is too small: the caller grows it
+  const int64_t row = live ? (a.tgt_index ? (int64_t)a.tgt_index[t] : t) : 0;
+  const float2 p = live ? reinterpret_cast<const float2*>(a.tgt_pos)[row] : make_float2(0.f, 0.f);
+  const float4* __restrict__ g0 = reinterpret_cast<const float4*>(a.geom0);
+  const float4* __restrict__ g1 = reinterpret_cast<const float4*>(a.geom1);
+  const int4* __restrict__ lk = reinterpret_cast<const int4*>(a.link);
+  const float2* __restrict__ lpos = reinterpret_cast<const float2*>(a.leaf_pos);
+  const float* __restrict__ lmass = a.leaf_mass;
+  const float theta = a.theta, clamp = a.clamp;
+  const int n_nodes = a.n_nodes;
+  int resume = live ? 0 : n_nodes;
+  uint32_t n_terms = 0;                       // terms of this lane's target so far
+  const uint32_t base = (EMIT && live) ? off[t] : 0u;
+  int i = 0;
+  while (i < n_nodes) {  // i is wave-uniform
+    const int4 l = lk[i];
+    const bool act = resume <= i;
+    int next;
+    if (l.w) {  // Leaf arm, main.rs:351-363: every particle of the slice, in slice order
+      if (EMIT) {
+        unsigned long long mask = __builtin_amdgcn_ballot_w64(act);
+        for (int k0 = 0; k0 < l.z; k0 += 64) {  // 64 particles at a time, lane = particle
+          const int mine = k0 + lane;
+          float2 q = make_float2(0.f, 0.f);
+          float m = 0.f;
+          if (mine < l.z) {
+            q = lpos[l.y + mine];
+            m = lmass[l.y + mine];
+          }
+          unsigned long long todo = mask;
+          while (todo) {  // one acting target after the other
+            const int tl = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const float tx = lane_f(p.x, tl), ty = lane_f(p.y, tl);
+            const uint32_t dst = (uint32_t)__builtin_amdgcn_readlane((int)(base + n_terms), tl) + (uint32_t)k0;
+            if (mine < l.z) terms[dst + lane] = pair_term(tx, ty, q.x, q.y, m, clamp);
+          }
+        }
+      }
+      if (act) {
+        n_terms += (uint32_t)l.z;
+        resume = l.x;
+      }
+      next = l.x;
+    } else {
+      const float4 b = g0[i];  // lo.x lo.y hi.x hi.y
+      const float4 c = g1[i];  // cog.x cog.y mass s2
+      bool descend = false;
+      if (act) {
+        const bool contains = p.y > b.y && p.x > b.x && p.x < b.z && p.y < b.w;  // bvh_tree.rs:15-20 (all strict)
+        const float ddx = p.x - c.x, ddy = p.y - c.y;                              // dist2(p, cog), main.rs:228-232
+        const float d2 = ddx * ddx + ddy * ddy;
+        if (!contains && c.w < d2 * theta * theta) {                               // :370-372
+          if (EMIT) terms[base + n_terms] = pair_term(p.x, p.y, c.x, c.y, c.z, clamp);  // :374-379
+          ++n_terms;
+          resume = l.x;
+        } else {
+          descend = true;                                                          // :381-382
+          resume = i + 1;
+        }
+      }
+      next = __builtin_amdgcn_ballot_w64(descend) != 0 ? i + 1 : l.x;
+    }
+    i = __builtin_amdgcn_readfirstlane(next);
+  }
+  if (!EMIT && live) cnt[t] = n_terms;
+}
+
+// total = off[n-1] + cnt[n-1]; flag what does not fit
+__global__ void walk_total(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off, int64_t n, int64_t capacity,
+                           int* __restrict__ info) {
+  const unsigned long long total = n > 0 ? (unsigned long long)off[n - 1] + cnt[n - 1] : 0ull;
+  // (the scan is 32 bits wide: walk_check_wrap has flagged a wrapped sum already)
+  info[0] = (int)(total > 0x7fffffffull ? 0x7fffffffull : total);
+  if (total > (unsigned long long)capacity) info[1] = 1;
+}
+__global__ __launch_bounds__(256) void walk_check_wrap(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off, int64_t n,
+                                                       int* __restrict__ info) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i + 1 < n && (unsigned long long)off[i] + cnt[i] != (unsigned long long)off[i + 1]) {  // the 32-bit scan wrapped
+    info[1] = 1;
+    info[2] = 1;
+  }
+}
+
+template <int K> __device__ __forceinline__ void add_row_lane(float& s, float v) {
+  asm volatile("v_add_f32_dpp %0, %1, %0 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(s) : "v"(v), "n"(K));
+}
+
+// acc[target] = ((+0 + t0) + t1) + ... in order; a row of 16 lanes per target, 16 terms per round.
+__global__ __launch_bounds__(256) void walk_sum(const WalkArgs<float> a, const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off,
+                                                const float2* __restrict__ terms, const int* __restrict__ info) {
+  if (info[1] != 0) return;
+  const int lane = threadIdx.x & 63, sub = lane & 15;
+  const int64_t t = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
+  const bool live = t < a.n_tgt;
+  const uint32_t n = live ? cnt[t] : 0u;
+  const uint32_t base = live ? off[t] : 0u;
+  uint32_t nmax = n;  // the wave runs as long as its longest target
+  for (int d = 32; d >= 16; d >>= 1) {
+    const uint32_t o = (uint32_t)__shfl_xor((int)nmax, d, 64);
+    nmax = o > nmax ? o : nmax;
+  }
+  float sx = 0.f, sy = 0.f;  // Vec2::zero(), main.rs:409
+  float2 q = make_float2(-0.0f, -0.0f);
+  if ((uint32_t)sub < n) q = terms[base + sub];
+  for (uint32_t p = 0; p < nmax; p += 16) {
+    float2 nq = make_float2(-0.0f, -0.0f);  // past the end: the identity of addition
+    if (p + 16 + sub < n) nq = terms[base + p + 16 + sub];
+    asm volatile("s_nop 1" ::: "memory");  // q may come from a VALU move: 2 wait states before a DPP read
+#define NB_ADD(K) add_row_lane<K>(sx, q.x); add_row_lane<K>(sy, q.y);
+    NB_ADD(0) NB_ADD(1) NB_ADD(2) NB_ADD(3) NB_ADD(4) NB_ADD(5) NB_ADD(6) NB_ADD(7)
+    NB_ADD(8) NB_ADD(9) NB_ADD(10) NB_ADD(11) NB_ADD(12) NB_ADD(13) NB_ADD(14) NB_ADD(15)
+#undef NB_ADD
+    q = nq;
+  }
+  if (live && sub == 0) {
+    const int64_t row = a.tgt_index ? (int64_t)a.tgt_index[t] : t;
+    reinterpret_cast<float2*>(a.acc)[row] = make_float2(sx, sy);
+  }
+}
+
+inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
+
+}  // namespace
+
+WalkSplitLayout walk_split_layout(int64_t n_tgt) {
+  WalkSplitLayout L{};
+  const size_t n = (size_t)(n_tgt > 0 ? n_tgt : 1);
+  size_t o = 0;
+  auto take = [&](size_t b) { size_t r = o; o += align_up(b); return r; };
+  L.cnt = take(4 * n);
+  L.off = take(4 * n);
+  L.info = take(16);
+  size_t tb = 0;
+  (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tb, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)n, (hipStream_t) nullptr);
+  L.cub_temp_bytes = tb;
+  L.cub_temp = take(tb);
+  L.total = o;
+  return L;
+}
+
+hipError_t launch_tree_walk_split(hipStream_t s, const WalkArgs<float>& a, char* scratch, const WalkSplitLayout& L, void* terms,
+                                  int64_t term_capacity) {
+  if (a.n_tgt <= 0) return hipSuccess;
+  uint32_t* cnt = (uint32_t*)(scratch + L.cnt);
+  uint32_t* off = (uint32_t*)(scratch + L.off);
+  int* info = (int*)(scratch + L.info);
+  const int64_t waves = (a.n_tgt + kTPW - 1) / kTPW;
+  const dim3 gw((unsigned)((waves + 3) / 4));
+  hipError_t e = hipMemsetAsync(info, 0, 16, s);
+  if (e != hipSuccess) return e;
+  walk_pass<false><<<gw, dim3(256), 0, s>>>(a, cnt, nullptr, nullptr, info, term_capacity);
+  size_t tb = L.cub_temp_bytes;
+  e = hipcub::DeviceScan::ExclusiveSum((void*)(scratch + L.cub_temp), tb, (const uint32_t*)cnt, off, (int)a.n_tgt, s);
+  if (e != hipSuccess) return e;
+  walk_check_wrap<<<dim3((unsigned)((a.n_tgt + 255) / 256)), dim3(256), 0, s>>>(cnt, off, a.n_tgt, info);
+  walk_total<<<dim3(1), dim3(1), 0, s>>>(cnt, off, a.n_tgt, term_capacity, info);
+  walk_pass<true><<<gw, dim3(256), 0, s>>>(a, cnt, off, (float2*)terms, info, term_capacity);
+  const int64_t sum_waves = (a.n_tgt + 3) / 4;
+  walk_sum<<<dim3((unsigned)((sum_waves + 3) / 4)), dim3(256), 0, s>>>(a, cnt, off, (const float2*)terms, info);
+  return hipGetLastError();
+}
+
+}  // namespace nbody
