@@ -780,7 +780,7 @@ int tree_walk_phase(nbody_ctx* c, State<T>& s, int kind, const void* tgt_pos, in
     const int mode = env_int("NBODY_WALK_SPLIT", 1);
     const bool eligible = w.big_leaves && !w.fast && !w.stats && w.n_tgt > 0 && w.n_nodes > 0 && env_int("NBODY_WALK_PER_THREAD", 0) == 0;
     if (eligible && mode != 0 && (mode == 2 || (w.n_tgt >= 4096 && s.ws_backoff == 0))) {
-      const int64_t hard_cap = (int64_t)1 << 29;  // terms: 4 GB; past that the fused walk
+      const int64_t hard_cap = ((int64_t)1 << 31) - 65536;  // terms (16 GB; the offsets are 32 bits wide); past that the fused walk
       const WalkSplitLayout L = walk_split_layout(w.n_tgt);
       if (s.ws_scratch_bytes < L.total) {
         free_dev(s.ws_scratch);
@@ -796,6 +796,9 @@ int tree_walk_phase(nbody_ctx* c, State<T>& s, int kind, const void* tgt_pos, in
         }
         HIPCHK(c, hipMemcpyAsync(info, s.ws_scratch + L.info, sizeof(info), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (env_int("NBODY_TRACE", 0) != 0)
+          std::fprintf(stderr, "[nbody] split walk: %d terms, overflow %d, longest term-pass wave %d us (leaf %d us, node %d us)\n", info[0], info[1],
+                       info[3] >> 20, (info[3] >> 10) & 1023, info[3] & 1023);
         if (info[1] == 0) {
           done = true;
         } else if (info[2] != 0 || info[0] > hard_cap) {

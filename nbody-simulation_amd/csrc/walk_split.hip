@@ -25,7 +25,10 @@ namespace nbody {
 
 namespace {
 
-constexpr int kTPW = 32;  // targets per wave in the two traversals (the other lanes only help at the leaves)
+// Targets per wave.  Counting is cheapest with full waves; in the term pass a wave's time grows with the number of
+// leaves the union of its targets visits, so fewer targets per wave (the other lanes only help at the leaves)
+// shorten the longest wave.
+constexpr int kCountTPW = 64, kTermTPW = 8;
 
 __device__ __forceinline__ float lane_f(float v, int k) {  // k uniform
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), k));
@@ -44,7 +47,7 @@ __device__ __forceinline__ float2 pair_term(float px, float py, float qx, float 
 }
 
 // The traversal both passes share.  F: what to do with an accepted node / a leaf.
-template <bool EMIT>
+template <bool EMIT, int kTPW>
 __global__ __launch_bounds__(256) void walk_pass(const WalkArgs<float> a, uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off,
                                                  float2* __restrict__ terms, const int* __restrict__ info, int64_t capacity) {
   const int lane = threadIdx.x & 63;
@@ -65,7 +68,13 @@ __global__ __launch_bounds__(256) void walk_pass(const WalkArgs<float> a, uint32
   uint32_t n_terms = 0;                       // terms of this lane's target so far
   const uint32_t base = (EMIT && live) ? off[t] : 0u;
   int i = 0;
+#ifdef NB_WALK_TIMING
+  long long tw0 = wall_clock64(), t_leaf = 0, t_node = 0;
+#endif
   while (i < n_nodes) {  // i is wave-uniform
+#ifdef NB_WALK_TIMING
+    const long long ts = wall_clock64();
+#endif
     const int4 l = lk[i];
     const bool act = resume <= i;
     int next;
@@ -115,7 +124,16 @@ __global__ __launch_bounds__(256) void walk_pass(const WalkArgs<float> a, uint32
       next = __builtin_amdgcn_ballot_w64(descend) != 0 ? i + 1 : l.x;
     }
     i = __builtin_amdgcn_readfirstlane(next);
+#ifdef NB_WALK_TIMING
+    if (l.w) t_leaf += wall_clock64() - ts; else t_node += wall_clock64() - ts;
+#endif
   }
+#ifdef NB_WALK_TIMING
+  if (EMIT && lane == 0) {  // longest wave: total us << 20 | leaf us << 10 | node us
+    const long long tot = wall_clock64() - tw0;
+    atomicMax(const_cast<int*>(info) + 3, (int)(((tot / 100) << 20) | (((t_leaf / 100) & 1023) << 10) | ((t_node / 100) & 1023)));
+  }
+#endif
   if (!EMIT && live) cnt[t] = n_terms;
 }
 
@@ -155,17 +173,24 @@ __global__ __launch_bounds__(256) void walk_sum(const WalkArgs<float> a, const u
     nmax = o > nmax ? o : nmax;
   }
   float sx = 0.f, sy = 0.f;  // Vec2::zero(), main.rs:409
-  float2 q = make_float2(-0.0f, -0.0f);
-  if ((uint32_t)sub < n) q = terms[base + sub];
-  for (uint32_t p = 0; p < nmax; p += 16) {
-    float2 nq = make_float2(-0.0f, -0.0f);  // past the end: the identity of addition
-    if (p + 16 + sub < n) nq = terms[base + p + 16 + sub];
+  // 256 terms per round: sixteen loads in flight per lane, then 512 dependent adds (16 terms add in ~0.06 us, a
+  // load takes ~2 us: the longest target, not the bandwidth, sets this kernel's time)
+  constexpr int R = 16;
+  for (uint32_t p = 0; p < nmax; p += 16 * R) {
+    float2 q[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      const uint32_t k = p + 16u * j + (uint32_t)sub;
+      q[j] = k < n ? terms[base + k] : make_float2(-0.0f, -0.0f);  // past the end: the identity of addition
+    }
     asm volatile("s_nop 1" ::: "memory");  // q may come from a VALU move: 2 wait states before a DPP read
-#define NB_ADD(K) add_row_lane<K>(sx, q.x); add_row_lane<K>(sy, q.y);
-    NB_ADD(0) NB_ADD(1) NB_ADD(2) NB_ADD(3) NB_ADD(4) NB_ADD(5) NB_ADD(6) NB_ADD(7)
-    NB_ADD(8) NB_ADD(9) NB_ADD(10) NB_ADD(11) NB_ADD(12) NB_ADD(13) NB_ADD(14) NB_ADD(15)
+#define NB_ADD(K) add_row_lane<K>(sx, q[j].x); add_row_lane<K>(sy, q[j].y);
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      NB_ADD(0) NB_ADD(1) NB_ADD(2) NB_ADD(3) NB_ADD(4) NB_ADD(5) NB_ADD(6) NB_ADD(7)
+      NB_ADD(8) NB_ADD(9) NB_ADD(10) NB_ADD(11) NB_ADD(12) NB_ADD(13) NB_ADD(14) NB_ADD(15)
+    }
 #undef NB_ADD
-    q = nq;
   }
   if (live && sub == 0) {
     const int64_t row = a.tgt_index ? (int64_t)a.tgt_index[t] : t;
@@ -199,17 +224,16 @@ hipError_t launch_tree_walk_split(hipStream_t s, const WalkArgs<float>& a, char*
   uint32_t* cnt = (uint32_t*)(scratch + L.cnt);
   uint32_t* off = (uint32_t*)(scratch + L.off);
   int* info = (int*)(scratch + L.info);
-  const int64_t waves = (a.n_tgt + kTPW - 1) / kTPW;
-  const dim3 gw((unsigned)((waves + 3) / 4));
+  const int64_t cwaves = (a.n_tgt + kCountTPW - 1) / kCountTPW, twaves = (a.n_tgt + kTermTPW - 1) / kTermTPW;
   hipError_t e = hipMemsetAsync(info, 0, 16, s);
   if (e != hipSuccess) return e;
-  walk_pass<false><<<gw, dim3(256), 0, s>>>(a, cnt, nullptr, nullptr, info, term_capacity);
+  walk_pass<false, kCountTPW><<<dim3((unsigned)((cwaves + 3) / 4)), dim3(256), 0, s>>>(a, cnt, nullptr, nullptr, info, term_capacity);
   size_t tb = L.cub_temp_bytes;
   e = hipcub::DeviceScan::ExclusiveSum((void*)(scratch + L.cub_temp), tb, (const uint32_t*)cnt, off, (int)a.n_tgt, s);
   if (e != hipSuccess) return e;
   walk_check_wrap<<<dim3((unsigned)((a.n_tgt + 255) / 256)), dim3(256), 0, s>>>(cnt, off, a.n_tgt, info);
   walk_total<<<dim3(1), dim3(1), 0, s>>>(cnt, off, a.n_tgt, term_capacity, info);
-  walk_pass<true><<<gw, dim3(256), 0, s>>>(a, cnt, off, (float2*)terms, info, term_capacity);
+  walk_pass<true, kTermTPW><<<dim3((unsigned)((twaves + 3) / 4)), dim3(256), 0, s>>>(a, cnt, off, (float2*)terms, info, term_capacity);
   const int64_t sum_waves = (a.n_tgt + 3) / 4;
   walk_sum<<<dim3((unsigned)((sum_waves + 3) / 4)), dim3(256), 0, s>>>(a, cnt, off, (const float2*)terms, info);
   return hipGetLastError();

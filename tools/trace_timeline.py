@@ -9,7 +9,7 @@ a, b = idx[which], idx[which + 1]
 t0 = int(rows[a]['Start_Timestamp'])
 for r in rows[a:b]:
     n = r['Kernel_Name']
-    m = re.search(r'(bvh_\w+|tree_walk_wave|gather_particles|integrate_inplace|copyBuffer|fillBuffer|radix_sort\w*|merge_sort\w*|transform)', n)
+    m = re.search(r'(bvh_\w+|tree_walk_wave|walk_\w+|DeviceScan\w*|scan\w*|gather_particles|integrate_inplace|copyBuffer|fillBuffer|radix_sort\w*|merge_sort\w*|transform)', n)
     short = m.group(1) if m else n[:30]
     s, e = int(r['Start_Timestamp']), int(r['End_Timestamp'])
     print(f"{(s - t0) / 1e3:9.1f} us  dur {(e - s) / 1e3:8.1f} us  grid {r.get('Grid_Size_X', '?'):>8} {short}")
