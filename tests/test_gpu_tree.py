@@ -376,3 +376,55 @@ def test_device_bvh_build_with_long_nodes_left_after_the_blind_levels(nb, orc, c
             assert np.array_equal(t[k], getattr(o, k)), (name, k)
         assert np.array_equal(t["geom"], o.geom, equal_nan=True), name
         assert np.array_equal(t["order"], o.ids), name
+
+
+# ------------------------------------------------------------------ split walk (walk_split.hip)
+@pytest.mark.parametrize("mode", ["0", "2"])
+def test_split_and_fused_walks_are_the_same_walk(nb, orc, ctx, monkeypatch, mode):
+    """count / emit / ordered-sum (NBODY_WALK_SPLIT=2) and the fused wave walk (=0) against the CPU recursion: the
+    same nodes, pairs, operations and order of additions, so the same bits — targets = the particles (tree order), a
+    strided subset of arbitrary targets, coincident and out-of-box targets, several thetas."""
+    C = nb._capi
+    monkeypatch.setenv("NBODY_WALK_SPLIT", mode)
+    pos, vel, w = nb.scenes.galaxy()
+    pos, vel, w = pos[::3].copy(), vel[::3].copy(), w[::3].copy()
+    pos[100] = pos[101]                                    # a pair the reference skips (sum == 0)
+    bvh = orc.BVH(pos, w)
+    extra = np.array([[-5e4, 2e5], [6e4, 6e4], [0, 0], [1e9, -1e9]], F32)
+    for theta in (50.0, 2.0):
+        ctx.set_params(theta=theta, leaf_size=64, order=C.ORDER_CONSISTENT)
+        ctx.upload(pos, vel, w)
+        assert np.array_equal(ctx.accel_tree(C.TREE_BVH), bvh.walk(bvh.flat().pos_perm, theta=theta, nthreads=8))
+        tg = np.concatenate([pos[::7], extra])
+        ctx.upload(pos, vel, w)                            # a build permutes the rows, and the tree depends on their order
+        assert np.array_equal(ctx.accel_tree(C.TREE_BVH, tg), bvh.walk(tg, theta=theta, nthreads=8))
+
+
+def test_split_walk_steps_equal_fused_walk_steps(nb, monkeypatch):
+    pos, vel, w = nb.scenes.galaxy()
+    res = []
+    for mode in ("0", "2"):
+        monkeypatch.setenv("NBODY_WALK_SPLIT", mode)
+        world = nb.World(pos, vel, w, method="bvh")
+        cnt = nb.Counting()
+        for _ in range(5):
+            world.update(0.1, cnt)
+        res.append(world.particles())
+        world.close()
+    for a, b in zip(*res):
+        assert np.array_equal(a, b)
+
+
+def test_split_walk_backs_off_when_the_terms_do_not_fit(nb, monkeypatch):
+    """N = 2^21 on the reference's needle-box BVH needs more terms than 32-bit offsets hold: the step must fall back to
+    the fused walk and give the same accelerations as with the split walk switched off."""
+    C = nb._capi
+    pos, vel, w = nb.scenes.plummer(1 << 21, seed=0x5EED0009)
+    out = []
+    for mode in ("1", "0"):
+        monkeypatch.setenv("NBODY_WALK_SPLIT", mode)
+        with C.Context(0) as c:
+            c.set_params(theta=50.0)
+            c.upload(pos, vel, w)
+            out.append(c.accel_tree(C.TREE_BVH))
+    assert np.array_equal(out[0], out[1])
