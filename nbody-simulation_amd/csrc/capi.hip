@@ -809,7 +809,12 @@ int tree_walk_phase(nbody_ctx* c, State<T>& s, int kind, const void* tgt_pos, in
           s.ws_capacity = 0;
           int64_t want = (int64_t)info[0] + info[0] / 2 + 4096;
           if (want > hard_cap) want = hard_cap;
-          HIPCHK(c, hipMalloc(&s.ws_terms, (size_t)want * sizeof(float2)));
+          if (hipMalloc(&s.ws_terms, (size_t)want * sizeof(float2)) != hipSuccess) {  // no room: the fused walk needs none
+            (void)hipGetLastError();
+            s.ws_terms = nullptr;
+            s.ws_backoff = 64;
+            break;
+          }
           s.ws_capacity = want;
         }
       }

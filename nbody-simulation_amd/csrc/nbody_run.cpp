@@ -1,7 +1,9 @@
 // Headless driver: the reference's scene (World::new, /root/reference src/main.rs:276-346, with a seeded
 // generator: the reference's own is unseeded) stepped through the C ABI, printing the reference's once-a-second
-// block (ups / step / Counting, main.rs:149-156).  The window, renderer and channel of the reference are out of scope.
-//   nbody_run [steps=100] [bvh|quad|direct] [seed]
+// block (ups / step / Counting, main.rs:149-156).  The window and the channel of the reference are out of scope; the frame
+// its render thread paints (draw, main.rs:41-72) can be written out instead of shown.
+//   nbody_run [steps=100] [bvh|quad|direct] [seed] [frame_every=0] [frame_prefix=frame]
+// frame_every = k > 0: every k-th step <frame_prefix>_<step>.pam (1250 x 1250 RGBA, Netpbm PAM) is written.
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -52,6 +54,9 @@ int main(int argc, char** argv) {
   if (argc > 2 && !std::strcmp(argv[2], "quad")) method = Method::Quad;
   if (argc > 2 && !std::strcmp(argv[2], "direct")) method = Method::Direct;
   uint64_t seed = argc > 3 ? std::strtoull(argv[3], nullptr, 0) : 0xC0FFEEull;
+  const int frame_every = argc > 4 ? std::atoi(argv[4]) : 0;
+  const char* frame_prefix = argc > 5 ? argv[5] : "frame";
+  std::vector<uint8_t> frame;
   try {
     World world(scene(seed), method);
     std::printf("len: %zu\n", world.particles.size());                // main.rs:343
@@ -61,6 +66,16 @@ int main(int argc, char** argv) {
     for (int s = 0; s < steps; ++s) {
       world.update(0.1f, counter);                                    // main.rs:120 (STEP_SIZE)
       ++updates;
+      if (frame_every > 0 && updates % frame_every == 0) {
+        world.draw(frame);
+        char path[512];
+        std::snprintf(path, sizeof(path), "%s_%06ld.pam", frame_prefix, updates);
+        if (FILE* f = std::fopen(path, "wb")) {
+          std::fprintf(f, "P7\nWIDTH 1250\nHEIGHT 1250\nDEPTH 4\nMAXVAL 255\nTUPLTYPE RGB_ALPHA\nENDHDR\n");
+          std::fwrite(frame.data(), 1, frame.size(), f);
+          std::fclose(f);
+        }
+      }
       auto now = std::chrono::steady_clock::now();
       if (std::chrono::duration<double>(now - t0).count() >= 1.0 || s + 1 == steps) {
         std::printf("ups: %ld\nstep: %ld\nCounting { build_bvh: %.6f, sum_gravity: %.6f, post_calculations: %.6f }\n",

@@ -67,6 +67,12 @@ class World {
     return particles;
   }
 
+  // draw(&particles, frame), main.rs:41-72: the render_px x render_px RGBA frame of the current particles.
+  void draw(std::vector<uint8_t>& frame, uint32_t height = 100000, uint32_t render_px = 1250) {
+    frame.resize((size_t)render_px * render_px * 4);
+    check(nbody_render_rgba(ctx_, height, render_px, frame.data()), "nbody_render_rgba");
+  }
+
  private:
   void check(int rc, const char* what) {
     if (rc != NBODY_OK) throw std::runtime_error(std::string(what) + ": " + nbody_last_error(ctx_));

@@ -66,5 +66,25 @@ class World:
         uint8 array (render_px, render_px, 4), RGBA."""
         return self.ctx.render(height, render_px)
 
+    def save_frame(self, path, height=100_000, render_px=1250):
+        """Write the frame as an RGBA PNG (what the reference shows in its window)."""
+        write_png(path, self.frame(height, render_px))
+
     def close(self):
         self.ctx.close()
+
+
+def write_png(path, rgba):
+    """Minimal PNG writer (8-bit RGBA, zlib only)."""
+    import struct
+    import zlib
+    rgba = np.ascontiguousarray(rgba, dtype=np.uint8)
+    h, w, _ = rgba.shape
+    raw = np.concatenate([np.zeros((h, 1), np.uint8), rgba.reshape(h, w * 4)], axis=1).tobytes()   # filter 0 per row
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 6, 0, 0, 0)) +
+                chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b""))

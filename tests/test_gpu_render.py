@@ -87,3 +87,44 @@ def test_snapshot_is_the_state_at_begin_even_if_steps_follow(nb, method, dtype):
     finally:
         world.close()
         ref.close()
+
+
+def test_headless_driver_writes_the_frames_the_window_would_show(nb, orc, tmp_path):
+    """nbody_run ... frame_every prefix: PAM files of draw() every k steps; the last one equals the oracle's draw() of a
+    Python run of the same (seeded) scene would need the C++ generator, so check structure + content sanity here and
+    the PNG writer against the frame it was given."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(nb._capi.LIB_PATH), "nbody_run")
+    if not os.path.exists(exe):
+        pytest.skip("nbody_run not built")
+    prefix = str(tmp_path / "f")
+    r = subprocess.run([exe, "4", "bvh", "777", "2", prefix], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    for step in (2, 4):
+        raw = open(f"{prefix}_{step:06d}.pam", "rb").read()
+        head, body = raw.split(b"ENDHDR\n", 1)
+        assert head.startswith(b"P7\nWIDTH 1250\nHEIGHT 1250\nDEPTH 4\nMAXVAL 255\nTUPLTYPE RGB_ALPHA")
+        f = np.frombuffer(body, np.uint8).reshape(1250, 1250, 4)
+        heavy = (f[..., 0] == 0) & (f[..., 1] == 255) & (f[..., 3] == 255)
+        assert heavy.sum() == 2                                   # the two heavy bodies, green
+        assert (f[..., 3] > 0).sum() > 20000                      # the disc and the cloud
+    # Python side: PNG of a frame
+    pos, vel, w = nb.scenes.plummer(5000, seed=3)
+    world = nb.World(pos, vel, w, method="direct")
+    try:
+        path = str(tmp_path / "frame.png")
+        world.save_frame(path)
+        import struct
+        import zlib
+        d = open(path, "rb").read()
+        i, idat = 8, b""
+        while i < len(d):
+            n = struct.unpack(">I", d[i:i + 4])[0]
+            if d[i + 4:i + 8] == b"IDAT":
+                idat += d[i + 8:i + 8 + n]
+            i += 12 + n
+        rows = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(1250, 1 + 1250 * 4)
+        assert np.array_equal(rows[:, 1:].reshape(1250, 1250, 4), orc.draw(pos, vel, w))
+    finally:
+        world.close()
