@@ -280,7 +280,7 @@ def _bvh_scenes(nb):
     return out
 
 
-@pytest.mark.parametrize("leaf", [64, 8, 1])
+@pytest.mark.parametrize("leaf", [64, 8, 1, 200, 5000])
 def test_device_bvh_build_equals_oracle_tree(nb, orc, ctx, leaf):
     """The tree built on the device (exact-sum scan, rank-list partition, path-key numbering) is the reference's tree:
     boxes, split order, leaf ranges, permutation, masses and centres of gravity, bit for bit."""
