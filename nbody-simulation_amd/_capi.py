@@ -91,6 +91,7 @@ _SIGS = {
     "nbody_render_rgba": (C.c_int, [_vp, C.c_uint32, C.c_uint32, _vp]),
     "nbody_render_rgba_dev": (C.c_int, [_vp, C.c_int64, C.c_int, _vp, _vp, _vp, C.c_uint32, C.c_uint32, _vp, _vp]),
     "nbody_selftest_exact_sum": (C.c_int, [_vp, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int64)]),
+    "nbody_selftest_exact_sum_chunked": (C.c_int, [_vp, C.c_int64, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int64)]),
     "nbody_bvh_build_restarts": (C.c_int, [_vp]),
     "nbody_last_build_on_device": (C.c_int, [_vp]),
     "nbody_timer_create": (C.c_int, [C.POINTER(_vp)]),
@@ -198,6 +199,14 @@ def selftest_exact_sum(x, tile=4096, seq_run=64):
     check(None, load().nbody_selftest_exact_sum(_ptr(x) if x.size else None, x.size, int(tile), int(seq_run),
                                                 C.byref(out), C.byref(st)))
     return np.float32(out.value), st.value
+
+
+def selftest_exact_sum_chunked(x, chunk=2048):
+    """CPU emulation of the chunked exact sum (predicted binades, runs with bounds) -> (sum, chunks taken whole)."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    out, used = C.c_float(0), _i64(0)
+    check(None, load().nbody_selftest_exact_sum_chunked(_ptr(x) if x.size else None, x.size, int(chunk), C.byref(out), C.byref(used)))
+    return np.float32(out.value), used.value
 
 
 def host_tree(kind, pos, weight=None, params: "Params | None" = None):

@@ -17,13 +17,14 @@ enum : int {
   kBvhStops = 3,      // restarts of the exact-sum scan (diagnostic)
   kBvhSubCount = 4,   // subtree roots queued for bvh_subtrees
   kBvhTopCount = 5,   // nodes made by the long-node levels (they sit above the subtrees)
+  kBvhRunsUsed = 6,   // chunks of long chains whose prepared run was used (diagnostic)
   kBvhDebug = 8,      // 8 words of max-over-groups cycle counts per phase of bvh_subtrees (NB_BVH_TIMING builds)
   kBvhFlagWords = 16,
 };
 
 struct BvhBuildLayout {
   int node_cap, big_cap, chunk_cap;
-  size_t flags, bigcount, chunkcount, zero_end, bigq, subq, topq, ch_node, ch_index, ch_cx, ch_cy, ch_before, pts, ids, lidx, ridx;
+  size_t flags, bigcount, chunkcount, zero_end, bigq, subq, topq, ch_node, ch_index, ch_sum, ch_box, ch_run, ch_cx, ch_cy, ch_before, pts, ids, lidx, ridx;
   size_t nbegin, nlen, nparent, nchild, ndepth, nleaf, nkey, nbox, ncog, nmass, narrive, nmean, nsplit, nchunk0, ndone, nbad;
   size_t keys, keys_sorted, vals, vals_sorted, rank, cub_temp, cub_temp_bytes, total;
 };

@@ -44,6 +44,7 @@ constexpr int kChainStart = 256; // real adds at the start of a long node's chai
 constexpr int kSub = 2048;       // nodes up to this long are built, subtree and all, by one work-group in LDS
 constexpr int kSubWaves = 8;     // waves of a subtree work-group
 constexpr int kChunk = 2048;     // points per work-group in the multi-group passes over a long node
+constexpr int kRunLen = 32768;   // nodes longer than this have their chain prepared chunk by chunk (bvh_chunk_runs)
 constexpr float kMaxF = 3.402823466e+38f;
 
 struct BvhPtrs {
@@ -53,8 +54,11 @@ struct BvhPtrs {
   int* bigq;        // [level & 1][cap_big]
   int* subq;        // subtree roots
   int* topq;        // nodes made by the long-node levels (the ones above the subtrees)
-  int* ch_node;     // chunk -> node
-  int* ch_index;    // chunk -> index inside the node
+  int* ch_node;     // [level & 1][cap_chunk] chunk -> node
+  int* ch_index;    // [level & 1][cap_chunk] chunk -> index inside the node
+  double2* ch_sum;  // exact-ish (f64) sums of the chunk's coordinates: only used to PREDICT binades
+  float4* ch_box;   // min.x min.y max.x max.y of the chunk
+  int* ch_run;      // [chunk][2 coordinates][8]: sign, E (0 = no run), a0, a1, lo0, lo1, hi0, hi1
   int* ch_cx;
   int* ch_cy;
   int* ch_before;   // predicate-true points of the node before the chunk
@@ -91,6 +95,9 @@ BvhPtrs make_ptrs(char* s, const BvhBuildLayout& L) {
   a.topq = (int*)(s + L.topq);
   a.ch_node = (int*)(s + L.ch_node);
   a.ch_index = (int*)(s + L.ch_index);
+  a.ch_sum = (double2*)(s + L.ch_sum);
+  a.ch_box = (float4*)(s + L.ch_box);
+  a.ch_run = (int*)(s + L.ch_run);
   a.ch_cx = (int*)(s + L.ch_cx);
   a.ch_cy = (int*)(s + L.ch_cy);
   a.ch_before = (int*)(s + L.ch_before);
@@ -234,14 +241,15 @@ template <int NW> __device__ __forceinline__ unsigned group_sum(unsigned v, unsi
 // independent chains: they run on different work-groups.
 // EPT: consecutive addends per thread and scan (the scan's fixed cost is per thread: more addends each = cheaper).
 template <int NW, int EPT>
-__device__ __forceinline__ void exact_fold(const float2* P, int len, int comp, int tid, Scratch<NW>* sh, float& out_sum,
-                                           float& out_min, float& out_max, int& stops) {
+__device__ __forceinline__ void exact_fold(const float2* P, int begin, int len, float s_in, int comp, int tid, Scratch<NW>* sh,
+                                           float& out_sum, float& out_min, float& out_max, int& stops) {
+  // the chain over P[begin, len), entered with the running sum s_in (0.0 and begin = 0 for a whole node)
   constexpr int TILE = NW * 64 * EPT;
   const int lane = tid & 63, wave = tid >> 6;
-  float s = 0.f;  // uniform across the group
+  float s = s_in;  // uniform across the group
   float mn = kMaxF, mx = 0.f;
-  int pos = 0;
-  bool seq = true;  // the chain starts at 0.0: not in any binade yet
+  int pos = begin;
+  bool seq = false;  // decided from s: a chain at 0.0 is not in any binade yet
   while (pos < len) {
     xsum::Chain ch;
     if (!seq) seq = !xsum::chain_open(s, ch);
@@ -437,6 +445,10 @@ __global__ __launch_bounds__(256) void bvh_init(BvhPtrs a, const float2* __restr
     a.ID[i] = (uint32_t)i;
     if (p.x != p.x || p.y != p.y) a.flags[kBvhFallback] = 1;
   }
+  if (n > kSub && i < (n + kChunk - 1) / kChunk) {  // the root's chunks
+    a.ch_node[i] = 0;
+    a.ch_index[i] = i;
+  }
   if (i == 0) {  // the top call is unconditional: the root is a Root whatever its length (main.rs:400)
     a.nbegin[0] = 0;
     a.nlen[0] = n;
@@ -453,6 +465,8 @@ __global__ __launch_bounds__(256) void bvh_init(BvhPtrs a, const float2* __restr
     if (n > kSub) {
       a.bigcount[0] = 1;
       a.bigq[0] = 0;
+      a.chunkcount[0] = (n + kChunk - 1) / kChunk;
+      a.nchunk0[0] = 0;
     } else {
       a.flags[kBvhSubCount] = 1;
       a.subq[0] = 0;
@@ -460,9 +474,140 @@ __global__ __launch_bounds__(256) void bvh_init(BvhPtrs a, const float2* __restr
   }
 }
 
+// ---- long nodes, one level: chunk sums and chunk runs (only nodes longer than kRunLen) ------------------------------------
+// A long chain is cut into chunks of kChunk addends.  bvh_chunk_sums: f64 sums (and the box) of every chunk, in parallel;
+// their prefix PREDICTS the binade the chain is in when it reaches a chunk.  bvh_chunk_runs: every chunk's run
+// (exact_sum.h) for that binade, in parallel.  bvh_big_fold then walks the chunks: a run is used iff the true state is in
+// the predicted binade and the run's bounds hold from it; the other chunks (the first one, the ~log2(len / kChunk) in which
+// the sum crosses a power of two, wrong guesses) are added by the scan, as before.
+__global__ __launch_bounds__(256) void bvh_chunk_sums(BvhPtrs a, int level) {
+  __shared__ double red[6][4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nc = a.chunkcount[level];
+  const int* ch_node = a.ch_node + (size_t)(level & 1) * a.cap_chunk;
+  const int* ch_index = a.ch_index + (size_t)(level & 1) * a.cap_chunk;
+  for (int c = blockIdx.x; c < nc; c += gridDim.x) {
+    const int node = ch_node[c], ci = ch_index[c];
+    const int len = a.nlen[node];
+    if (len <= kRunLen) continue;
+    const float2* P = a.P + a.nbegin[node];
+    const int lo = ci * kChunk, hi = lo + kChunk < len ? lo + kChunk : len;
+    double sx = 0.0, sy = 0.0;
+    Box bx;
+    for (int i = lo + tid; i < hi; i += 256) {
+      const float2 q = P[i];
+      sx += (double)q.x;
+      sy += (double)q.y;
+      bx.add(q);
+    }
+    for (int d = 32; d >= 1; d >>= 1) {
+      sx += __shfl_xor(sx, d, 64);
+      sy += __shfl_xor(sy, d, 64);
+    }
+    bx.reduce_wave();
+    if (lane == 0) {
+      red[0][wave] = sx; red[1][wave] = sy;
+      red[2][wave] = bx.mnx; red[3][wave] = bx.mny; red[4][wave] = bx.mxx; red[5][wave] = bx.mxy;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      double tx = 0.0, ty = 0.0;
+      float mnx = kMaxF, mny = kMaxF, mxx = 0.f, mxy = 0.f;
+      for (int w = 0; w < 4; ++w) {
+        tx += red[0][w]; ty += red[1][w];
+        mnx = sse_min(mnx, (float)red[2][w]); mny = sse_min(mny, (float)red[3][w]);
+        mxx = sse_max(mxx, (float)red[4][w]); mxy = sse_max(mxy, (float)red[5][w]);
+      }
+      a.ch_sum[c] = make_double2(tx, ty);
+      a.ch_box[c] = make_float4(mnx, mny, mxx, mxy);
+    }
+    __syncthreads();
+  }
+}
+
+__device__ __forceinline__ xsum::Run shfl_down_run(const xsum::Run& r, int d) {
+  xsum::Run o;
+  for (int p = 0; p < 2; ++p) {
+    o.a[p] = __shfl_down(r.a[p], d, 64);
+    o.lo[p] = __shfl_down(r.lo[p], d, 64);
+    o.hi[p] = __shfl_down(r.hi[p], d, 64);
+  }
+  return o;
+}
+
+__global__ __launch_bounds__(256) void bvh_chunk_runs(BvhPtrs a, int level) {
+  constexpr int PER = kChunk / 256;
+  __shared__ double redd[2][4];
+  __shared__ xsum::Run redr[2][4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nc = a.chunkcount[level];
+  const int* ch_node = a.ch_node + (size_t)(level & 1) * a.cap_chunk;
+  const int* ch_index = a.ch_index + (size_t)(level & 1) * a.cap_chunk;
+  for (int c = blockIdx.x; c < nc; c += gridDim.x) {
+    const int node = ch_node[c], ci = ch_index[c];
+    const int len = a.nlen[node];
+    if (len <= kRunLen) continue;
+    int* rec = a.ch_run + (size_t)c * 16;
+    if (ci == 0) {  // the chain starts here: nothing to predict
+      if (tid == 0) { rec[1] = 0; rec[9] = 0; }
+      continue;
+    }
+    // where the chain should be when it gets here: the f64 sums of the node's chunks before this one
+    const int c0 = c - ci;  // a node's chunks are consecutive
+    double px = 0.0, py = 0.0;
+    for (int i = tid; i < ci; i += 256) {
+      const double2 v = a.ch_sum[c0 + i];
+      px += v.x;
+      py += v.y;
+    }
+    for (int d = 32; d >= 1; d >>= 1) {
+      px += __shfl_xor(px, d, 64);
+      py += __shfl_xor(py, d, 64);
+    }
+    if (lane == 0) { redd[0][wave] = px; redd[1][wave] = py; }
+    __syncthreads();
+    px = redd[0][0] + redd[0][1] + redd[0][2] + redd[0][3];
+    py = redd[1][0] + redd[1][1] + redd[1][2] + redd[1][3];
+    xsum::Chain cx, cy;
+    const bool okx = xsum::chain_open((float)px, cx), oky = xsum::chain_open((float)py, cy);
+    const float2* P = a.P + a.nbegin[node];
+    const int base = ci * kChunk + tid * PER;
+    xsum::Run rx = xsum::run_none(), ry = xsum::run_none();
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      if (base + j < len) {
+        const float2 q = P[base + j];
+        if (okx) rx = xsum::run_then(rx, xsum::run_of(xsum::step_of(q.x, cx.sign, cx.E)));
+        if (oky) ry = xsum::run_then(ry, xsum::run_of(xsum::step_of(q.y, cy.sign, cy.E)));
+      }
+    }
+    for (int d = 1; d < 64; d <<= 1) {  // in order: lane l takes lane l + d behind it
+      const xsum::Run ox = shfl_down_run(rx, d), oy = shfl_down_run(ry, d);
+      if ((lane & (2 * d - 1)) == 0) {
+        rx = xsum::run_then(rx, ox);
+        ry = xsum::run_then(ry, oy);
+      }
+    }
+    if (lane == 0) { redr[0][wave] = rx; redr[1][wave] = ry; }
+    __syncthreads();
+    if (tid < 2) {
+      xsum::Run r = redr[tid][0];
+      for (int w = 1; w < 4; ++w) r = xsum::run_then(r, redr[tid][w]);
+      const xsum::Chain& ch = tid ? cy : cx;
+      int* o = rec + 8 * tid;
+      o[0] = (int)ch.sign;
+      o[1] = (tid ? oky : okx) ? (int)ch.E : 0;
+      o[2] = r.a[0]; o[3] = r.a[1]; o[4] = r.lo[0]; o[5] = r.lo[1]; o[6] = r.hi[0]; o[7] = r.hi[1];
+    }
+    __syncthreads();
+  }
+}
+
 // ---- long nodes, one level: fold ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void bvh_big_fold(BvhPtrs a, int level) {
+__global__ __launch_bounds__(512) void bvh_big_fold(BvhPtrs a, int level, int use_runs) {
+  constexpr int kRecBatch = 512;
   __shared__ Scratch<8> sh;
+  __shared__ int recs[kRecBatch * 8];
   const int tid = threadIdx.x;
   const int comp = blockIdx.y;  // 0: x, 1: y
   const int nq = a.bigcount[level];
@@ -471,29 +616,63 @@ __global__ __launch_bounds__(512) void bvh_big_fold(BvhPtrs a, int level) {
   for (int qi = blockIdx.x; qi < nq; qi += gridDim.x) {
     const int node = queue[qi];
     const int b = a.nbegin[node], len = a.nlen[node];
+    const float2* P = (const float2*)(a.P + b);
     float sum, mn, mx;
-    exact_fold<8, 8>((const float2*)(a.P + b), len, comp, tid, &sh, sum, mn, mx, stops);
+    if (use_runs && len > kRunLen) {
+      const int c0 = a.nchunk0[node], nch = (len + kChunk - 1) / kChunk;
+      sum = 0.f;
+      int used = 0;
+      for (int b0 = 0; b0 < nch; b0 += kRecBatch) {  // the runs of a batch of chunks come to LDS together ...
+        const int nb = nch - b0 < kRecBatch ? nch - b0 : kRecBatch;
+        for (int k = tid; k < nb * 8; k += 512) recs[k] = a.ch_run[(size_t)(c0 + b0 + (k >> 3)) * 16 + 8 * comp + (k & 7)];
+        __syncthreads();
+        for (int ci = b0; ci < b0 + nb; ++ci) {  // ... and the chain walks through them in order
+          const int* rec = recs + (ci - b0) * 8;
+          xsum::Chain ch;
+          bool ok = rec[1] != 0 && xsum::chain_open(sum, ch) && (int)ch.E == rec[1] && (int)ch.sign == rec[0];
+          if (ok) {
+            xsum::Run r;
+            r.a[0] = rec[2]; r.a[1] = rec[3]; r.lo[0] = rec[4]; r.lo[1] = rec[5]; r.hi[0] = rec[6]; r.hi[1] = rec[7];
+            ok = xsum::run_fits(ch.S, r);
+            if (ok) sum = xsum::chain_value(ch, (uint32_t)((int)ch.S + r.a[ch.S & 1u]));
+          }
+          if (!ok) {  // this chunk by the scan, from the true state
+            const int hi = (ci + 1) * kChunk < len ? (ci + 1) * kChunk : len;
+            float dmn, dmx;
+            exact_fold<8, 8>(P, ci * kChunk, hi, sum, comp, tid, &sh, sum, dmn, dmx, stops);
+          } else {
+            ++used;
+          }
+        }
+        __syncthreads();
+      }
+      mn = kMaxF;
+      mx = 0.f;
+      for (int ci = tid; ci < nch; ci += 512) {
+        const float4 bx = a.ch_box[c0 + ci];
+        mn = sse_min(mn, comp ? bx.y : bx.x);
+        mx = sse_max(mx, comp ? bx.w : bx.z);
+      }
+      for (int d = 32; d >= 1; d >>= 1) {
+        mn = sse_min(mn, __shfl_xor(mn, d, 64));
+        mx = sse_max(mx, __shfl_xor(mx, d, 64));
+      }
+      if ((tid & 63) == 0) { sh.redf[0][tid >> 6] = mn; sh.redf[1][tid >> 6] = mx; }
+      __syncthreads();
+      for (int w = 0; w < 8; ++w) {
+        mn = sse_min(mn, sh.redf[0][w]);
+        mx = sse_max(mx, sh.redf[1][w]);
+      }
+      __syncthreads();
+      if (tid == 0 && used) atomicAdd(&a.flags[kBvhRunsUsed], used);
+    } else {
+      exact_fold<8, 8>(P, 0, len, 0.f, comp, tid, &sh, sum, mn, mx, stops);
+    }
     if (tid == 0) {
       float* box = (float*)&a.nbox[node];
       box[comp] = mn;
       box[2 + comp] = mx;
       ((float*)&a.nmean[node])[comp] = sum / (float)len;  // :67
-    }
-    if (comp == 0) {  // the node's chunks for the passes that follow
-      const int nch = (len + kChunk - 1) / kChunk;
-      if (tid == 0) sh.bad = atomicAdd(&a.chunkcount[level], nch);
-      __syncthreads();
-      const int c0 = sh.bad;
-      if (tid == 0) a.nchunk0[node] = c0;
-      if (c0 + nch > a.cap_chunk) {
-        if (tid == 0) a.flags[kBvhFallback] = 1;
-      } else {
-        for (int i = tid; i < nch; i += 512) {
-          a.ch_node[c0 + i] = node;
-          a.ch_index[c0 + i] = i;
-        }
-      }
-      __syncthreads();
     }
   }
   if (tid == 0 && stops) atomicAdd(&a.flags[kBvhStops], stops);
@@ -503,10 +682,13 @@ __global__ __launch_bounds__(512) void bvh_big_fold(BvhPtrs a, int level) {
 __global__ __launch_bounds__(256) void bvh_big_count(BvhPtrs a, int level, int leaf_size) {
   __shared__ unsigned red[2][4];
   __shared__ int last_flag;
+  __shared__ int kid[2], kid_c0[2], kid_n[2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nc = a.chunkcount[level];
+  const int* ch_node = a.ch_node + (size_t)(level & 1) * a.cap_chunk;
+  const int* ch_index = a.ch_index + (size_t)(level & 1) * a.cap_chunk;
   for (int c = blockIdx.x; c < nc; c += gridDim.x) {
-    const int node = a.ch_node[c], ci = a.ch_index[c];
+    const int node = ch_node[c], ci = ch_index[c];
     const int b = a.nbegin[node], len = a.nlen[node];
     const float2 h = a.nmean[node];
     const int lo = ci * kChunk, hi = lo + kChunk < len ? lo + kChunk : len;
@@ -562,6 +744,7 @@ __global__ __launch_bounds__(256) void bvh_big_count(BvhPtrs a, int level, int l
       __syncthreads();
     }
     if (tid == 0) {
+      kid[0] = kid[1] = -1;
       a.nsplit[node] = m | (on_x ? (int)0x80000000 : 0);
       bool leaf[2];
       const int first = alloc_nodes(a, 2);
@@ -577,6 +760,11 @@ __global__ __launch_bounds__(256) void bvh_big_count(BvhPtrs a, int level, int l
             const int slot = atomicAdd(&a.bigcount[level + 1], 1);
             if (slot < a.cap_big) a.bigq[(size_t)((level + 1) & 1) * a.cap_big + slot] = first + side;
             else a.flags[kBvhFallback] = 1;
+            const int cn = (cl + kChunk - 1) / kChunk;  // its chunks for the next level's passes
+            const int cc0 = atomicAdd(&a.chunkcount[level + 1], cn);
+            a.nchunk0[first + side] = cc0;
+            if (cc0 + cn > a.cap_chunk) a.flags[kBvhFallback] = 1;
+            else { kid[side] = first + side; kid_c0[side] = cc0; kid_n[side] = cn; }
           } else {
             const int slot = atomicAdd(&a.flags[kBvhSubCount], 1);
             a.subq[slot] = first + side;  // at most one entry per node: cap entries
@@ -584,6 +772,17 @@ __global__ __launch_bounds__(256) void bvh_big_count(BvhPtrs a, int level, int l
         }
       }
     }
+    __syncthreads();
+    for (int side = 0; side < 2; ++side) {  // chunk -> node tables of the long children, by everybody
+      if (kid[side] < 0) continue;
+      int* tn = a.ch_node + (size_t)((level + 1) & 1) * a.cap_chunk + kid_c0[side];
+      int* ti = a.ch_index + (size_t)((level + 1) & 1) * a.cap_chunk + kid_c0[side];
+      for (int i = tid; i < kid_n[side]; i += 256) {
+        tn[i] = kid[side];
+        ti[i] = i;
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -594,8 +793,10 @@ __global__ __launch_bounds__(256) void bvh_big_ranks(BvhPtrs a, int level) {
   constexpr int PER = kChunk / 256;  // consecutive points per thread
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nc = a.chunkcount[level];
+  const int* ch_node = a.ch_node + (size_t)(level & 1) * a.cap_chunk;
+  const int* ch_index = a.ch_index + (size_t)(level & 1) * a.cap_chunk;
   for (int c = blockIdx.x; c < nc; c += gridDim.x) {
-    const int node = a.ch_node[c], ci = a.ch_index[c];
+    const int node = ch_node[c], ci = ch_index[c];
     const int b = a.nbegin[node], len = a.nlen[node];
     const float2 h = a.nmean[node];
     const int sp = a.nsplit[node];
@@ -643,8 +844,10 @@ __global__ __launch_bounds__(256) void bvh_big_ranks(BvhPtrs a, int level) {
 
 __global__ __launch_bounds__(256) void bvh_big_swap(BvhPtrs a, int level) {
   const int nc = a.chunkcount[level];
+  const int* ch_node = a.ch_node + (size_t)(level & 1) * a.cap_chunk;
+  const int* ch_index = a.ch_index + (size_t)(level & 1) * a.cap_chunk;
   for (int c = blockIdx.x; c < nc; c += gridDim.x) {
-    const int node = a.ch_node[c], ci = a.ch_index[c];
+    const int node = ch_node[c], ci = ch_index[c];
     const int b = a.nbegin[node];
     const int nbad = a.nbad[node];
     float2* P = a.P + b;
@@ -1014,8 +1217,11 @@ BvhBuildLayout bvh_build_layout(int64_t n, int leaf_size) {
   L.bigq = take(4 * 2 * CB);
   L.subq = take(4 * C);
   L.topq = take(4 * C);
-  L.ch_node = take(4 * CC);
-  L.ch_index = take(4 * CC);
+  L.ch_node = take(4 * 2 * CC);
+  L.ch_index = take(4 * 2 * CC);
+  L.ch_sum = take(16 * CC);
+  L.ch_box = take(16 * CC);
+  L.ch_run = take(4 * 16 * CC);
   L.ch_cx = take(4 * CC);
   L.ch_cy = take(4 * CC);
   L.ch_before = take(4 * CC);
@@ -1075,7 +1281,12 @@ hipError_t bvh_build_levels(hipStream_t s, int n, int leaf_size, int level_begin
     int64_t gb = L.big_cap < width ? L.big_cap : width;
     int64_t gc = L.chunk_cap;
     if (gc > 1024) gc = 1024;
-    bvh_big_fold<<<dim3((unsigned)gb, 2), dim3(512), 0, s>>>(a, level);
+    const int use_runs = (n >> level) > kRunLen / 2 ? 1 : 0;  // could a node of this level be longer than kRunLen?
+    if (use_runs) {
+      bvh_chunk_sums<<<dim3((unsigned)gc), dim3(256), 0, s>>>(a, level);
+      bvh_chunk_runs<<<dim3((unsigned)gc), dim3(256), 0, s>>>(a, level);
+    }
+    bvh_big_fold<<<dim3((unsigned)gb, 2), dim3(512), 0, s>>>(a, level, use_runs);
     bvh_big_count<<<dim3((unsigned)gc), dim3(256), 0, s>>>(a, level, leaf_size);
     bvh_big_ranks<<<dim3((unsigned)gc), dim3(256), 0, s>>>(a, level);
     bvh_big_swap<<<dim3((unsigned)gc), dim3(256), 0, s>>>(a, level);

@@ -562,8 +562,8 @@ template <class T> int bvh_build_device(nbody_ctx* c, State<T>& s) {
       if (hostf[kBvhFallback] != 0) return 1;
     }
     if (env_int("NBODY_TRACE", 0) != 0)
-      std::fprintf(stderr, "[nbody] device bvh build: %d nodes, depth %d, %d subtrees, %d long-node levels, %d scan restarts\n",
-                   hostf[kBvhNodeCount], hostf[kBvhMaxDepth], hostf[kBvhSubCount], lv_end, hostf[kBvhStops]);
+      std::fprintf(stderr, "[nbody] device bvh build: %d nodes, depth %d, %d subtrees, %d long-node levels, %d scan restarts, %d prepared chunk runs used\n",
+                   hostf[kBvhNodeCount], hostf[kBvhMaxDepth], hostf[kBvhSubCount], lv_end, hostf[kBvhStops], hostf[kBvhRunsUsed]);
     const int m = hostf[kBvhNodeCount];
     if (m <= 0 || m > L.node_cap) return 1;
     s.cur = 1 - s.cur;
@@ -1444,6 +1444,11 @@ NB_API int nbody_weights_to_mass_dev(void* stream, int64_t n, const void* weight
 NB_API int nbody_selftest_exact_sum(const float* x, int64_t n, int tile, int seq_run, float* out_sum, int64_t* out_restarts) {
   if ((!x && n > 0) || n < 0 || tile < 1 || seq_run < 1 || !out_sum) return NBODY_ERR_INVALID;
   *out_sum = xsum::emulate_fold(x, n, tile, seq_run, out_restarts);
+  return NBODY_OK;
+}
+NB_API int nbody_selftest_exact_sum_chunked(const float* x, int64_t n, int chunk, float* out_sum, int64_t* out_runs_used) {
+  if ((!x && n > 0) || n < 0 || chunk < 1 || !out_sum) return NBODY_ERR_INVALID;
+  *out_sum = xsum::emulate_fold_chunked(x, n, chunk, out_runs_used);
   return NBODY_OK;
 }
 NB_API int nbody_bvh_build_restarts(const nbody_ctx* ctx) { return ctx ? ctx->bvh_stops : 0; }

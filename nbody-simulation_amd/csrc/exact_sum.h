@@ -84,6 +84,42 @@ NB_HD Step compose(Step f, Step g) {
   return h;
 }
 
+// ---- whole runs of addends, so that a long chain can be cut into chunks that are prepared in parallel ------------------
+// A run seen from a chain in one binade: the total increment of S and the extremes of every intermediate S, relative to
+// the S the run starts from, for an even (index 0) / odd (1) start.  If S + lo > 2^23 and S + hi < 2^24 for the actual
+// start, every add of the run stayed in the binade and S + a is the exact result.  Saturating at +-2^30: beyond that a
+// run is unusable anyway (a poison step is 2^30).
+struct Run {
+  int32_t a[2], lo[2], hi[2];
+};
+NB_HD int32_t run_sat(int64_t v) {
+  const int64_t m = (int64_t)1 << 30;
+  return (int32_t)(v > m ? m : (v < -m ? -m : v));
+}
+NB_HD Run run_of(Step f) {
+  Run r;
+  r.a[0] = r.lo[0] = r.hi[0] = (int32_t)f.a0;
+  r.a[1] = r.lo[1] = r.hi[1] = (int32_t)f.a1;
+  return r;
+}
+NB_HD Run run_none() { return Run{{0, 0}, {0, 0}, {0, 0}}; }  // an open chain has S inside the binade: offsets 0 fit
+// f first, then g
+NB_HD Run run_then(const Run& f, const Run& g) {
+  Run h;
+  for (int p = 0; p < 2; ++p) {
+    const int q = (p + f.a[p]) & 1;
+    h.a[p] = run_sat((int64_t)f.a[p] + g.a[q]);
+    const int32_t gl = run_sat((int64_t)f.a[p] + g.lo[q]), gh = run_sat((int64_t)f.a[p] + g.hi[q]);
+    h.lo[p] = f.lo[p] < gl ? f.lo[p] : gl;
+    h.hi[p] = f.hi[p] > gh ? f.hi[p] : gh;
+  }
+  return h;
+}
+NB_HD bool run_fits(uint32_t S, const Run& r) {
+  const int p = (int)(S & 1u);
+  return (int64_t)S + r.lo[p] > (int64_t)kLo && (int64_t)S + r.hi[p] < (int64_t)kHi;
+}
+
 // CPU emulation of the device fold's control flow (tile = `tile` addends scanned at once, `seq_run` real adds after a
 // stop), used to check the functions above against the plain loop.  Returns the sum; *stops counts the restarts.
 inline float emulate_fold(const float* x, int64_t n, int tile, int seq_run, int64_t* stops) {
@@ -120,6 +156,33 @@ inline float emulate_fold(const float* x, int64_t n, int tile, int seq_run, int6
     pos += run;
   }
   if (stops) *stops = nstop;
+  return s;
+}
+
+// CPU emulation of the chunked fold (bvh_build.hip: bvh_chunk_sums / bvh_chunk_runs / the chunk walk of bvh_big_fold):
+// every chunk's run is prepared for the binade its start is PREDICTED to be in (from exact f64 partial sums); the walk
+// uses a run only if the prediction and the bounds hold for the true state, and adds the chunk for real otherwise.
+inline float emulate_fold_chunked(const float* x, int64_t n, int chunk, int64_t* used_runs) {
+  float s = 0.0f;
+  double prefix = 0.0;
+  int64_t used = 0;
+  for (int64_t c0 = 0; c0 < n; c0 += chunk) {
+    const int64_t c1 = c0 + chunk < n ? c0 + chunk : n;
+    Chain pred;
+    bool have = c0 > 0 && chain_open((float)prefix, pred);
+    Run r = run_none();
+    if (have)
+      for (int64_t k = c0; k < c1; ++k) r = run_then(r, run_of(step_of(x[k], pred.sign, pred.E)));
+    Chain cur;
+    if (have && chain_open(s, cur) && cur.E == pred.E && cur.sign == pred.sign && run_fits(cur.S, r)) {
+      s = chain_value(cur, (uint32_t)((int64_t)cur.S + r.a[cur.S & 1u]));
+      ++used;
+    } else {
+      for (int64_t k = c0; k < c1; ++k) s = s + x[k];
+    }
+    for (int64_t k = c0; k < c1; ++k) prefix += (double)x[k];
+  }
+  if (used_runs) *used_runs = used;
   return s;
 }
 

@@ -186,3 +186,31 @@ def test_exact_sum_scan_restarts_are_rare_on_scene_data(nb):
         got, restarts = C.selftest_exact_sum(pos[:, col], 4096, 64)
         assert _bits(got) == _bits(_seq_sum_f32(pos[:, col]))
         assert restarts <= 40
+
+
+@pytest.mark.parametrize("chunk", [2048, 64, 8])
+def test_chunked_exact_sum_reproduces_the_sequential_chain(nb, chunk):
+    """Long chains are cut into chunks whose runs are prepared for a predicted binade; a run may only be used when the
+    prediction and its bounds hold, so the result is the plain loop's whatever the data."""
+    C = nb._capi
+    rng = np.random.default_rng(41)
+    cases = {}
+    for n in (0, 1, 65, 5000, 151405):
+        cases[f"uniform{n}"] = rng.random(n) * 1e5
+        cases[f"negative{n}"] = -rng.random(n) * 1e5
+        cases[f"centred{n}"] = rng.standard_normal(n) * 3e4
+        cases[f"lattice{n}"] = rng.integers(0, 7000, n) * 14.0
+        cases[f"halves_pm{n}"] = rng.integers(-1000, 1000, n) * 0.5
+        cases[f"wide{n}"] = 10.0 ** rng.uniform(-12, 12, n) * rng.choice([-1.0, 1.0], n)
+    for name, bad in (("inf", np.inf), ("nan", np.nan), ("big", 3e38)):
+        x = rng.random(20000) * 1e5
+        x[9000] = bad
+        x[9001] = bad
+        cases[name] = x
+    for name, x in cases.items():
+        x = np.asarray(x, np.float32)
+        got, used = C.selftest_exact_sum_chunked(x, chunk)
+        want = _seq_sum_f32(x)
+        assert _bits(got) == _bits(want) or (np.isnan(got) and np.isnan(want)), (name, got, want)
+        if name == "uniform151405" and chunk == 2048:
+            assert used >= 60      # all but the first chunk and the ones a power of two falls into
