@@ -122,3 +122,38 @@ def test_gpu_accelerations_at_step0(nb):
         ctx.set_params(theta=50.0)
         ctx.upload(G["ic_pos"], G["ic_vel"], G["ic_weight"])
         assert np.array_equal(ctx.accel_tree(C.TREE_BVH, G["ic_pos"]), G["bvh_theta50_acc0"])
+
+
+# ---------------------------------------------------------------- frames of draw() (tests/golden/frames.npz)
+def _frames():
+    import os
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", "frames.npz"))
+
+
+def test_oracle_reproduces_golden_frames(nb, orc):
+    f = _frames()
+    pos, vel, w = nb.scenes.galaxy()
+    assert np.array_equal(orc.draw(pos, vel, w, 100_000, 125), f["galaxy_125"])
+    full = orc.draw(pos, vel, w, 100_000, 1250).reshape(-1, 4)
+    nz = np.flatnonzero(full[:, 3])
+    assert np.array_equal(nz, f["galaxy_1250_nz_index"]) and np.array_equal(full[nz], f["galaxy_1250_nz_rgba"])
+
+
+@pytest.mark.gpu
+def test_gpu_frames_equal_golden_frames(nb):
+    C = nb._capi
+    f = _frames()
+    pos, vel, w = nb.scenes.galaxy()
+    with C.Context(0) as ctx:
+        ctx.upload(pos, vel, w)
+        assert np.array_equal(ctx.render(100_000, 125), f["galaxy_125"])
+        full = ctx.render(100_000, 1250).reshape(-1, 4)
+        nz = np.flatnonzero(full[:, 3])
+        assert np.array_equal(nz, f["galaxy_1250_nz_index"]) and np.array_equal(full[nz], f["galaxy_1250_nz_rgba"])
+    g = np.load(__import__("os").path.join(__import__("os").path.dirname(__file__), "golden", "config1_1024.npz"))
+    world = nb.World(g["ic_pos"], g["ic_vel"], g["ic_weight"], method="bvh", theta=50.0, order="as_written")
+    try:
+        world.update(0.1, None, n_steps=100)
+        assert np.array_equal(world.frame(100_000, 125), f["plummer_s100_125"])
+    finally:
+        world.close()
