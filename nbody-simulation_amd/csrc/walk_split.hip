@@ -75,7 +75,9 @@ __global__ __launch_bounds__(256) void walk_pass(const WalkArgs<float> a, uint32
 #ifdef NB_WALK_TIMING
     const long long ts = wall_clock64();
 #endif
-    const int4 l = lk[i];
+    const int4 l = lk[i];    // the three records of a node are fetched together: one latency per step, not two
+    const float4 b = g0[i];  // lo.x lo.y hi.x hi.y
+    const float4 c = g1[i];  // cog.x cog.y mass s2
     const bool act = resume <= i;
     int next;
     if (l.w) {  // Leaf arm, main.rs:351-363: every particle of the slice, in slice order
@@ -105,8 +107,6 @@ __global__ __launch_bounds__(256) void walk_pass(const WalkArgs<float> a, uint32
       }
       next = l.x;
     } else {
-      const float4 b = g0[i];  // lo.x lo.y hi.x hi.y
-      const float4 c = g1[i];  // cog.x cog.y mass s2
       bool descend = false;
       if (act) {
         const bool contains = p.y > b.y && p.x > b.x && p.x < b.z && p.y < b.w;  // bvh_tree.rs:15-20 (all strict)
