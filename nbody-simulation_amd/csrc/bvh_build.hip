@@ -44,7 +44,7 @@ constexpr int kChainStart = 256; // real adds at the start of a long node's chai
 constexpr int kSub = 2048;       // nodes up to this long are built, subtree and all, by one work-group in LDS
 constexpr int kSubWaves = 8;     // waves of a subtree work-group
 constexpr int kChunk = 2048;     // points per work-group in the multi-group passes over a long node
-constexpr int kRunLen = 32768;   // nodes longer than this have their chain prepared chunk by chunk (bvh_chunk_runs)
+constexpr int kRunLen = 16384;   // nodes longer than this have their chain prepared chunk by chunk (bvh_chunk_runs)
 constexpr float kMaxF = 3.402823466e+38f;
 
 struct BvhPtrs {
@@ -58,7 +58,7 @@ struct BvhPtrs {
   int* ch_index;    // [level & 1][cap_chunk] chunk -> index inside the node
   double2* ch_sum;  // exact-ish (f64) sums of the chunk's coordinates: only used to PREDICT binades
   float4* ch_box;   // min.x min.y max.x max.y of the chunk
-  int* ch_run;      // [chunk][2 coordinates][8]: sign, E (0 = no run), a0, a1, lo0, lo1, hi0, hi1
+  int* ch_run;      // [chunk][2 coordinates][kRunRec]: see bvh_chunk_runs
   int* ch_cx;
   int* ch_cy;
   int* ch_before;   // predicate-true points of the node before the chunk
@@ -535,10 +535,36 @@ __device__ __forceinline__ xsum::Run shfl_down_run(const xsum::Run& r, int d) {
   return o;
 }
 
+// Runs are prepared per RUN chunk = m consecutive chunks of kChunk addends, m a power of two such that a node has at most
+// 64 of them: the chain's walk over the runs is sequential (~0.7 us per run), the preparation is not.
+__host__ __device__ inline int run_mult(int len) {
+  const int nch = (len + kChunk - 1) / kChunk;
+  int m = 1;
+  while (nch > 64 * m) m <<= 1;
+  return m;
+}
+constexpr int kRunRec = 24;  // ints per chunk and coordinate: sign, E_a (0: no run), E_b, u0, u1, run A (6), run B (6), pad
+__device__ __forceinline__ void store_run(int* o, const xsum::Run& r) {
+  o[0] = r.a[0]; o[1] = r.a[1]; o[2] = r.lo[0]; o[3] = r.lo[1]; o[4] = r.hi[0]; o[5] = r.hi[1];
+}
+// ordered reduction over the wave: lane 0 ends with r(lane 0) then r(lane 1) then ...
+__device__ __forceinline__ xsum::Run wave_run_in_order(xsum::Run r, int lane) {
+  for (int d = 1; d < 64; d <<= 1) {
+    const xsum::Run o = shfl_down_run(r, d);
+    if ((lane & (2 * d - 1)) == 0) r = xsum::run_then(r, o);
+  }
+  return r;
+}
+
+// One chunk's runs.  Every thread takes PER consecutive addends and the f64 prefix PREDICTS where the chain is at each
+// thread.  If the chunk stays in one binade: one run (A) over all of it.  If the prefix crosses ONE power of two B inside
+// the chunk (same-signed data): run A (old binade) over the threads safely below B (1 - kRunMargin), run B (new binade)
+// over the threads safely above B (1 + kRunMargin), and the threads in between are left to real adds (u0 .. u1).
 __global__ __launch_bounds__(256) void bvh_chunk_runs(BvhPtrs a, int level) {
   constexpr int PER = kChunk / 256;
-  __shared__ double redd[2][4];
-  __shared__ xsum::Run redr[2][4];
+  __shared__ double redd[4][4];
+  __shared__ xsum::Run redr[2][2][4];  // [coordinate][A / B][wave]
+  __shared__ int redi[2][4][4];        // [coordinate][#A, #B, #active, shape ok][wave]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nc = a.chunkcount[level];
   const int* ch_node = a.ch_node + (size_t)(level & 1) * a.cap_chunk;
@@ -547,67 +573,146 @@ __global__ __launch_bounds__(256) void bvh_chunk_runs(BvhPtrs a, int level) {
     const int node = ch_node[c], ci = ch_index[c];
     const int len = a.nlen[node];
     if (len <= kRunLen) continue;
-    int* rec = a.ch_run + (size_t)c * 16;
+    constexpr int m = 1;  // runs are prepared per chunk; bvh_big_fold merges them into at most 64 per node
+    int* rec = a.ch_run + (size_t)c * 2 * kRunRec;
     if (ci == 0) {  // the chain starts here: nothing to predict
-      if (tid == 0) { rec[1] = 0; rec[9] = 0; }
+      if (tid == 0) { rec[1] = 0; rec[kRunRec + 1] = 0; }
       continue;
     }
     // where the chain should be when it gets here: the f64 sums of the node's chunks before this one
     const int c0 = c - ci;  // a node's chunks are consecutive
-    double px = 0.0, py = 0.0;
-    for (int i = tid; i < ci; i += 256) {
+    const int nchn = (len + kChunk - 1) / kChunk;
+    double px = 0.0, py = 0.0, tx = 0.0, ty = 0.0;
+    for (int i = tid; i < ci + m && i < nchn; i += 256) {
       const double2 v = a.ch_sum[c0 + i];
-      px += v.x;
-      py += v.y;
+      if (i < ci) { px += v.x; py += v.y; } else { tx += v.x; ty += v.y; }
     }
     for (int d = 32; d >= 1; d >>= 1) {
       px += __shfl_xor(px, d, 64);
       py += __shfl_xor(py, d, 64);
+      tx += __shfl_xor(tx, d, 64);
+      ty += __shfl_xor(ty, d, 64);
     }
-    if (lane == 0) { redd[0][wave] = px; redd[1][wave] = py; }
+    if (lane == 0) { redd[0][wave] = px; redd[1][wave] = py; redd[2][wave] = tx; redd[3][wave] = ty; }
     __syncthreads();
     px = redd[0][0] + redd[0][1] + redd[0][2] + redd[0][3];
     py = redd[1][0] + redd[1][1] + redd[1][2] + redd[1][3];
-    xsum::Chain cx, cy;
-    const bool okx = xsum::chain_open((float)px, cx), oky = xsum::chain_open((float)py, cy);
-    const float2* P = a.P + a.nbegin[node];
-    const int base = ci * kChunk + tid * PER;
-    xsum::Run rx = xsum::run_none(), ry = xsum::run_none();
-#pragma unroll
-    for (int j = 0; j < PER; ++j) {
-      if (base + j < len) {
-        const float2 q = P[base + j];
-        if (okx) rx = xsum::run_then(rx, xsum::run_of(xsum::step_of(q.x, cx.sign, cx.E)));
-        if (oky) ry = xsum::run_then(ry, xsum::run_of(xsum::step_of(q.y, cy.sign, cy.E)));
-      }
-    }
-    for (int d = 1; d < 64; d <<= 1) {  // in order: lane l takes lane l + d behind it
-      const xsum::Run ox = shfl_down_run(rx, d), oy = shfl_down_run(ry, d);
-      if ((lane & (2 * d - 1)) == 0) {
-        rx = xsum::run_then(rx, ox);
-        ry = xsum::run_then(ry, oy);
-      }
-    }
-    if (lane == 0) { redr[0][wave] = rx; redr[1][wave] = ry; }
+    const double2 tot = make_double2(redd[2][0] + redd[2][1] + redd[2][2] + redd[2][3], redd[3][0] + redd[3][1] + redd[3][2] + redd[3][3]);
     __syncthreads();
-    if (tid < 2) {
-      xsum::Run r = redr[tid][0];
-      for (int w = 1; w < 4; ++w) r = xsum::run_then(r, redr[tid][w]);
-      const xsum::Chain& ch = tid ? cy : cx;
-      int* o = rec + 8 * tid;
-      o[0] = (int)ch.sign;
-      o[1] = (tid ? oky : okx) ? (int)ch.E : 0;
-      o[2] = r.a[0]; o[3] = r.a[1]; o[4] = r.lo[0]; o[5] = r.lo[1]; o[6] = r.hi[0]; o[7] = r.hi[1];
+    const float2* P = a.P + a.nbegin[node] + (size_t)ci * kChunk;               // this run chunk
+    const int cnt = (ci + m) * kChunk < len ? m * kChunk : len - ci * kChunk;  // its addends
+    const int seg = m * PER;                                                    // consecutive addends per thread
+    const int base = tid * seg;
+    // does either coordinate cross a power of two in this chunk?  Only then the threads need their own f64 prefix
+    xsum::Chain cax, cbx, cay, cby;
+    const bool hx = xsum::chain_open((float)px, cax) && xsum::chain_open((float)(px + tot.x), cbx) && cax.sign == cbx.sign;
+    const bool hy = xsum::chain_open((float)py, cay) && xsum::chain_open((float)(py + tot.y), cby) && cay.sign == cby.sign;
+    const bool crossing = (hx && cbx.E == cax.E + 1u) || (hy && cby.E == cay.E + 1u);  // uniform
+    double sx0 = 0.0, sy0 = 0.0, lx = 0.0, ly = 0.0;
+    if (crossing) {  // f64 prefix of my first addend
+      for (int j = 0; j < seg && base + j < cnt; ++j) {
+        const float2 qq = P[base + j];
+        lx += (double)qq.x;
+        ly += (double)qq.y;
+      }
+      double ix = lx, iy = ly;
+      for (int d = 1; d < 64; d <<= 1) {
+        const double ox = __shfl_up(ix, d, 64), oy = __shfl_up(iy, d, 64);
+        if (lane >= d) { ix += ox; iy += oy; }
+      }
+      if (lane == 63) { redd[0][wave] = ix; redd[1][wave] = iy; }
+      __syncthreads();
+      sx0 = px + ix - lx;
+      sy0 = py + iy - ly;
+      for (int w = 0; w < wave; ++w) { sx0 += redd[0][w]; sy0 += redd[1][w]; }
     }
-    __syncthreads();
+    const bool active = base < cnt;
+    for (int comp = 0; comp < 2; ++comp) {
+      const double s0 = comp ? sy0 : sx0, s1 = s0 + (comp ? ly : lx);
+      const xsum::Chain ca = comp ? cay : cax, cb = comp ? cby : cbx;
+      const bool have = (comp ? hy : hx) && (cb.E == ca.E || cb.E == ca.E + 1u);
+      int cls = 2;  // 0: run A, 1: run B, 2: left to real adds
+      if (have) {
+        if (cb.E == ca.E) {
+          cls = 0;
+        } else {
+          const double sgn = ca.sign ? -1.0 : 1.0;
+          const double B = __builtin_ldexp(1.0, (int)cb.E - 127);
+          const double lo = B * (1.0 - xsum::kRunMargin), hi = B * (1.0 + xsum::kRunMargin);
+          const double qs = sgn * s0, qe = sgn * s1;
+          if (qs < lo && qe < lo) cls = 0;
+          else if (qs > hi && qe > hi) cls = 1;
+        }
+      }
+      if (!active) cls = 3;
+      const unsigned long long mA = __builtin_amdgcn_ballot_w64(cls == 0), mB = __builtin_amdgcn_ballot_w64(cls == 1);
+      const unsigned long long mAct = __builtin_amdgcn_ballot_w64(active);
+      if (lane == 0) {  // inside the wave: A threads first, B threads last (the active threads are a prefix of the lanes)
+        const int nA = __builtin_popcountll(mA), nB = __builtin_popcountll(mB), nAct = __builtin_popcountll(mAct);
+        const unsigned long long lowA = nA >= 64 ? ~0ull : ((1ull << nA) - 1ull);
+        const unsigned long long lowNB = (nAct - nB) >= 64 ? ~0ull : ((1ull << (nAct - nB)) - 1ull);
+        redi[comp][0][wave] = nA;
+        redi[comp][1][wave] = nB;
+        redi[comp][2][wave] = nAct;
+        redi[comp][3][wave] = (mA == lowA && mB == (mAct & ~lowNB)) ? 1 : 0;
+      }
+      xsum::Run r = xsum::run_none();
+      if (cls == 0 || cls == 1) {
+        const xsum::Chain& ch = cls ? cb : ca;
+        for (int j = 0; j < seg && base + j < cnt; ++j) {
+          const float2 qq = P[base + j];
+          r = xsum::run_then(r, xsum::run_of(xsum::step_of(comp ? qq.y : qq.x, ch.sign, ch.E)));
+        }
+      }
+      // ordered reduction: a wave is usually all A or all B; only a wave that straddles the crossing reduces twice
+      xsum::Run ra = xsum::run_none(), rb = xsum::run_none();
+      if (mB == 0ull) {
+        ra = wave_run_in_order(cls == 0 ? r : xsum::run_none(), lane);
+      } else if (mA == 0ull) {
+        rb = wave_run_in_order(cls == 1 ? r : xsum::run_none(), lane);
+      } else {
+        ra = wave_run_in_order(cls == 0 ? r : xsum::run_none(), lane);
+        rb = wave_run_in_order(cls == 1 ? r : xsum::run_none(), lane);
+      }
+      if (lane == 0) { redr[comp][0][wave] = ra; redr[comp][1][wave] = rb; }
+      __syncthreads();
+      if (tid == 0) {
+        int* o = rec + comp * kRunRec;
+        int nA = 0, nB = 0, nAct = 0;
+        for (int w = 0; w < 4; ++w) { nA += redi[comp][0][w]; nB += redi[comp][1][w]; nAct += redi[comp][2][w]; }
+        // A must be a prefix of the chunk's threads and B a suffix (same-signed data, one crossing)
+        bool ok = have;
+        bool a_over = false, b_begun = false;
+        for (int w = 0; w < 4; ++w) {
+          const int wa = redi[comp][0][w], wb = redi[comp][1][w], wact = redi[comp][2][w];
+          if (!redi[comp][3][w]) ok = false;
+          if (a_over && wa > 0) ok = false;
+          if (b_begun && wb != wact) ok = false;
+          if (wa < wact) a_over = true;
+          if (wb > 0) b_begun = true;
+        }
+        o[0] = (int)ca.sign;
+        o[1] = ok ? (int)ca.E : 0;
+        o[2] = (int)cb.E;
+        const int u0 = nA * seg < cnt ? nA * seg : cnt;
+        const int u1 = (nAct - nB) * seg < cnt ? (nAct - nB) * seg : cnt;
+        o[3] = u0;
+        o[4] = u1 > u0 ? u1 : u0;
+        xsum::Run A = redr[comp][0][0], Bq = redr[comp][1][0];
+        for (int w = 1; w < 4; ++w) { A = xsum::run_then(A, redr[comp][0][w]); Bq = xsum::run_then(Bq, redr[comp][1][w]); }
+        store_run(o + 5, A);
+        store_run(o + 11, Bq);
+      }
+      __syncthreads();
+    }
   }
 }
 
 // ---- long nodes, one level: fold ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(512) void bvh_big_fold(BvhPtrs a, int level, int use_runs) {
-  constexpr int kRecBatch = 512;
+  constexpr int kRecBatch = 64;
   __shared__ Scratch<8> sh;
-  __shared__ int recs[kRecBatch * 8];
+  __shared__ __attribute__((aligned(16))) int recs[kRecBatch * kRunRec];
   const int tid = threadIdx.x;
   const int comp = blockIdx.y;  // 0: x, 1: y
   const int nq = a.bigcount[level];
@@ -620,28 +725,107 @@ __global__ __launch_bounds__(512) void bvh_big_fold(BvhPtrs a, int level, int us
     float sum, mn, mx;
     if (use_runs && len > kRunLen) {
       const int c0 = a.nchunk0[node], nch = (len + kChunk - 1) / kChunk;
+      const int rm = run_mult(len), rlen = rm * kChunk, nrun = (nch + rm - 1) / rm;  // run chunks: <= 64 of them
       sum = 0.f;
       int used = 0;
-      for (int b0 = 0; b0 < nch; b0 += kRecBatch) {  // the runs of a batch of chunks come to LDS together ...
-        const int nb = nch - b0 < kRecBatch ? nch - b0 : kRecBatch;
-        for (int k = tid; k < nb * 8; k += 512) recs[k] = a.ch_run[(size_t)(c0 + b0 + (k >> 3)) * 16 + 8 * comp + (k & 7)];
-        __syncthreads();
-        for (int ci = b0; ci < b0 + nb; ++ci) {  // ... and the chain walks through them in order
-          const int* rec = recs + (ci - b0) * 8;
-          xsum::Chain ch;
-          bool ok = rec[1] != 0 && xsum::chain_open(sum, ch) && (int)ch.E == rec[1] && (int)ch.sign == rec[0];
-          if (ok) {
-            xsum::Run r;
-            r.a[0] = rec[2]; r.a[1] = rec[3]; r.lo[0] = rec[4]; r.lo[1] = rec[5]; r.hi[0] = rec[6]; r.hi[1] = rec[7];
-            ok = xsum::run_fits(ch.S, r);
-            if (ok) sum = xsum::chain_value(ch, (uint32_t)((int)ch.S + r.a[ch.S & 1u]));
+      {  // the chunks' runs are merged, rm at a time, into the <= 64 runs the chain will walk (one thread per merged run)
+        const int b0 = 0, nb = nrun;
+        if (tid < nrun) {
+          const int f0 = tid * rm, f1 = f0 + rm < nch ? f0 + rm : nch;
+          xsum::Run A = xsum::run_none(), B = xsum::run_none();
+          int sign = 0, Ea = 0, Eb = 0, u0 = 0, u1 = 0, pos = 0;
+          bool valid = true, crossed = false;
+          for (int f = f0; f < f1 && valid; ++f) {
+            const int* fr = a.ch_run + (size_t)(c0 + f) * 2 * kRunRec + comp * kRunRec;
+            const int cntf = (f + 1) * kChunk < len ? kChunk : len - f * kChunk;
+            const int fE = fr[1];
+            if (fE == 0) { valid = false; break; }
+            xsum::Run fa, fb;
+            fa.a[0] = fr[5]; fa.a[1] = fr[6]; fa.lo[0] = fr[7]; fa.lo[1] = fr[8]; fa.hi[0] = fr[9]; fa.hi[1] = fr[10];
+            fb.a[0] = fr[11]; fb.a[1] = fr[12]; fb.lo[0] = fr[13]; fb.lo[1] = fr[14]; fb.hi[0] = fr[15]; fb.hi[1] = fr[16];
+            const bool whole = fr[3] >= cntf;  // one run over the whole chunk
+            if (f == f0) { sign = fr[0]; Ea = fE; Eb = fE; }
+            if (fr[0] != sign) { valid = false; break; }
+            if (!crossed) {
+              if (fE != Ea) { valid = false; break; }
+              A = xsum::run_then(A, fa);
+              if (!whole) {  // the power of two falls into this chunk
+                u0 = pos + fr[3];
+                u1 = pos + fr[4];
+                B = fb;
+                Eb = fr[2];
+                crossed = true;
+              }
+            } else {
+              if (fE != Eb || !whole) { valid = false; break; }  // a second crossing: leave it to the scan
+              B = xsum::run_then(B, fa);
+            }
+            pos += cntf;
           }
-          if (!ok) {  // this chunk by the scan, from the true state
-            const int hi = (ci + 1) * kChunk < len ? (ci + 1) * kChunk : len;
+          if (!crossed) { u0 = pos; u1 = pos; }
+          int* o = recs + tid * kRunRec;
+          o[0] = sign; o[1] = valid ? Ea : 0; o[2] = Eb; o[3] = u0; o[4] = u1;
+          o[5] = A.a[0]; o[6] = A.a[1]; o[7] = A.lo[0]; o[8] = A.lo[1]; o[9] = A.hi[0]; o[10] = A.hi[1];
+          o[11] = B.a[0]; o[12] = B.a[1]; o[13] = B.lo[0]; o[14] = B.lo[1]; o[15] = B.hi[0]; o[16] = B.hi[1];
+        }
+        __syncthreads();
+        int ci = b0;
+        while (ci < b0 + nb) {  // ... and the chain walks through them in order
+          // one wave runs ahead as long as the prepared runs hold (a few dozen instructions per chunk, no barrier) ...
+          if (tid < 64) {
+            int u = 0;
+            for (; ci < b0 + nb; ++ci) {
+              // the whole record in one go (LDS latency once per chunk, not once per field)
+              const int4* rv = reinterpret_cast<const int4*>(recs + (ci - b0) * kRunRec);
+              const int4 r0 = rv[0], r1 = rv[1], r2 = rv[2], r3 = rv[3], r4 = rv[4];
+              const int rec[20] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y,
+                                   r2.z, r2.w, r3.x, r3.y, r3.z, r3.w, r4.x, r4.y, r4.z, r4.w};
+              if (rec[1] == 0) break;
+              const int lo = ci * rlen, hi = lo + rlen < len ? lo + rlen : len;
+              const int u0 = rec[3], u1 = rec[4];
+              float t = sum;
+              bool good = true;
+#pragma unroll
+              for (int part = 0; part < 2; ++part) {
+                const int pb = part ? lo + u1 : lo, pe = part ? hi : lo + u0;
+                if (good && pe > pb) {
+                  xsum::Chain ch;
+                  good = xsum::chain_open(t, ch) && (int)ch.E == rec[1 + part] && (int)ch.sign == rec[0];
+                  if (good) {
+                    xsum::Run r;
+                    r.a[0] = rec[5 + 6 * part]; r.a[1] = rec[6 + 6 * part];
+                    r.lo[0] = rec[7 + 6 * part]; r.lo[1] = rec[8 + 6 * part];
+                    r.hi[0] = rec[9 + 6 * part]; r.hi[1] = rec[10 + 6 * part];
+                    good = xsum::run_fits(ch.S, r);
+                    if (good) { t = xsum::chain_value(ch, (uint32_t)((int)ch.S + r.a[ch.S & 1u])); ++u; }
+                  }
+                }
+                if (good && part == 0 && u1 > u0) {  // the addends around the power of two: real adds
+                  Box bx;
+                  float sx = t, sy = t;
+                  chain_run(P, lo + u0, u1 - u0, tid, sx, sy, bx);
+                  t = comp ? sy : sx;
+                }
+              }
+              if (!good) break;  // ... a chunk whose run does not hold is everybody's business
+              sum = t;
+              used += u;
+              u = 0;
+            }
+            if (tid == 0) { sh.bad_s = xsum::f2u(sum); sh.bad = ci; }
+          }
+          __syncthreads();
+          sum = xsum::u2f(sh.bad_s);
+          ci = sh.bad;
+          __syncthreads();
+          if (ci >= b0 + nb) break;
+          {  // this chunk by the scan, from the true state (its first part may still be taken whole)
+            const int* rec = recs + (ci - b0) * kRunRec;
+            const int lo = ci * rlen, hi = lo + rlen < len ? lo + rlen : len;
             float dmn, dmx;
-            exact_fold<8, 8>(P, ci * kChunk, hi, sum, comp, tid, &sh, sum, dmn, dmx, stops);
-          } else {
-            ++used;
+            exact_fold<8, 8>(P, lo, hi, sum, comp, tid, &sh, sum, dmn, dmx, stops);
+            (void)rec;
+            ++ci;
           }
         }
         __syncthreads();
@@ -1221,7 +1405,7 @@ BvhBuildLayout bvh_build_layout(int64_t n, int leaf_size) {
   L.ch_index = take(4 * 2 * CC);
   L.ch_sum = take(16 * CC);
   L.ch_box = take(16 * CC);
-  L.ch_run = take(4 * 16 * CC);
+  L.ch_run = take(4 * 48 * CC);  // 2 * kRunRec ints per chunk
   L.ch_cx = take(4 * CC);
   L.ch_cy = take(4 * CC);
   L.ch_before = take(4 * CC);

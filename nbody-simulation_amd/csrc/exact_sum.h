@@ -87,19 +87,22 @@ NB_HD Step compose(Step f, Step g) {
 // ---- whole runs of addends, so that a long chain can be cut into chunks that are prepared in parallel ------------------
 // A run seen from a chain in one binade: the total increment of S and the extremes of every intermediate S, relative to
 // the S the run starts from, for an even (index 0) / odd (1) start.  If S + lo > 2^23 and S + hi < 2^24 for the actual
-// start, every add of the run stayed in the binade and S + a is the exact result.  Saturating at +-2^30: beyond that a
-// run is unusable anyway (a poison step is 2^30).
+// start, every add of the run stayed in the binade and S + a is the exact result.  Saturating at +-2^29: beyond that a
+// run is unusable anyway (a poison step is 2^30, saturated on entry).
 struct Run {
   int32_t a[2], lo[2], hi[2];
 };
-NB_HD int32_t run_sat(int64_t v) {
-  const int64_t m = (int64_t)1 << 30;
-  return (int32_t)(v > m ? m : (v < -m ? -m : v));
-}
+// How close (relatively) to a power of two a predicted prefix may come and still be trusted.  The f32 chain drifts from the
+// exact prefix by ~sqrt(n) half-ulps (worst case n): 2^-13 covers millions of addends; if it is ever too tight, the run's
+// own bounds fail when it is applied and the scan takes over.  The addends inside the margin are added for real, so the
+// margin also is 2 * margin * (addends so far) of serial work per crossing.
+constexpr double kRunMargin = 1.0 / 8192.0;
+constexpr int32_t kRunSat = 1 << 29;  // two saturated values still add without wrapping
+NB_HD int32_t run_sat(int32_t v) { return v > kRunSat ? kRunSat : (v < -kRunSat ? -kRunSat : v); }
 NB_HD Run run_of(Step f) {
   Run r;
-  r.a[0] = r.lo[0] = r.hi[0] = (int32_t)f.a0;
-  r.a[1] = r.lo[1] = r.hi[1] = (int32_t)f.a1;
+  r.a[0] = r.lo[0] = r.hi[0] = run_sat((int32_t)f.a0);
+  r.a[1] = r.lo[1] = r.hi[1] = run_sat((int32_t)f.a1);
   return r;
 }
 NB_HD Run run_none() { return Run{{0, 0}, {0, 0}, {0, 0}}; }  // an open chain has S inside the binade: offsets 0 fit
@@ -108,8 +111,9 @@ NB_HD Run run_then(const Run& f, const Run& g) {
   Run h;
   for (int p = 0; p < 2; ++p) {
     const int q = (p + f.a[p]) & 1;
-    h.a[p] = run_sat((int64_t)f.a[p] + g.a[q]);
-    const int32_t gl = run_sat((int64_t)f.a[p] + g.lo[q]), gh = run_sat((int64_t)f.a[p] + g.hi[q]);
+    const int32_t ga = q ? g.a[1] : g.a[0], glo = q ? g.lo[1] : g.lo[0], ghi = q ? g.hi[1] : g.hi[0];
+    h.a[p] = run_sat(f.a[p] + ga);
+    const int32_t gl = run_sat(f.a[p] + glo), gh = run_sat(f.a[p] + ghi);
     h.lo[p] = f.lo[p] < gl ? f.lo[p] : gl;
     h.hi[p] = f.hi[p] > gh ? f.hi[p] : gh;
   }
@@ -181,6 +185,82 @@ inline float emulate_fold_chunked(const float* x, int64_t n, int chunk, int64_t*
       for (int64_t k = c0; k < c1; ++k) s = s + x[k];
     }
     for (int64_t k = c0; k < c1; ++k) prefix += (double)x[k];
+  }
+  if (used_runs) *used_runs = used;
+  return s;
+}
+
+// The same with the chunk that contains a crossing split three ways (bvh_chunk_runs' second form): thread segments of
+// `seg` addends whose predicted prefix stays below (1 - kRunMargin) of the power of two form run A (old binade), those above
+// (1 + kRunMargin) of it run B (new binade), the segments in between are added for real.
+inline float emulate_fold_chunked2(const float* x, int64_t n, int chunk, int seg, int64_t* used_runs) {
+  float s = 0.0f;
+  double prefix = 0.0;
+  int64_t used = 0;
+  auto real = [&](int64_t b, int64_t e) { for (int64_t k = b; k < e; ++k) s = s + x[k]; };
+  auto take = [&](const Run& r, uint32_t sign, uint32_t E, int64_t b, int64_t e) {
+    Chain cur;
+    if (e > b && chain_open(s, cur) && cur.E == E && cur.sign == sign && run_fits(cur.S, r)) {
+      s = chain_value(cur, (uint32_t)((int64_t)cur.S + r.a[cur.S & 1u]));
+      ++used;
+    } else {
+      real(b, e);
+    }
+  };
+  for (int64_t c0 = 0; c0 < n; c0 += chunk) {
+    const int64_t c1 = c0 + chunk < n ? c0 + chunk : n;
+    double total = 0.0;
+    for (int64_t k = c0; k < c1; ++k) total += (double)x[k];
+    Chain ca, cb;
+    const bool have = c0 > 0 && chain_open((float)prefix, ca) && chain_open((float)(prefix + total), cb) && ca.sign == cb.sign &&
+                      (cb.E == ca.E || cb.E == ca.E + 1);
+    if (!have) {
+      real(c0, c1);
+    } else {
+      const int64_t nseg = (c1 - c0 + seg - 1) / seg;
+      const double sgn = ca.sign ? -1.0 : 1.0;
+      double B = 1.0;
+      for (int e = 127; e < (int)cb.E; ++e) B *= 2.0;
+      for (int e = 127; e > (int)cb.E; --e) B *= 0.5;
+      const double lo = B * (1.0 - kRunMargin), hi = B * (1.0 + kRunMargin);
+      int64_t nA = 0, nB = 0;
+      bool contiguous = true;
+      {
+        double run = prefix;
+        // pass 1: classify
+        static thread_local int cls[1 << 16];
+        for (int64_t t = 0; t < nseg; ++t) {
+          const int64_t b = c0 + t * seg, e = b + seg < c1 ? b + seg : c1;
+          const double qs = sgn * run;
+          for (int64_t k = b; k < e; ++k) run += (double)x[k];
+          const double qe = sgn * run;
+          int cl = 2;  // zone
+          if (cb.E == ca.E) cl = 0;
+          else if (qs < lo && qe < lo) cl = 0;
+          else if (qs > hi && qe > hi) cl = 1;
+          cls[t] = cl;
+          nA += cl == 0;
+          nB += cl == 1;
+        }
+        for (int64_t t = 0; t < nseg; ++t) {
+          if (cls[t] == 0 && t >= nA) contiguous = false;
+          if (cls[t] == 1 && t < nseg - nB) contiguous = false;
+        }
+      }
+      if (!contiguous) {
+        real(c0, c1);
+      } else {
+        const int64_t u0 = c0 + (nA * seg < c1 - c0 ? nA * seg : c1 - c0);
+        const int64_t u1 = c0 + ((nseg - nB) * seg < c1 - c0 ? (nseg - nB) * seg : c1 - c0);
+        Run ra = run_none(), rb = run_none();
+        for (int64_t k = c0; k < u0; ++k) ra = run_then(ra, run_of(step_of(x[k], ca.sign, ca.E)));
+        for (int64_t k = u1; k < c1; ++k) rb = run_then(rb, run_of(step_of(x[k], cb.sign, cb.E)));
+        take(ra, ca.sign, ca.E, c0, u0);
+        real(u0, u1);
+        take(rb, cb.sign, cb.E, u1, c1);
+      }
+    }
+    prefix += total;
   }
   if (used_runs) *used_runs = used;
   return s;
