@@ -232,8 +232,9 @@ int nbody_render_rgba_dev(void* stream, int64_t n, int is_f64, const void* pos_x
  * (csrc/exact_sum.h).  This runs the same scan functions on the CPU, `tile` addends per scan and `seq_run` plain
  * adds after every restart, so the CPU tests can check them against the plain loop. */
 int nbody_selftest_exact_sum(const float* x, int64_t n, int tile, int seq_run, float* out_sum, int64_t* out_restarts);
-/* The chunked variant long chains use (runs prepared per chunk for a PREDICTED binade, used only when the prediction and
- * the run's bounds hold for the true state): same functions on the CPU; *out_runs_used counts the chunks taken whole. */
+/* The chunked variant long chains use (runs prepared per chunk for a PREDICTED binade — two runs and a few real adds in
+ * between where the prefix crosses a power of two — used only when the prediction and the run's bounds hold for the true
+ * state): same functions on the CPU; *out_runs_used counts the runs that were applied. */
 int nbody_selftest_exact_sum_chunked(const float* x, int64_t n, int chunk, float* out_sum, int64_t* out_runs_used);
 /* Restarts of that scan during the last device BVH build of this context (diagnostic; 0 after a host build). */
 int nbody_bvh_build_restarts(const nbody_ctx* ctx);

@@ -1448,7 +1448,8 @@ NB_API int nbody_selftest_exact_sum(const float* x, int64_t n, int tile, int seq
 }
 NB_API int nbody_selftest_exact_sum_chunked(const float* x, int64_t n, int chunk, float* out_sum, int64_t* out_runs_used) {
   if ((!x && n > 0) || n < 0 || chunk < 1 || !out_sum) return NBODY_ERR_INVALID;
-  *out_sum = xsum::emulate_fold_chunked(x, n, chunk, out_runs_used);
+  // segments of 8 addends per thread, as bvh_chunk_runs cuts a chunk
+  *out_sum = xsum::emulate_fold_chunked2(x, n, chunk, chunk >= 8 ? 8 : 1, out_runs_used);
   return NBODY_OK;
 }
 NB_API int nbody_bvh_build_restarts(const nbody_ctx* ctx) { return ctx ? ctx->bvh_stops : 0; }

@@ -218,6 +218,7 @@ inline float emulate_fold_chunked2(const float* x, int64_t n, int chunk, int seg
       real(c0, c1);
     } else {
       const int64_t nseg = (c1 - c0 + seg - 1) / seg;
+      if (nseg > (1 << 16)) { real(c0, c1); prefix += total; continue; }  // more segments than the scratch below holds
       const double sgn = ca.sign ? -1.0 : 1.0;
       double B = 1.0;
       for (int e = 127; e < (int)cb.E; ++e) B *= 2.0;
