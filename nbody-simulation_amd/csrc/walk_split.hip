@@ -26,9 +26,9 @@ namespace nbody {
 namespace {
 
 // Targets per wave.  Counting is cheapest with full waves; in the term pass a wave's time grows with the number of
-// leaves the union of its targets visits, so fewer targets per wave (the other lanes only help at the leaves)
-// shorten the longest wave.
-constexpr int kCountTPW = 64, kTermTPW = 8;
+// leaves its targets visit, so its waves are cut by work (see walk_pass).
+constexpr int kCountTPW = 64;
+constexpr uint32_t kTermBudget = 8192;  // terms a wave of the term pass writes, about
 
 __device__ __forceinline__ float lane_f(float v, int k) {  // k uniform
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), k));
@@ -52,9 +52,31 @@ __global__ __launch_bounds__(256) void walk_pass(const WalkArgs<float> a, uint32
                                                  float2* __restrict__ terms, const int* __restrict__ info, int64_t capacity) {
   const int lane = threadIdx.x & 63;
   const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int64_t t = wave * kTPW + lane;
-  const bool live = lane < kTPW && t < a.n_tgt;
   if (EMIT && (info[1] != 0)) return;  // the term array is too small: the caller grows it
+  int64_t t;
+  bool live;
+  if (EMIT) {
+    // Waves by WORK, not by head count: wave w takes the targets t with g(t) = off[t] / kTermBudget + t / 64 == w
+    // (g never decreases: at most 64 targets, about kTermBudget terms — a target with thousands of terms walks alone,
+    // and its wave is as short as its own path).  The two ends of the range by binary search.
+    int64_t lo = 0, hi = a.n_tgt;
+    while (lo < hi) {  // first t with g(t) >= wave
+      const int64_t mid = (lo + hi) >> 1;
+      if ((int64_t)(off[mid] / kTermBudget) + (mid >> 6) < wave) lo = mid + 1; else hi = mid;
+    }
+    const int64_t t0 = lo;
+    hi = t0 + 64 < a.n_tgt ? t0 + 64 : a.n_tgt;
+    while (lo < hi) {  // first t with g(t) > wave
+      const int64_t mid = (lo + hi) >> 1;
+      if ((int64_t)(off[mid] / kTermBudget) + (mid >> 6) <= wave) lo = mid + 1; else hi = mid;
+    }
+    if (lo == t0) return;  // no target has this number
+    t = t0 + lane;
+    live = t < lo;
+  } else {
+    t = wave * kTPW + lane;
+    live = lane < kTPW && t < a.n_tgt;
+  }
   const int64_t row = live ? (a.tgt_index ? (int64_t)a.tgt_index[t] : t) : 0;
   const float2 p = live ? reinterpret_cast<const float2*>(a.tgt_pos)[row] : make_float2(0.f, 0.f);
   const float4* __restrict__ g0 = reinterpret_cast<const float4*>(a.geom0);
@@ -224,7 +246,8 @@ hipError_t launch_tree_walk_split(hipStream_t s, const WalkArgs<float>& a, char*
   uint32_t* cnt = (uint32_t*)(scratch + L.cnt);
   uint32_t* off = (uint32_t*)(scratch + L.off);
   int* info = (int*)(scratch + L.info);
-  const int64_t cwaves = (a.n_tgt + kCountTPW - 1) / kCountTPW, twaves = (a.n_tgt + kTermTPW - 1) / kTermTPW;
+  const int64_t cwaves = (a.n_tgt + kCountTPW - 1) / kCountTPW;
+  const int64_t twaves = term_capacity / kTermBudget + a.n_tgt / 64 + 2;  // upper bound of g(t) + 1
   hipError_t e = hipMemsetAsync(info, 0, 16, s);
   if (e != hipSuccess) return e;
   walk_pass<false, kCountTPW><<<dim3((unsigned)((cwaves + 3) / 4)), dim3(256), 0, s>>>(a, cnt, nullptr, nullptr, info, term_capacity);
@@ -233,7 +256,7 @@ hipError_t launch_tree_walk_split(hipStream_t s, const WalkArgs<float>& a, char*
   if (e != hipSuccess) return e;
   walk_check_wrap<<<dim3((unsigned)((a.n_tgt + 255) / 256)), dim3(256), 0, s>>>(cnt, off, a.n_tgt, info);
   walk_total<<<dim3(1), dim3(1), 0, s>>>(cnt, off, a.n_tgt, term_capacity, info);
-  walk_pass<true, kTermTPW><<<dim3((unsigned)((twaves + 3) / 4)), dim3(256), 0, s>>>(a, cnt, off, (float2*)terms, info, term_capacity);
+  walk_pass<true, 64><<<dim3((unsigned)((twaves + 3) / 4)), dim3(256), 0, s>>>(a, cnt, off, (float2*)terms, info, term_capacity);
   const int64_t sum_waves = (a.n_tgt + 3) / 4;
   walk_sum<<<dim3((unsigned)((sum_waves + 3) / 4)), dim3(256), 0, s>>>(a, cnt, off, (const float2*)terms, info);
   return hipGetLastError();
