@@ -775,10 +775,10 @@ int tree_walk_phase(nbody_ctx* c, State<T>& s, int kind, const void* tgt_pos, in
   }
   bool done = false;
   if constexpr (std::is_same<T, float>::value) {
-    // Big leaves and the reference's arithmetic: count / terms / ordered sum (walk_split.hip) unless it would need more
+    // Big leaves: count / terms / ordered sum (walk_split.hip) unless it would need more
     // memory than it is worth.  NBODY_WALK_SPLIT: 0 never, 1 when it pays (default), 2 whenever it is possible.
     const int mode = env_int("NBODY_WALK_SPLIT", 1);
-    const bool eligible = w.big_leaves && !w.fast && !w.stats && w.n_tgt > 0 && w.n_nodes > 0 && env_int("NBODY_WALK_PER_THREAD", 0) == 0;
+    const bool eligible = w.big_leaves && !w.stats && w.n_tgt > 0 && w.n_nodes > 0 && env_int("NBODY_WALK_PER_THREAD", 0) == 0;
     if (eligible && mode != 0 && (mode == 2 || (w.n_tgt >= 4096 && s.ws_backoff == 0))) {
       const int64_t hard_cap = ((int64_t)1 << 31) - 65536;  // terms (16 GB; the offsets are 32 bits wide); past that the fused walk
       const WalkSplitLayout L = walk_split_layout(w.n_tgt);

@@ -46,8 +46,22 @@ __device__ __forceinline__ float2 pair_term(float px, float py, float qx, float 
   return make_float2((dx * force) / den, (dy * force) / den);      // :252
 }
 
+// nbody_arith FAST (opt-in, tolerance instead of bit parity): one reciprocal instead of two IEEE divisions; a zero difference
+// contributes exactly 0 through the biased denominator (direct_kernels.hip)
+__device__ __forceinline__ float2 pair_term_fast(float px, float py, float qx, float qy, float force, float clamp) {
+  const float dx = qx - px, dy = qy - py;
+  const float sum = __builtin_fabsf(dx) + __builtin_fabsf(dy);
+  const float d2 = __builtin_fmaxf(__builtin_fmaf(dy, dy, dx * dx), clamp);
+  const float s = force * __builtin_amdgcn_rcpf(__builtin_fmaf(sum, d2, 8.0779356694631609e-28f));  // 2^-90
+  return make_float2(dx * s, dy * s);
+}
+template <bool FAST> __device__ __forceinline__ float2 term_of(float px, float py, float qx, float qy, float force, float clamp) {
+  if constexpr (FAST) return pair_term_fast(px, py, qx, qy, force, clamp);
+  else return pair_term(px, py, qx, qy, force, clamp);
+}
+
 // The traversal both passes share.  F: what to do with an accepted node / a leaf.
-template <bool EMIT, int kTPW>
+template <bool EMIT, int kTPW, bool FAST>
 __global__ __launch_bounds__(256) void walk_pass(const WalkArgs<float> a, uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off,
                                                  float2* __restrict__ terms, const int* __restrict__ info, int64_t capacity) {
   const int lane = threadIdx.x & 63;
@@ -119,7 +133,7 @@ __global__ __launch_bounds__(256) void walk_pass(const WalkArgs<float> a, uint32
             todo &= todo - 1;
             const float tx = lane_f(p.x, tl), ty = lane_f(p.y, tl);
             const uint32_t dst = (uint32_t)__builtin_amdgcn_readlane((int)(base + n_terms), tl) + (uint32_t)k0;
-            if (mine < l.z) terms[dst + lane] = pair_term(tx, ty, q.x, q.y, m, clamp);
+            if (mine < l.z) terms[dst + lane] = term_of<FAST>(tx, ty, q.x, q.y, m, clamp);
           }
         }
       }
@@ -135,7 +149,7 @@ __global__ __launch_bounds__(256) void walk_pass(const WalkArgs<float> a, uint32
         const float ddx = p.x - c.x, ddy = p.y - c.y;                              // dist2(p, cog), main.rs:228-232
         const float d2 = ddx * ddx + ddy * ddy;
         if (!contains && c.w < d2 * theta * theta) {                               // :370-372
-          if (EMIT) terms[base + n_terms] = pair_term(p.x, p.y, c.x, c.y, c.z, clamp);  // :374-379
+          if (EMIT) terms[base + n_terms] = term_of<FAST>(p.x, p.y, c.x, c.y, c.z, clamp);  // :374-379
           ++n_terms;
           resume = l.x;
         } else {
@@ -250,13 +264,14 @@ hipError_t launch_tree_walk_split(hipStream_t s, const WalkArgs<float>& a, char*
   const int64_t twaves = term_capacity / kTermBudget + a.n_tgt / 64 + 2;  // upper bound of g(t) + 1
   hipError_t e = hipMemsetAsync(info, 0, 16, s);
   if (e != hipSuccess) return e;
-  walk_pass<false, kCountTPW><<<dim3((unsigned)((cwaves + 3) / 4)), dim3(256), 0, s>>>(a, cnt, nullptr, nullptr, info, term_capacity);
+  walk_pass<false, kCountTPW, false><<<dim3((unsigned)((cwaves + 3) / 4)), dim3(256), 0, s>>>(a, cnt, nullptr, nullptr, info, term_capacity);
   size_t tb = L.cub_temp_bytes;
   e = hipcub::DeviceScan::ExclusiveSum((void*)(scratch + L.cub_temp), tb, (const uint32_t*)cnt, off, (int)a.n_tgt, s);
   if (e != hipSuccess) return e;
   walk_check_wrap<<<dim3((unsigned)((a.n_tgt + 255) / 256)), dim3(256), 0, s>>>(cnt, off, a.n_tgt, info);
   walk_total<<<dim3(1), dim3(1), 0, s>>>(cnt, off, a.n_tgt, term_capacity, info);
-  walk_pass<true, 64><<<dim3((unsigned)((twaves + 3) / 4)), dim3(256), 0, s>>>(a, cnt, off, (float2*)terms, info, term_capacity);
+  if (a.fast) walk_pass<true, 64, true><<<dim3((unsigned)((twaves + 3) / 4)), dim3(256), 0, s>>>(a, cnt, off, (float2*)terms, info, term_capacity);
+  else walk_pass<true, 64, false><<<dim3((unsigned)((twaves + 3) / 4)), dim3(256), 0, s>>>(a, cnt, off, (float2*)terms, info, term_capacity);
   const int64_t sum_waves = (a.n_tgt + 3) / 4;
   walk_sum<<<dim3((unsigned)((sum_waves + 3) / 4)), dim3(256), 0, s>>>(a, cnt, off, (const float2*)terms, info);
   return hipGetLastError();
