@@ -789,7 +789,7 @@ int tree_walk_phase(nbody_ctx* c, State<T>& s, int kind, const void* tgt_pos, in
         s.ws_scratch_bytes = L.total;
       }
       for (int attempt = 0; attempt < 2 && !done; ++attempt) {
-        int info[4] = {0, 0, 0, 0};
+        int info[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         {
           TimerScope ts(c->timer, c->stream);
           HIPCHK(c, launch_tree_walk_split(c->stream, w, s.ws_scratch, L, s.ws_terms, s.ws_capacity));
@@ -797,8 +797,8 @@ int tree_walk_phase(nbody_ctx* c, State<T>& s, int kind, const void* tgt_pos, in
         HIPCHK(c, hipMemcpyAsync(info, s.ws_scratch + L.info, sizeof(info), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if (env_int("NBODY_TRACE", 0) != 0)
-          std::fprintf(stderr, "[nbody] split walk: %d terms, overflow %d, longest term-pass wave %d us (leaf %d us, node %d us)\n", info[0], info[1],
-                       info[3] >> 20, (info[3] >> 10) & 1023, info[3] & 1023);
+          std::fprintf(stderr, "[nbody] split walk: %d terms, overflow %d, %d terms per term-pass wave; longest such wave %d us (leaf %d us, node %d us; timing builds)\n",
+                       info[0], info[1], info[3], info[5] >> 20, (info[5] >> 10) & 1023, info[5] & 1023);
         if (info[1] == 0) {
           done = true;
         } else if (info[2] != 0 || info[0] > hard_cap) {

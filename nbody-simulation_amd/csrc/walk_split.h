@@ -13,7 +13,8 @@ struct WalkSplitLayout {
 };
 WalkSplitLayout walk_split_layout(int64_t n_tgt);
 
-// info (int[4] at scratch + L.info) afterwards: {total terms (low 31 bits), overflow flag, 0, 0}.
+// info (int[8] at scratch + L.info) afterwards: {total terms, term array too small, 32-bit offsets wrapped, terms per wave
+// of the term pass, ...}.
 // terms: float2[term_capacity].  When the walk needs more than term_capacity terms nothing is written to acc and the
 // overflow flag is set: the caller grows the buffer (or uses the fused walk) and calls again.
 hipError_t launch_tree_walk_split(hipStream_t s, const WalkArgs<float>& a, char* scratch, const WalkSplitLayout& L, void* terms,

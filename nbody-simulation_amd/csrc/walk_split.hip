@@ -28,7 +28,8 @@ namespace {
 // Targets per wave.  Counting is cheapest with full waves; in the term pass a wave's time grows with the number of
 // leaves its targets visit, so its waves are cut by work (see walk_pass).
 constexpr int kCountTPW = 64;
-constexpr uint32_t kTermBudget = 8192;  // terms a wave of the term pass writes, about
+constexpr uint32_t kTermBudget = 8192;  // terms a wave of the term pass writes, about (at least: see walk_total)
+constexpr uint32_t kBudgetTargets = 12; // ... or this many average targets' worth, if that is more
 
 __device__ __forceinline__ float lane_f(float v, int k) {  // k uniform
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), k));
@@ -70,19 +71,20 @@ __global__ __launch_bounds__(256) void walk_pass(const WalkArgs<float> a, uint32
   int64_t t;
   bool live;
   if (EMIT) {
-    // Waves by WORK, not by head count: wave w takes the targets t with g(t) = off[t] / kTermBudget + t / 64 == w
-    // (g never decreases: at most 64 targets, about kTermBudget terms — a target with thousands of terms walks alone,
+    // Waves by WORK, not by head count: wave w takes the targets t with g(t) = off[t] / budget + t / 64 == w
+    // (g never decreases: at most 64 targets, about `budget` terms — a target with thousands of terms walks alone,
     // and its wave is as short as its own path).  The two ends of the range by binary search.
+    const uint32_t budget = (uint32_t)info[3];  // set by walk_total
     int64_t lo = 0, hi = a.n_tgt;
     while (lo < hi) {  // first t with g(t) >= wave
       const int64_t mid = (lo + hi) >> 1;
-      if ((int64_t)(off[mid] / kTermBudget) + (mid >> 6) < wave) lo = mid + 1; else hi = mid;
+      if ((int64_t)(off[mid] / budget) + (mid >> 6) < wave) lo = mid + 1; else hi = mid;
     }
     const int64_t t0 = lo;
     hi = t0 + 64 < a.n_tgt ? t0 + 64 : a.n_tgt;
     while (lo < hi) {  // first t with g(t) > wave
       const int64_t mid = (lo + hi) >> 1;
-      if ((int64_t)(off[mid] / kTermBudget) + (mid >> 6) <= wave) lo = mid + 1; else hi = mid;
+      if ((int64_t)(off[mid] / budget) + (mid >> 6) <= wave) lo = mid + 1; else hi = mid;
     }
     if (lo == t0) return;  // no target has this number
     t = t0 + lane;
@@ -167,7 +169,7 @@ __global__ __launch_bounds__(256) void walk_pass(const WalkArgs<float> a, uint32
 #ifdef NB_WALK_TIMING
   if (EMIT && lane == 0) {  // longest wave: total us << 20 | leaf us << 10 | node us
     const long long tot = wall_clock64() - tw0;
-    atomicMax(const_cast<int*>(info) + 3, (int)(((tot / 100) << 20) | (((t_leaf / 100) & 1023) << 10) | ((t_node / 100) & 1023)));
+    atomicMax(const_cast<int*>(info) + 5, (int)(((tot / 100) << 20) | (((t_leaf / 100) & 1023) << 10) | ((t_node / 100) & 1023)));
   }
 #endif
   if (!EMIT && live) cnt[t] = n_terms;
@@ -180,6 +182,12 @@ __global__ void walk_total(const uint32_t* __restrict__ cnt, const uint32_t* __r
   // (the scan is 32 bits wide: walk_check_wrap has flagged a wrapped sum already)
   info[0] = (int)(total > 0x7fffffffull ? 0x7fffffffull : total);
   if (total > (unsigned long long)capacity) info[1] = 1;
+  // the term pass' budget per wave: enough for a dozen average targets (each wave repeats the traversal: where every
+  // target is heavy, few targets per wave only multiply that), never less than kTermBudget; a power of two
+  unsigned long long want = n > 0 ? kBudgetTargets * total / (unsigned long long)n : 0ull;
+  uint32_t budget = kTermBudget;
+  while (budget < want && budget < (1u << 30)) budget <<= 1;
+  info[3] = (int)budget;
 }
 __global__ __launch_bounds__(256) void walk_check_wrap(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off, int64_t n,
                                                        int* __restrict__ info) {
@@ -245,7 +253,7 @@ WalkSplitLayout walk_split_layout(int64_t n_tgt) {
   auto take = [&](size_t b) { size_t r = o; o += align_up(b); return r; };
   L.cnt = take(4 * n);
   L.off = take(4 * n);
-  L.info = take(16);
+  L.info = take(32);
   size_t tb = 0;
   (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tb, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)n, (hipStream_t) nullptr);
   L.cub_temp_bytes = tb;
@@ -262,7 +270,7 @@ hipError_t launch_tree_walk_split(hipStream_t s, const WalkArgs<float>& a, char*
   int* info = (int*)(scratch + L.info);
   const int64_t cwaves = (a.n_tgt + kCountTPW - 1) / kCountTPW;
   const int64_t twaves = term_capacity / kTermBudget + a.n_tgt / 64 + 2;  // upper bound of g(t) + 1
-  hipError_t e = hipMemsetAsync(info, 0, 16, s);
+  hipError_t e = hipMemsetAsync(info, 0, 32, s);
   if (e != hipSuccess) return e;
   walk_pass<false, kCountTPW, false><<<dim3((unsigned)((cwaves + 3) / 4)), dim3(256), 0, s>>>(a, cnt, nullptr, nullptr, info, term_capacity);
   size_t tb = L.cub_temp_bytes;
