@@ -7,7 +7,7 @@
 namespace nbody {
 
 constexpr int kBvhLevels = 64;    // level counters kept on the device
-constexpr int kBvhKeyDepth = 56;  // deepest node the pre-order key can express; deeper -> host builder
+constexpr int kBvhKeyDepth = 56;  // deepest level the device build follows; deeper (degenerate input) -> host builder
 
 // flags (int[] at scratch + L.flags)
 enum : int {
@@ -18,6 +18,7 @@ enum : int {
   kBvhSubCount = 4,   // subtree roots queued for bvh_subtrees
   kBvhTopCount = 5,   // nodes made by the long-node levels (they sit above the subtrees)
   kBvhRunsUsed = 6,   // chunks of long chains whose prepared run was used (diagnostic)
+  kBvhBadIndex = 7,   // bvh_emit met a node it could not number (expected while long nodes are still pending only)
   kBvhDebug = 8,      // 8 words of max-over-groups cycle counts per phase of bvh_subtrees (NB_BVH_TIMING builds)
   kBvhFlagWords = 16,
 };
@@ -25,8 +26,8 @@ enum : int {
 struct BvhBuildLayout {
   int node_cap, big_cap, chunk_cap;
   size_t flags, bigcount, chunkcount, zero_end, bigq, subq, topq, ch_node, ch_index, ch_sum, ch_box, ch_run, ch_cx, ch_cy, ch_before, pts, ids, lidx, ridx;
-  size_t nbegin, nlen, nparent, nchild, ndepth, nleaf, nkey, nbox, ncog, nmass, narrive, nmean, nsplit, nchunk0, ndone, nbad;
-  size_t keys, keys_sorted, vals, vals_sorted, rank, cub_temp, cub_temp_bytes, total;
+  size_t nbegin, nlen, nparent, nchild, ndepth, nleaf, nsize, npre, nbox, ncog, nmass, narrive, nmean, nsplit, nchunk0, ndone, nbad;
+  size_t total;
 };
 BvhBuildLayout bvh_build_layout(int64_t n, int leaf_size);
 

@@ -19,15 +19,14 @@
 // bvh_big_ranks (rank lists), bvh_big_swap.  Every node of at most kSub points is the root of a subtree that ONE
 // work-group builds completely out of LDS (bvh_subtrees): long nodes by the whole group, short ones a wave each.
 //
-// Nodes get breadth-first ids; the pre-order index the walk needs is the rank of the node's root-to-node path
-// (left-aligned, depth as tie-break) after one radix sort; `skip` is a binary search for the end of the path's
-// sub-range.  Leaves (unweighted mean in slice order, u32 wrapping mass, :98-131) and the upward pass (:133-158) run
-// bottom-up, a wave per leaf, with one arrival counter per internal node.
+// Nodes get breadth-first ids while they are made.  The upward pass (:133-158; leaves: unweighted mean in slice order,
+// u32 wrapping mass, :98-131) also counts the nodes of every subtree; the pre-order index the walk needs follows top-down
+// (node, left subtree, right subtree) for the nodes above the subtrees, and by a walk up to the nearest numbered ancestor
+// for the others; `skip` = index + subtree size.
 //
 // Anything this cannot express (NaN positions — pathfinder's minps/maxps are order-dependent there —, a node deeper than
 // the 56-bit path, more nodes than the buffers hold) raises a flag and the caller uses the host builder instead.
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
 #include <limits.h>
 #include <stdint.h>
 
@@ -72,7 +71,8 @@ struct BvhPtrs {
   int* nchild;
   int* ndepth;
   int* nleaf;
-  uint64_t* nkey;
+  int* nsize;  // nodes in the subtree (the node itself included)
+  int* npre;   // pre-order index, -1 while unknown
   float4* nbox;  // min.x, min.y, max.x, max.y
   float2* ncog;
   uint32_t* nmass;
@@ -111,7 +111,8 @@ BvhPtrs make_ptrs(char* s, const BvhBuildLayout& L) {
   a.nchild = (int*)(s + L.nchild);
   a.ndepth = (int*)(s + L.ndepth);
   a.nleaf = (int*)(s + L.nleaf);
-  a.nkey = (uint64_t*)(s + L.nkey);
+  a.nsize = (int*)(s + L.nsize);
+  a.npre = (int*)(s + L.npre);
   a.nbox = (float4*)(s + L.nbox);
   a.ncog = (float2*)(s + L.ncog);
   a.nmass = (uint32_t*)(s + L.nmass);
@@ -406,7 +407,6 @@ __device__ __forceinline__ void make_children(const BvhPtrs& a, int node, int fi
                                               bool leaf[2]) {
   const int d = a.ndepth[node];
   a.nchild[node] = first;
-  const uint64_t path = a.nkey[node] & ~63ull;
   for (int side = 0; side < 2; ++side) {
     const int id = first + side;
     const int cl = side ? len - m : m;
@@ -419,8 +419,7 @@ __device__ __forceinline__ void make_children(const BvhPtrs& a, int node, int fi
     if (!lf && d + 1 >= kBvhKeyDepth) { a.flags[kBvhFallback] = 1; lf = true; }
     leaf[side] = lf;
     a.nleaf[id] = lf ? 1 : 0;
-    const int dc = d + 1 > kBvhKeyDepth ? kBvhKeyDepth : d + 1;
-    a.nkey[id] = (path | (side ? (1ull << (64 - dc)) : 0ull)) | (uint64_t)dc;
+    a.npre[id] = -1;
     a.ndone[id] = 0;
     a.nbad[id] = 0;
   }
@@ -456,7 +455,7 @@ __global__ __launch_bounds__(256) void bvh_init(BvhPtrs a, const float2* __restr
     a.nchild[0] = -1;
     a.ndepth[0] = 0;
     a.nleaf[0] = 0;
-    a.nkey[0] = 0ull;
+    a.npre[0] = 0;  // the root comes first
     a.ndone[0] = 0;
     a.nbad[0] = 0;
     a.flags[kBvhNodeCount] = 1;
@@ -1154,7 +1153,10 @@ __device__ __forceinline__ void node_in_lds(const BvhPtrs& a, SubLds& s, int gbe
 // Centre and mass of an internal node from its two children (bvh_tree.rs:133-158)
 __device__ __forceinline__ void combine_children(const BvhPtrs& a, int node) {
   const int c0 = a.nchild[node];
-  if (c0 < 0) return;  // children were never made (buffers full; the fallback flag is up)
+  if (c0 < 0) {  // children not made (yet: a blind pass on an unfinished tree; or buffers full, the fallback flag is up)
+    a.nsize[node] = 1;
+    return;
+  }
   const float2 g0 = a.ncog[c0], g1 = a.ncog[c0 + 1];
   const uint32_t m0 = a.nmass[c0], m1 = a.nmass[c0 + 1];
   const uint32_t ms = m0 + m1;                                      // :148
@@ -1162,6 +1164,7 @@ __device__ __forceinline__ void combine_children(const BvhPtrs& a, int node) {
   const float by = (g0.y * (float)m0) + (g1.y * (float)m1);
   a.ncog[node] = make_float2(bx / (float)ms, by / (float)ms);       // :154
   a.nmass[node] = ms;
+  a.nsize[node] = 1 + a.nsize[c0] + a.nsize[c0 + 1];
 }
 
 // make_leaf (:40-54) + leaf mass and centre (:98-131) by one wave.  P: the leaf's points; wid(i): row of point i.
@@ -1193,6 +1196,7 @@ __device__ __forceinline__ void leaf_by_wave(const BvhPtrs& a, int leaf, PosPtr 
     a.nbox[leaf] = make_float4(mnx, mny, mxx, mxy);
     a.ncog[leaf] = make_float2(sx / (float)len, sy / (float)len);  // NaN for an empty leaf, as upstream
     a.nmass[leaf] = ms;
+    a.nsize[leaf] = 1;
   }
 }
 
@@ -1279,6 +1283,7 @@ __global__ __launch_bounds__(kSubWaves * 64) void bvh_subtrees(BvhPtrs a, const 
       a.nbox[c] = make_float4(box.mnx, box.mny, box.mxx, box.mxy);
       a.ncog[c] = make_float2(sx / (float)ln, sy / (float)ln);  // NaN for an empty leaf, as upstream
       a.nmass[c] = ms;
+      a.nsize[c] = 1;
     }
     __syncthreads();
     NB_STAMP(5)
@@ -1314,6 +1319,7 @@ __global__ __launch_bounds__(kSubWaves * 64) void bvh_subtrees(BvhPtrs a, const 
 __global__ __launch_bounds__(256) void bvh_top_upward(BvhPtrs a, const uint32_t* __restrict__ weight) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n_top = a.flags[kBvhTopCount];
+  if (tid == 0) a.flags[kBvhBadIndex] = 0;
   for (int e = wave; e < n_top; e += 4) {
     const int id = a.topq[e];
     if (!a.nleaf[id]) continue;
@@ -1329,30 +1335,49 @@ __global__ __launch_bounds__(256) void bvh_top_upward(BvhPtrs a, const uint32_t*
     }
     __syncthreads();
   }
+  // pre-order numbers, top down: a node, its left subtree, its right subtree (the root has number 0); the nodes inside the
+  // subtrees find theirs from here in bvh_emit
+  for (int d = 0; d <= a.flags[kBvhMaxDepth]; ++d) {
+    for (int e = tid; e < n_top; e += 256) {
+      const int id = a.topq[e];
+      if (a.ndepth[id] == d && !a.nleaf[id] && a.nlen[id] > kSub) {
+        const int c0 = a.nchild[id];
+        if (c0 >= 0) {
+          a.npre[c0] = a.npre[id] + 1;
+          a.npre[c0 + 1] = a.npre[id] + 1 + a.nsize[c0];
+        }
+      }
+    }
+    __syncthreads();
+  }
 }
 
 // ---- numbering -----------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bvh_keys(BvhPtrs a, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= a.cap) return;
-  const int m = a.flags[kBvhNodeCount] < a.cap ? a.flags[kBvhNodeCount] : a.cap;
-  keys[i] = i < m ? a.nkey[i] : ~0ull;  // unused slots sort last
-  vals[i] = (uint32_t)i;
-}
-__global__ __launch_bounds__(256) void bvh_rank(BvhPtrs a, const uint32_t* __restrict__ vals_sorted, int* __restrict__ rank) {
-  const int r = blockIdx.x * 256 + threadIdx.x;
-  const int m = a.flags[kBvhNodeCount] < a.cap ? a.flags[kBvhNodeCount] : a.cap;
-  if (r < m) rank[vals_sorted[r]] = r;
-}
-
-__global__ __launch_bounds__(256) void bvh_emit(BvhPtrs a, const int* __restrict__ rank, const uint64_t* __restrict__ keys_sorted,
-                                                float4* __restrict__ geom0, float4* __restrict__ geom1, int4* __restrict__ link,
+// Final arrays in pre-order.  A node's number: walk up to the nearest ancestor whose number is known (one of the nodes above
+// the subtrees), adding 1 per step and the left sibling's subtree where the step comes from a right child.
+__global__ __launch_bounds__(256) void bvh_emit(BvhPtrs a, float4* __restrict__ geom0, float4* __restrict__ geom1, int4* __restrict__ link,
                                                 int* __restrict__ depth_out, uint32_t* __restrict__ mass_out,
                                                 float2* __restrict__ size_out) {
   const int m = a.flags[kBvhNodeCount] < a.cap ? a.flags[kBvhNodeCount] : a.cap;
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= m) return;
-  const int idx = rank[i];
+  int idx = 0, v = i;
+  for (int guard = 0; a.npre[v] < 0 && guard <= kBvhLevels; ++guard) {
+    const int p = a.nparent[v];
+    const int c0 = a.nchild[p];
+    idx += 1 + (v == c0 ? 0 : a.nsize[c0]);
+    v = p;
+  }
+  // (this kernel also runs, blind, on trees whose long nodes are not all split yet: never write through a bad index)
+  if (a.npre[v] < 0) {
+    a.flags[kBvhBadIndex] = 1;
+    return;
+  }
+  idx += a.npre[v];
+  if (idx < 0 || idx >= m) {
+    a.flags[kBvhBadIndex] = 1;
+    return;
+  }
   const int d = a.ndepth[i];
   const float4 box = a.nbox[i];
   const float w = box.z - box.x, h = box.w - box.y;  // boundary.size = max - min (:63-66)
@@ -1361,25 +1386,7 @@ __global__ __launch_bounds__(256) void bvh_emit(BvhPtrs a, const int* __restrict
   const float tx = sse_max(w, h), ty = sse_max(h, w);  // size.max(size.yx()), main.rs:371
   geom0[idx] = make_float4(box.x, box.y, box.x + w, box.y + h);
   geom1[idx] = make_float4(cog.x, cog.y, (float)ms, tx * ty);
-  int skip;
-  if (a.nleaf[i]) {
-    skip = idx + 1;
-  } else if (d == 0) {
-    skip = m;
-  } else {
-    const uint64_t upper = (a.nkey[i] & ~63ull) + (1ull << (64 - d));  // first path after this subtree
-    if (upper == 0ull) {
-      skip = m;
-    } else {
-      int lo = idx + 1, hi = m;
-      while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (keys_sorted[mid] < upper) lo = mid + 1; else hi = mid;
-      }
-      skip = lo;
-    }
-  }
-  link[idx] = make_int4(skip, a.nbegin[i], a.nlen[i], a.nleaf[i]);
+  link[idx] = make_int4(idx + a.nsize[i], a.nbegin[i], a.nlen[i], a.nleaf[i]);  // skip: the first node after the subtree
   depth_out[idx] = d;
   mass_out[idx] = ms;
   size_out[idx] = make_float2(w, h);
@@ -1427,7 +1434,8 @@ BvhBuildLayout bvh_build_layout(int64_t n, int leaf_size) {
   L.nchild = take(4 * C);
   L.ndepth = take(4 * C);
   L.nleaf = take(4 * C);
-  L.nkey = take(8 * C);
+  L.nsize = take(4 * C);
+  L.npre = take(4 * C);
   L.nbox = take(16 * C);
   L.ncog = take(8 * C);
   L.nmass = take(4 * C);
@@ -1437,16 +1445,6 @@ BvhBuildLayout bvh_build_layout(int64_t n, int leaf_size) {
   L.nchunk0 = take(4 * C);
   L.ndone = take(4 * C);
   L.nbad = take(4 * C);
-  L.keys = take(8 * C);
-  L.keys_sorted = take(8 * C);
-  L.vals = take(4 * C);
-  L.vals_sorted = take(4 * C);
-  L.rank = take(4 * C);
-  size_t tb = 0;
-  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tb, (const uint64_t*)nullptr, (uint64_t*)nullptr, (const uint32_t*)nullptr,
-                                           (uint32_t*)nullptr, (int)C, 0, 64, (hipStream_t) nullptr);
-  L.cub_temp_bytes = tb;
-  L.cub_temp = take(tb);
   L.total = off;
   return L;
 }
@@ -1492,24 +1490,13 @@ hipError_t bvh_build_finish(hipStream_t s, const uint32_t* weight, int n, int le
                             float2* size_out) {
   BvhPtrs a = make_ptrs(scratch, L);
   const int C = L.node_cap;
-  uint64_t* keys = (uint64_t*)(scratch + L.keys);
-  uint32_t* vals = (uint32_t*)(scratch + L.vals);
-  uint32_t* vals_sorted = (uint32_t*)(scratch + L.vals_sorted);
-  uint64_t* keys_sorted = (uint64_t*)(scratch + L.keys_sorted);
-  int* rank = (int*)(scratch + L.rank);
   int64_t gs = (int64_t)n / 64 + 1;  // subtree roots
   if (gs > 2048) gs = 2048;
   bvh_subtrees<<<dim3((unsigned)gs), dim3(kSubWaves * 64), 0, s>>>(a, weight, leaf_size, sub_start);
   bvh_top_upward<<<dim3(1), dim3(256), 0, s>>>(a, weight);
   const dim3 gm((unsigned)((C + 255) / 256));
-  bvh_keys<<<gm, dim3(256), 0, s>>>(a, keys, vals);
-  size_t tb = L.cub_temp_bytes;
-  hipError_t e = hipcub::DeviceRadixSort::SortPairs((void*)(scratch + L.cub_temp), tb, (const uint64_t*)keys, keys_sorted,
-                                                    (const uint32_t*)vals, vals_sorted, C, 0, 64, s);
-  if (e != hipSuccess) return e;
-  bvh_rank<<<gm, dim3(256), 0, s>>>(a, vals_sorted, rank);
-  bvh_emit<<<gm, dim3(256), 0, s>>>(a, rank, keys_sorted, (float4*)geom0, (float4*)geom1, (int4*)link, depth_out, mass_out, size_out);
-  e = hipGetLastError();
+  bvh_emit<<<gm, dim3(256), 0, s>>>(a, (float4*)geom0, (float4*)geom1, (int4*)link, depth_out, mass_out, size_out);
+  hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   return hipMemcpyAsync(order_out, a.ID, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToDevice, s);
 }

@@ -565,7 +565,7 @@ template <class T> int bvh_build_device(nbody_ctx* c, State<T>& s) {
       std::fprintf(stderr, "[nbody] device bvh build: %d nodes, depth %d, %d subtrees, %d long-node levels, %d scan restarts, %d prepared chunk runs used\n",
                    hostf[kBvhNodeCount], hostf[kBvhMaxDepth], hostf[kBvhSubCount], lv_end, hostf[kBvhStops], hostf[kBvhRunsUsed]);
     const int m = hostf[kBvhNodeCount];
-    if (m <= 0 || m > L.node_cap) return 1;
+    if (m <= 0 || m > L.node_cap || hostf[kBvhBadIndex] != 0) return 1;
     s.cur = 1 - s.cur;
     s.h_weight_stale = true;
     s.n_nodes = m;
