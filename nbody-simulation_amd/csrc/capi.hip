@@ -115,6 +115,7 @@ template <class T> struct State {
   char* bb_scratch = nullptr;    // device BVH build
   size_t bb_scratch_bytes = 0;
   bool h_weight_stale = false;   // a device BVH build permuted the rows without touching h_weight
+  int quad_depth_hint = 0;       // depth of the last device-built quad tree (how many levels the next build sorts by)
   // split walk (walk_split.hip): counts/offsets scratch and the term array
   char* ws_scratch = nullptr;
   size_t ws_scratch_bytes = 0;
@@ -217,7 +218,7 @@ template <class T> void free_state(State<T>& s) {
   free_dev(s.pos_next); free_dev(s.acc); free_dev(s.geom0); free_dev(s.geom1); free_dev(s.link); free_dev(s.order_dev);
   free_dev(s.node_depth); free_dev(s.node_mass); free_dev(s.node_size); free_dev(s.qb_scratch); free_dev(s.bb_scratch); free_dev(s.ws_scratch); free_dev(s.ws_terms);
   s.node_aux_cap = 0; s.qb_scratch_bytes = 0; s.bb_scratch_bytes = 0; s.h_weight_stale = false;
-  s.ws_scratch_bytes = 0; s.ws_capacity = 0; s.ws_backoff = 0;
+  s.ws_scratch_bytes = 0; s.ws_capacity = 0; s.ws_backoff = 0; s.quad_depth_hint = 0;
   s.tree_host_stale = false; s.n_nodes = 0;
   s.node_cap = 0; s.n = 0; s.tree_valid = false; s.tree.clear();
   s.h_pos.clear(); s.h_weight.clear();
@@ -591,11 +592,21 @@ template <class T> int quad_build_device(nbody_ctx* c, State<T>& s) {
   auto& in = s.set[s.cur];
   auto& out = s.set[1 - s.cur];
   const T rx = (T)c->params.quad_root_x, ry = (T)c->params.quad_root_y, rh = (T)c->params.quad_root_h;
-  HIPCHK(c, quad_build_phase_a<T>(c->stream, in.pos, n, rx, ry, rh, s.qb_scratch, L, s.order_dev));
+  // the sorts only look at as many levels as the tree is expected to have: the last quad tree's depth plus three (all 31
+  // the first time, and again whenever that turns out to be too few)
+  int sort_levels = s.quad_depth_hint > 0 ? s.quad_depth_hint + 3 : 31;
   int flags[3] = {0, 0, 0};
-  HIPCHK(c, hipMemcpyAsync(flags, s.qb_scratch + L.flags, sizeof(flags), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  if (flags[0] != 0 || flags[1] <= 0) return 1;
+  for (;;) {
+    HIPCHK(c, quad_build_phase_a<T>(c->stream, in.pos, n, rx, ry, rh, s.qb_scratch, L, s.order_dev, sort_levels));
+    HIPCHK(c, hipMemcpyAsync(flags, s.qb_scratch + L.flags, sizeof(flags), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (env_int("NBODY_TRACE", 0) != 0)
+      std::fprintf(stderr, "[nbody] device quad build: sorted by %d levels, flags %d, %d nodes, depth %d\n", sort_levels, flags[0], flags[1], flags[2]);
+    if ((flags[0] & 2) != 0 && sort_levels < 31) { sort_levels = 31; continue; }
+    break;
+  }
+  if ((flags[0] & 1) != 0 || flags[1] <= 0) { s.quad_depth_hint = 0; return 1; }
+  s.quad_depth_hint = flags[2];
   const int m = flags[1];
   int rc = ensure_node_buffers<T>(c, s, (size_t)m);
   if (rc) return rc;

@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void qb_path_keys(const void* pos_, int n, T r
 
 // leaf depth of the particle at sorted position r, stored by particle index
 __global__ __launch_bounds__(256) void qb_leaf_depth(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ idx, int n,
-                                                     int* __restrict__ ld_by_index, int* __restrict__ flags) {
+                                                     int* __restrict__ ld_by_index, int* __restrict__ flags, int sort_levels) {
   int r = blockIdx.x * 256 + threadIdx.x;
   if (r >= n) return;
   int best = -1;  // longest prefix shared by 9 consecutive keys that include r
@@ -82,6 +82,9 @@ __global__ __launch_bounds__(256) void qb_leaf_depth(const uint64_t* __restrict_
     atomicOr(&flags[0], 1);  // deeper than the key can say: host builder
     ld = kLevels;
   }
+  // the sort looked at the first sort_levels child codes only: 9 keys that agree on all of them are in no particular
+  // order below, so a leaf that deep has to be found again with more levels sorted
+  if (ld > sort_levels) atomicOr(&flags[0], 2);
   ld_by_index[idx[r]] = ld;
 }
 
@@ -244,7 +247,10 @@ QuadBuildLayout quad_build_layout(int64_t n_) {
 // Phase A: everything up to the node count (flags[1]).  The caller reads flags {fallback, n_nodes, max_depth}.
 template <class T>
 hipError_t quad_build_phase_a(hipStream_t s, const void* pos, int n, T rx, T ry, T rh, char* scratch, const QuadBuildLayout& L,
-                              uint32_t* order_out) {
+                              uint32_t* order_out, int sort_levels) {
+  if (sort_levels < 1) sort_levels = 1;
+  if (sort_levels > kLevels) sort_levels = kLevels;
+  const int bit0 = 2 * (kLevels - sort_levels);  // the radix sorts skip the child codes below sort_levels
   int* flags = (int*)(scratch + L.flags);
   uint64_t* ka = (uint64_t*)(scratch + L.keys_a);
   uint64_t* kb = (uint64_t*)(scratch + L.keys_b);
@@ -270,19 +276,19 @@ hipError_t quad_build_phase_a(hipStream_t s, const void* pos, int n, T rx, T ry,
   {
     hipcub::DoubleBuffer<uint64_t> dk(ka, kb);
     hipcub::DoubleBuffer<uint32_t> dv(ia, ib);
-    e = hipcub::DeviceRadixSort::SortPairs(nullptr, need, dk, dv, n, 0, 62, s);
+    e = hipcub::DeviceRadixSort::SortPairs(nullptr, need, dk, dv, n, 0, 62, s);  // (size query: the widest sort)
     if (e != hipSuccess) return e;
     if (need > L.cub_temp_bytes) return hipErrorOutOfMemory;
-    e = hipcub::DeviceRadixSort::SortPairs(scratch + L.cub_temp, tb, dk, dv, n, 0, 62, s);
+    e = hipcub::DeviceRadixSort::SortPairs(scratch + L.cub_temp, tb, dk, dv, n, bit0, 62, s);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(qb_leaf_depth, dim3(blocks), dim3(256), 0, s, dk.Current(), dv.Current(), n, ldi, flags);
+    hipLaunchKernelGGL(qb_leaf_depth, dim3(blocks), dim3(256), 0, s, dk.Current(), dv.Current(), n, ldi, flags, sort_levels);
   }
   hipLaunchKernelGGL(qb_mask_keys, dim3(blocks), dim3(256), 0, s, kbi, ldi, n, ka, ia);
   {
     hipcub::DoubleBuffer<uint64_t> dk(ka, kb);
     hipcub::DoubleBuffer<uint32_t> dv(ia, ib);
     tb = L.cub_temp_bytes;
-    e = hipcub::DeviceRadixSort::SortPairs(scratch + L.cub_temp, tb, dk, dv, n, 0, 62, s);  // stable
+    e = hipcub::DeviceRadixSort::SortPairs(scratch + L.cub_temp, tb, dk, dv, n, bit0, 62, s);  // stable; masked keys are 0 below
     if (e != hipSuccess) return e;
     // keep the sorted keys in keys_a and the order in order_out
     if (dk.Current() != ka) {
@@ -325,8 +331,8 @@ hipError_t quad_build_phase_b(hipStream_t s, const void* pos, const uint32_t* we
   return hipGetLastError();
 }
 
-template hipError_t quad_build_phase_a<float>(hipStream_t, const void*, int, float, float, float, char*, const QuadBuildLayout&, uint32_t*);
-template hipError_t quad_build_phase_a<double>(hipStream_t, const void*, int, double, double, double, char*, const QuadBuildLayout&, uint32_t*);
+template hipError_t quad_build_phase_a<float>(hipStream_t, const void*, int, float, float, float, char*, const QuadBuildLayout&, uint32_t*, int);
+template hipError_t quad_build_phase_a<double>(hipStream_t, const void*, int, double, double, double, char*, const QuadBuildLayout&, uint32_t*, int);
 template hipError_t quad_build_phase_b<float>(hipStream_t, const void*, const uint32_t*, int, float, float, float, char*,
                                               const QuadBuildLayout&, const uint32_t*, int, int, void*, void*, void*, int*, uint32_t*);
 template hipError_t quad_build_phase_b<double>(hipStream_t, const void*, const uint32_t*, int, double, double, double, char*,

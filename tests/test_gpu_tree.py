@@ -428,3 +428,27 @@ def test_split_walk_backs_off_when_the_terms_do_not_fit(nb, monkeypatch):
             c.upload(pos, vel, w)
             out.append(c.accel_tree(C.TREE_BVH))
     assert np.array_equal(out[0], out[1])
+
+
+def test_device_quad_build_sorts_by_the_previous_depth_and_recovers_when_the_tree_got_deeper(nb, orc):
+    """The quad build's radix sorts look at (depth of the previous tree + 3) levels only; a tree that turns out deeper has
+    to be noticed and built again with all levels, bit for bit the same as ever."""
+    C = nb._capi
+    rng = np.random.default_rng(77)
+    n = 40000
+    shallow = (rng.random((n, 2)) * 1e5).astype(F32)                 # depth ~9
+    deep = shallow.copy()
+    deep[:3000] = (5e4 + rng.random((3000, 2)) * 50.0).astype(F32)   # 3000 points in a 50-unit box: ~8 levels more
+    w = np.ones(n, np.uint32)
+    with C.Context(0) as ctx:
+        ctx.set_params(theta=0.5)
+        for pos in (shallow, deep, shallow):
+            ctx.upload(pos, np.zeros_like(pos), w)
+            ctx.accel_tree(C.TREE_QUAD, pos[:8])
+            assert ctx.last_build_on_device()
+            t, o = ctx.tree_export(), orc.Quad(pos, w).flat()
+            for k in ("geom", "mass", "is_leaf", "first", "count", "skip", "order"):
+                assert np.array_equal(t[k], getattr(o, k)), k
+            assert t["max_depth"] == int(o.depth.max())
+        d_shallow, d_deep = int(orc.Quad(shallow, w).flat().depth.max()), int(orc.Quad(deep, w).flat().depth.max())
+        assert d_deep > d_shallow + 3
