@@ -215,6 +215,37 @@ int nbody_snapshot_pending(const nbody_ctx* ctx);
 int nbody_snapshot_end_f32(nbody_ctx* ctx, float* pos_xy, float* vel_xy, uint32_t* weight, uint32_t* ids, uint64_t* step_out);
 int nbody_snapshot_end_f64(nbody_ctx* ctx, double* pos_xy, double* vel_xy, uint32_t* weight, uint32_t* ids, uint64_t* step_out);
 
+/* ---- delta snapshots (the commented experiment of main.rs:107-134) ------------------------------------------ */
+/* Upstream tried, and left commented out, taking the difference of the positions across an update and printing its
+ * zstd-compressed size.  There is no behaviour or format to match; this is the device-side counterpart of that idea
+ * for the snapshot hand-off above: the POSITIONS of a snapshot, in upload (id) order, as a lossless stream of bit
+ * planes of the change against the previous delta snapshot (format "NBD1": csrc/delta_codec.h, restated in
+ * oracle/delta_codec.py).  The first stream after an upload or nbody_delta_reset is a key frame (the change against
+ * all-zero state); every later one needs all streams since the key frame applied in order.
+ * nbody_delta_begin encodes on the device (ordered after the last step; waits for the encoder to learn the size) and
+ * starts the transfer of the stream to pinned host memory on the copy stream; nbody_delta_end waits for it and copies
+ * the stream out.  *bytes_out receives the stream's size; if cap is smaller the call fails with NBODY_ERR_INVALID
+ * and the stream stays pending (nbody_delta_bound gives the worst case for n bodies).  One in flight per context. */
+int nbody_delta_begin(nbody_ctx* ctx);
+int nbody_delta_pending(const nbody_ctx* ctx);
+int nbody_delta_end(nbody_ctx* ctx, uint8_t* out, size_t cap, size_t* bytes_out, uint64_t* step_out);
+int nbody_delta_reset(nbody_ctx* ctx);
+size_t nbody_delta_bound(int64_t n, int is_f64);
+/* The receiving side (host only, no device needed): a decoder holds the keys of the last two snapshots. */
+typedef struct nbody_delta_decoder nbody_delta_decoder;
+nbody_delta_decoder* nbody_delta_decoder_create(void);
+void nbody_delta_decoder_destroy(nbody_delta_decoder* dec);
+/* Applies one stream.  A malformed, truncated or out-of-sequence stream (a delta before any key frame, another n or
+ * element size than the state) fails with NBODY_ERR_INVALID and leaves the decoder as it was. */
+int nbody_delta_decoder_apply(nbody_delta_decoder* dec, const uint8_t* stream, size_t bytes);
+const char* nbody_delta_decoder_error(const nbody_delta_decoder* dec);
+int64_t nbody_delta_decoder_count(const nbody_delta_decoder* dec);   /* bodies of the current state, -1 before a key frame */
+int nbody_delta_decoder_is_f64(const nbody_delta_decoder* dec);
+uint64_t nbody_delta_decoder_step(const nbody_delta_decoder* dec);
+/* Positions of the current state, x y per body in id order; the precision must be the stream's. */
+int nbody_delta_decoder_positions_f32(const nbody_delta_decoder* dec, float* pos_xy);
+int nbody_delta_decoder_positions_f64(const nbody_delta_decoder* dec, double* pos_xy);
+
 /* ---- frame raster: the reference's draw() (main.rs:41-72) ---------------------------------------------- */
 /* A render_px x render_px RGBA8 frame of the current rows, exactly as draw() paints `world.particles` (row order
  * = the order nbody_download returns): rows inside [0, height)^2 land on pixel (y as u32 / cell) * render_px +

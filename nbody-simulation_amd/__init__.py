@@ -11,6 +11,7 @@ There is no CPU fallback: every compute entry point raises if the HIP library or
 """
 from . import _capi  # noqa: F401
 from .world import Counting, World  # noqa: F401
+from ._capi import DeltaDecoder  # noqa: F401
 from . import scenes  # noqa: F401
 
-__all__ = ["World", "Counting", "scenes", "_capi"]
+__all__ = ["World", "Counting", "DeltaDecoder", "scenes", "_capi"]

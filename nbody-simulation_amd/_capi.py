@@ -88,6 +88,20 @@ _SIGS = {
     "nbody_snapshot_pending": (C.c_int, [_vp]),
     "nbody_snapshot_end_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_uint64)]),
     "nbody_snapshot_end_f64": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_uint64)]),
+    "nbody_delta_begin": (C.c_int, [_vp]),
+    "nbody_delta_pending": (C.c_int, [_vp]),
+    "nbody_delta_end": (C.c_int, [_vp, _vp, _sz, C.POINTER(_sz), C.POINTER(C.c_uint64)]),
+    "nbody_delta_reset": (C.c_int, [_vp]),
+    "nbody_delta_bound": (_sz, [_i64, C.c_int]),
+    "nbody_delta_decoder_create": (_vp, []),
+    "nbody_delta_decoder_destroy": (None, [_vp]),
+    "nbody_delta_decoder_apply": (C.c_int, [_vp, _vp, _sz]),
+    "nbody_delta_decoder_error": (C.c_char_p, [_vp]),
+    "nbody_delta_decoder_count": (_i64, [_vp]),
+    "nbody_delta_decoder_is_f64": (C.c_int, [_vp]),
+    "nbody_delta_decoder_step": (C.c_uint64, [_vp]),
+    "nbody_delta_decoder_positions_f32": (C.c_int, [_vp, _vp]),
+    "nbody_delta_decoder_positions_f64": (C.c_int, [_vp, _vp]),
     "nbody_render_rgba": (C.c_int, [_vp, C.c_uint32, C.c_uint32, _vp]),
     "nbody_render_rgba_dev": (C.c_int, [_vp, C.c_int64, C.c_int, _vp, _vp, _vp, C.c_uint32, C.c_uint32, _vp, _vp]),
     "nbody_selftest_exact_sum": (C.c_int, [_vp, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int64)]),
@@ -207,6 +221,53 @@ def selftest_exact_sum_chunked(x, chunk=2048):
     out, used = C.c_float(0), _i64(0)
     check(None, load().nbody_selftest_exact_sum_chunked(_ptr(x) if x.size else None, x.size, int(chunk), C.byref(out), C.byref(used)))
     return np.float32(out.value), used.value
+
+
+class DeltaDecoder:
+    """Receiving side of the delta snapshots (host only): apply every stream since the key frame, in order."""
+
+    def __init__(self):
+        self.lib = load()
+        self.h = self.lib.nbody_delta_decoder_create()
+        if not self.h:
+            raise MemoryError("nbody_delta_decoder_create")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.nbody_delta_decoder_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def apply(self, stream: bytes):
+        buf = np.frombuffer(bytes(stream), np.uint8)
+        rc = self.lib.nbody_delta_decoder_apply(self.h, buf.ctypes.data_as(C.c_void_p) if buf.size else None, buf.size)
+        if rc != 0:
+            raise NBodyError(rc, self.lib.nbody_delta_decoder_error(self.h).decode())
+
+    @property
+    def n(self) -> int:
+        return int(self.lib.nbody_delta_decoder_count(self.h))
+
+    @property
+    def step(self) -> int:
+        return int(self.lib.nbody_delta_decoder_step(self.h))
+
+    @property
+    def dtype(self):
+        return np.float64 if self.lib.nbody_delta_decoder_is_f64(self.h) else np.float32
+
+    def positions(self):
+        """Positions of the last applied snapshot, (n, 2), in upload (id) order."""
+        n, dt = self.n, self.dtype
+        if n < 0:
+            raise NBodyError(ERR_INVALID, "no key frame applied yet")
+        out = np.zeros((n, 2), dt)
+        f = self.lib.nbody_delta_decoder_positions_f64 if dt == np.float64 else self.lib.nbody_delta_decoder_positions_f32
+        rc = f(self.h, _ptr(out))
+        if rc != 0:
+            raise NBodyError(rc, "delta decoder: positions")
+        return out
 
 
 def host_tree(kind, pos, weight=None, params: "Params | None" = None):
@@ -363,6 +424,25 @@ class Context:
         f = self.lib.nbody_snapshot_end_f64 if dt == np.float64 else self.lib.nbody_snapshot_end_f32
         check(self.h, f(self.h, _ptr(pos), _ptr(vel), _ptr(w), _ptr(ids), C.byref(step)))
         return pos, vel, w, ids, step.value
+
+    def delta_begin(self):
+        """Encode the positions (id order) against the previous delta snapshot and start the stream's hand-off."""
+        check(self.h, self.lib.nbody_delta_begin(self.h))
+
+    def delta_pending(self) -> bool:
+        return bool(self.lib.nbody_delta_pending(self.h))
+
+    def delta_end(self, cap=None):
+        """-> (the stream as bytes, steps done when it was taken)."""
+        if cap is None:
+            cap = int(self.lib.nbody_delta_bound(self.n, 1 if self.dtype == np.float64 else 0))
+        buf = np.zeros(max(int(cap), 1), np.uint8)
+        size, step = _sz(0), C.c_uint64(0)
+        check(self.h, self.lib.nbody_delta_end(self.h, _ptr(buf), int(cap), C.byref(size), C.byref(step)))
+        return buf[:size.value].tobytes(), step.value
+
+    def delta_reset(self):
+        check(self.h, self.lib.nbody_delta_reset(self.h))
 
     def render(self, height=100_000, render_px=1250):
         """The reference's draw() of the current rows -> uint8 array (render_px, render_px, 4), RGBA."""

@@ -19,6 +19,8 @@
 #include "common.h"
 #include "direct_kernels.h"
 #include "bvh_build.h"
+#include "delta_codec.h"
+#include "delta_snapshot.h"
 #include "exact_sum.h"
 #include "quad_build.h"
 #include "render.h"
@@ -182,6 +184,21 @@ struct nbody_ctx {
   size_t snap_bytes2 = 0;  // bytes of one position array the staging holds
   int64_t snap_n = 0;
   bool snap_f64 = false;
+  // delta snapshots (delta_snapshot.hip): three key arrays in rotation (this / previous / the one before), the pieces
+  // of the stream on the device, the assembled stream in pinned memory
+  void* dl_keys[3] = {nullptr, nullptr, nullptr};
+  int dl_cur = 0;
+  uint8_t* dl_widths = nullptr;
+  uint32_t *dl_words = nullptr, *dl_offsets = nullptr;
+  void* dl_scan = nullptr;
+  size_t dl_scan_bytes = 0;
+  uint64_t *dl_payload = nullptr, *dl_total = nullptr, *dl_htotal = nullptr;
+  uint8_t* dl_host = nullptr;
+  int64_t dl_n = -1;
+  int dl_bits = 0;
+  bool dl_key_next = true, dl_pending = false;
+  size_t dl_stream_bytes = 0;
+  uint64_t dl_step = 0;
   uint8_t* frame_rgba = nullptr;
   uint32_t frame_px = 0;
   unsigned long long last_stats[3] = {0, 0, 0};
@@ -386,6 +403,7 @@ template <class T> int upload(nbody_ctx* c, int64_t n, const T* pos, const T* ve
   free_state(c->sf);
   free_state(c->sd);
   c->has_f32 = c->has_f64 = false;
+  c->dl_key_next = true;  // new bodies: the next delta snapshot starts a sequence
   State<T>& s = state_of<T>(c);
   using T2 = typename State<T>::T2;
   s.n = n;
@@ -1057,6 +1075,7 @@ NB_API int nbody_create(nbody_ctx** out, int device_id) {
 }
 
 static void free_snapshot(nbody_ctx* c);
+static void free_delta(nbody_ctx* c);
 NB_API void nbody_destroy(nbody_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
@@ -1070,6 +1089,7 @@ NB_API void nbody_destroy(nbody_ctx* c) {
   free_dev(c->frame_rgba);
   if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
   free_snapshot(c);
+  free_delta(c);
   if (c->snap_event) (void)hipEventDestroy(c->snap_event);
   if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1186,6 +1206,199 @@ NB_API int nbody_snapshot_end_f32(nbody_ctx* c, float* pos, float* vel, uint32_t
 NB_API int nbody_snapshot_end_f64(nbody_ctx* c, double* pos, double* vel, uint32_t* w, uint32_t* ids, uint64_t* step) {
   return snapshot_end(c, true, pos, vel, w, ids, step);
 }
+
+// ---- delta snapshots (the commented experiment of main.rs:107-134; format: delta_codec.h) -------------------------
+static void free_delta(nbody_ctx* c) {
+  for (auto& k : c->dl_keys) free_dev(k);
+  free_dev(c->dl_widths); free_dev(c->dl_words); free_dev(c->dl_offsets); free_dev(c->dl_scan); free_dev(c->dl_payload);
+  free_dev(c->dl_total);
+  if (c->dl_host) (void)hipHostFree(c->dl_host);
+  if (c->dl_htotal) (void)hipHostFree(c->dl_htotal);
+  c->dl_host = nullptr;
+  c->dl_htotal = nullptr;
+  c->dl_n = -1;
+  c->dl_bits = 0;
+  c->dl_key_next = true;
+  c->dl_pending = false;
+}
+template <class T> int delta_begin(nbody_ctx* c, State<T>& s) {
+  const int bits = (int)sizeof(T) * 8;
+  const int64_t n = s.n;
+  const size_t nblk = delta_blocks(n), npad = nblk * 64, kb = 2 * npad * sizeof(T), wb = delta_width_bytes(n);
+  if (c->dl_n != n || c->dl_bits != bits) {
+    free_delta(c);
+    for (auto& k : c->dl_keys) HIPCHK(c, hipMalloc(&k, kb ? kb : 8));
+    HIPCHK(c, hipMalloc((void**)&c->dl_widths, wb ? wb : 8));
+    HIPCHK(c, hipMalloc((void**)&c->dl_words, 2 * nblk * 4 + 8));
+    HIPCHK(c, hipMalloc((void**)&c->dl_offsets, 2 * nblk * 4 + 8));
+    c->dl_scan_bytes = delta_scan_temp_bytes(n);
+    HIPCHK(c, hipMalloc(&c->dl_scan, c->dl_scan_bytes ? c->dl_scan_bytes : 8));
+    HIPCHK(c, hipMalloc((void**)&c->dl_payload, 2 * nblk * (size_t)bits * 8 + 8));
+    HIPCHK(c, hipMalloc((void**)&c->dl_total, 8));
+    HIPCHK(c, hipHostMalloc((void**)&c->dl_host, delta_bound(n, bits), hipHostMallocDefault));
+    HIPCHK(c, hipHostMalloc((void**)&c->dl_htotal, 8, hipHostMallocDefault));
+    if (wb) HIPCHK(c, hipMemsetAsync(c->dl_widths, 0, wb, c->stream));  // the padding bytes stay zero
+    c->dl_n = n;
+    c->dl_bits = bits;
+    c->dl_key_next = true;
+  }
+  const bool key = c->dl_key_next;
+  if (key && kb)
+    for (auto& k : c->dl_keys) HIPCHK(c, hipMemsetAsync(k, 0, kb, c->stream));
+  void* cur = c->dl_keys[c->dl_cur];
+  const void* prev = c->dl_keys[(c->dl_cur + 2) % 3];
+  const void* prev2 = c->dl_keys[(c->dl_cur + 1) % 3];
+  auto& st = s.set[s.cur];
+  HIPCHK(c, launch_delta_encode<T>(c->stream, n, st.pos, st.ids, cur, prev, prev2, c->dl_widths, c->dl_words, c->dl_offsets,
+                                   c->dl_scan, c->dl_scan_bytes, c->dl_payload, c->dl_total));
+  HIPCHK(c, hipEventRecord(c->snap_event, c->stream));
+  HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->snap_event, 0));
+  // the size of the stream is known on the device only: fetch it, then start the transfer proper (which later steps overlap)
+  HIPCHK(c, hipMemcpyAsync(c->dl_htotal, c->dl_total, 8, hipMemcpyDeviceToHost, c->copy_stream));
+  HIPCHK(c, hipStreamSynchronize(c->copy_stream));
+  const uint64_t total = *c->dl_htotal;
+  if (total > 2 * nblk * (uint64_t)bits) return fail(c, NBODY_ERR_HIP, "delta_begin: the encoder reported an impossible size");
+  uint8_t* h = c->dl_host;
+  std::memset(h, 0, kDeltaHeader);
+  h[0] = 'N'; h[1] = 'B'; h[2] = 'D'; h[3] = '1';
+  h[4] = (uint8_t)bits;
+  h[5] = key ? 1 : 0;
+  const uint64_t n64 = (uint64_t)n, step = c->steps_done;
+  std::memcpy(h + 8, &n64, 8);
+  std::memcpy(h + 16, &step, 8);
+  std::memcpy(h + 24, &total, 8);
+  if (wb) HIPCHK(c, hipMemcpyAsync(h + kDeltaHeader, c->dl_widths, wb, hipMemcpyDeviceToHost, c->copy_stream));
+  if (total) HIPCHK(c, hipMemcpyAsync(h + kDeltaHeader + wb, c->dl_payload, total * 8, hipMemcpyDeviceToHost, c->copy_stream));
+  c->dl_stream_bytes = kDeltaHeader + wb + (size_t)total * 8;
+  c->dl_cur = (c->dl_cur + 1) % 3;  // the oldest keys are overwritten next time
+  c->dl_key_next = false;
+  c->dl_step = step;
+  c->dl_pending = true;
+  return NBODY_OK;
+}
+NB_API int nbody_delta_begin(nbody_ctx* c) {
+  if (!c) return NBODY_ERR_INVALID;
+  if (!c->has_f32 && !c->has_f64) return fail(c, NBODY_ERR_INVALID, "delta_begin: no particles uploaded");
+  if (c->dl_pending) return fail(c, NBODY_ERR_INVALID, "delta_begin: a stream is still pending (take it with nbody_delta_end)");
+  HIPCHK(c, hipSetDevice(c->device));
+  return c->has_f32 ? delta_begin<float>(c, c->sf) : delta_begin<double>(c, c->sd);
+}
+NB_API int nbody_delta_pending(const nbody_ctx* c) { return c && c->dl_pending ? 1 : 0; }
+NB_API int nbody_delta_end(nbody_ctx* c, uint8_t* out, size_t cap, size_t* bytes_out, uint64_t* step_out) {
+  if (!c) return NBODY_ERR_INVALID;
+  if (!c->dl_pending) return fail(c, NBODY_ERR_INVALID, "delta_end: no stream pending");
+  if (bytes_out) *bytes_out = c->dl_stream_bytes;
+  if (step_out) *step_out = c->dl_step;
+  if (!out || cap < c->dl_stream_bytes) return fail(c, NBODY_ERR_INVALID, "delta_end: the output buffer is smaller than the stream");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->copy_stream));
+  std::memcpy(out, c->dl_host, c->dl_stream_bytes);
+  c->dl_pending = false;
+  return NBODY_OK;
+}
+NB_API int nbody_delta_reset(nbody_ctx* c) {
+  if (!c) return NBODY_ERR_INVALID;
+  if (c->dl_pending) return fail(c, NBODY_ERR_INVALID, "delta_reset: a stream is still pending");
+  c->dl_key_next = true;
+  return NBODY_OK;
+}
+NB_API size_t nbody_delta_bound(int64_t n, int is_f64) { return n < 0 ? 0 : delta_bound(n, is_f64 ? 64 : 32); }
+
+// The receiving side: plain host code (the consumer of a snapshot is a host thread, main.rs:147-150).
+struct nbody_delta_decoder {
+  int bits = 0;
+  int64_t n = -1;
+  uint64_t step = 0;
+  std::vector<uint64_t> prev, prev2, next;  // keys, x then y, 64 * ceil(n/64) each (u32 keys are stored widened)
+  std::string err;
+};
+static int dec_fail(nbody_delta_decoder* d, const char* msg) {
+  d->err = msg;
+  return NBODY_ERR_INVALID;
+}
+NB_API nbody_delta_decoder* nbody_delta_decoder_create(void) { return new (std::nothrow) nbody_delta_decoder(); }
+NB_API void nbody_delta_decoder_destroy(nbody_delta_decoder* d) { delete d; }
+NB_API const char* nbody_delta_decoder_error(const nbody_delta_decoder* d) { return d ? d->err.c_str() : "null decoder"; }
+NB_API int64_t nbody_delta_decoder_count(const nbody_delta_decoder* d) { return d ? d->n : -1; }
+NB_API int nbody_delta_decoder_is_f64(const nbody_delta_decoder* d) { return d && d->bits == 64 ? 1 : 0; }
+NB_API uint64_t nbody_delta_decoder_step(const nbody_delta_decoder* d) { return d ? d->step : 0; }
+NB_API int nbody_delta_decoder_apply(nbody_delta_decoder* d, const uint8_t* stream, size_t bytes) {
+  if (!d) return NBODY_ERR_INVALID;
+  if (!stream || bytes < kDeltaHeader) return dec_fail(d, "delta stream: shorter than its header");
+  if (std::memcmp(stream, "NBD1", 4) != 0) return dec_fail(d, "delta stream: bad magic");
+  const int bits = stream[4];
+  const int key = stream[5];
+  if ((bits != 32 && bits != 64) || key > 1 || stream[6] || stream[7]) return dec_fail(d, "delta stream: bad header");
+  uint64_t n64, step, total;
+  std::memcpy(&n64, stream + 8, 8);
+  std::memcpy(&step, stream + 16, 8);
+  std::memcpy(&total, stream + 24, 8);
+  if (n64 > 0x7fffffffULL) return dec_fail(d, "delta stream: body count out of range");
+  const int64_t n = (int64_t)n64;
+  const size_t nblk = delta_blocks(n), npad = nblk * 64, wb = delta_width_bytes(n);
+  if (total > 2 * nblk * (uint64_t)bits || bytes != kDeltaHeader + wb + (size_t)total * 8)
+    return dec_fail(d, "delta stream: size does not match its header");
+  if (!key && (d->n != n || d->bits != bits))
+    return dec_fail(d, d->n < 0 ? "delta stream: a delta before any key frame" : "delta stream: another body count or precision than the state");
+  const uint8_t* widths = stream + kDeltaHeader;
+  uint64_t sum = 0;
+  for (size_t i = 0; i < 2 * nblk; ++i) {
+    const int w = widths[i] & 127;
+    if (w > bits) return dec_fail(d, "delta stream: a width exceeds the element size");
+    sum += (uint64_t)w;
+  }
+  for (size_t i = 2 * nblk; i < wb; ++i)
+    if (widths[i]) return dec_fail(d, "delta stream: non-zero padding");
+  if (sum != total) return dec_fail(d, "delta stream: the widths do not add up to the payload");
+  // valid from here on: the state may change
+  if (key) {
+    d->prev.assign(2 * npad, 0);
+    d->prev2.assign(2 * npad, 0);
+  }
+  d->next.assign(2 * npad, 0);
+  const uint64_t mask = bits == 64 ? ~0ull : 0xFFFFFFFFull;
+  const uint8_t* pay = stream + kDeltaHeader + wb;
+  for (size_t blk = 0; blk < nblk; ++blk)
+    for (int co = 0; co < 2; ++co) {
+      const int wbyte = widths[2 * blk + co], w = wbyte & 127;
+      uint64_t z[64] = {0};
+      for (int b = 0; b < w; ++b) {
+        uint64_t plane;
+        std::memcpy(&plane, pay, 8);
+        pay += 8;
+        for (int l = 0; l < 64; ++l) z[l] |= ((plane >> l) & 1ull) << b;
+      }
+      const size_t base = (size_t)co * npad + blk * 64;
+      for (int l = 0; l < 64; ++l) {
+        const uint64_t p1 = d->prev[base + l], p2 = d->prev2[base + l];
+        const uint64_t pred = (wbyte & 128) ? (p1 + (p1 - p2)) : p1;
+        uint64_t r;
+        if (bits == 64) r = delta_unzigzag(z[l]);
+        else r = (uint64_t)delta_unzigzag((uint32_t)z[l]);
+        d->next[base + l] = (pred + r) & mask;
+      }
+    }
+  d->prev2.swap(d->prev);
+  d->prev.swap(d->next);
+  d->n = n;
+  d->bits = bits;
+  d->step = step;
+  d->err.clear();
+  return NBODY_OK;
+}
+template <class T, class K> static int decoder_positions(const nbody_delta_decoder* d, T* pos) {
+  if (!d || d->n < 0) return NBODY_ERR_INVALID;
+  if (d->bits != (int)sizeof(T) * 8 || (d->n > 0 && !pos)) return NBODY_ERR_INVALID;
+  const size_t npad = delta_blocks(d->n) * 64;
+  for (int64_t i = 0; i < d->n; ++i)
+    for (int co = 0; co < 2; ++co) {
+      const K u = delta_unkey((K)d->prev[(size_t)co * npad + (size_t)i]);
+      std::memcpy(&pos[2 * i + co], &u, sizeof(T));
+    }
+  return NBODY_OK;
+}
+NB_API int nbody_delta_decoder_positions_f32(const nbody_delta_decoder* d, float* pos) { return decoder_positions<float, uint32_t>(d, pos); }
+NB_API int nbody_delta_decoder_positions_f64(const nbody_delta_decoder* d, double* pos) { return decoder_positions<double, uint64_t>(d, pos); }
 
 template <class T> int render_rows(nbody_ctx* c, State<T>& s, uint32_t height, uint32_t render_px, uint8_t* rgba_out) {
   auto& st = s.set[s.cur];

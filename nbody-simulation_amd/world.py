@@ -61,6 +61,15 @@ class World:
         """-> (position, velocity, weight, ids, updates) of the pending snapshot."""
         return self.ctx.snapshot_end()
 
+    def delta_begin(self):
+        """Like snapshot_begin, but hands over only what changed: the positions, in id order, as a lossless stream
+        of the change against the previous delta snapshot (the idea of the commented experiment, main.rs:107-134)."""
+        self.ctx.delta_begin()
+
+    def delta_end(self):
+        """-> (stream bytes, updates); feed the streams in order to a `DeltaDecoder`."""
+        return self.ctx.delta_end()
+
     def frame(self, height=100_000, render_px=1250):
         """The frame the reference's render thread would draw from these particles (`draw`, main.rs:41-72):
         uint8 array (render_px, render_px, 4), RGBA."""
