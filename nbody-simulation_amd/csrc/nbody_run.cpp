@@ -2,8 +2,11 @@
 // generator: the reference's own is unseeded) stepped through the C ABI, printing the reference's once-a-second
 // block (ups / step / Counting, main.rs:149-156).  The window and the channel of the reference are out of scope; the frame
 // its render thread paints (draw, main.rs:41-72) can be written out instead of shown.
-//   nbody_run [steps=100] [bvh|quad|direct] [seed] [frame_every=0] [frame_prefix=frame]
+//   nbody_run [steps=100] [bvh|quad|direct] [seed] [frame_every=0] [frame_prefix=frame] [delta_every=0]
 // frame_every = k > 0: every k-th step <frame_prefix>_<step>.pam (1250 x 1250 RGBA, Netpbm PAM) is written.
+// delta_every = k > 0: every k-th step the positions are taken as a delta stream and the two lines of the commented
+// experiment of main.rs:124-133 are printed ("raw: <bytes>" / "comp: <bytes>"); the streams are applied to a decoder and
+// its state is compared with the device's at the end.
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -56,7 +59,9 @@ int main(int argc, char** argv) {
   uint64_t seed = argc > 3 ? std::strtoull(argv[3], nullptr, 0) : 0xC0FFEEull;
   const int frame_every = argc > 4 ? std::atoi(argv[4]) : 0;
   const char* frame_prefix = argc > 5 ? argv[5] : "frame";
-  std::vector<uint8_t> frame;
+  const int delta_every = argc > 6 ? std::atoi(argv[6]) : 0;
+  std::vector<uint8_t> frame, stream;
+  nbody_delta_decoder* dec = delta_every > 0 ? nbody_delta_decoder_create() : nullptr;
   try {
     World world(scene(seed), method);
     std::printf("len: %zu\n", world.particles.size());                // main.rs:343
@@ -76,6 +81,12 @@ int main(int argc, char** argv) {
           std::fclose(f);
         }
       }
+      if (delta_every > 0 && updates % delta_every == 0) {
+        world.delta_snapshot(stream);
+        std::printf("raw: %zu\ncomp: %zu\n", world.particles.size() * 8, stream.size());
+        if (nbody_delta_decoder_apply(dec, stream.data(), stream.size()) != NBODY_OK)
+          throw std::runtime_error(nbody_delta_decoder_error(dec));
+      }
       auto now = std::chrono::steady_clock::now();
       if (std::chrono::duration<double>(now - t0).count() >= 1.0 || s + 1 == steps) {
         std::printf("ups: %ld\nstep: %ld\nCounting { build_bvh: %.6f, sum_gravity: %.6f, post_calculations: %.6f }\n",
@@ -84,13 +95,30 @@ int main(int argc, char** argv) {
         t0 = now;
       }
     }
+    if (dec && nbody_delta_decoder_count(dec) >= 0) {   // what the receiver holds is what the device held at the last stream
+      if (steps % delta_every != 0) {
+        world.delta_snapshot(stream);
+        if (nbody_delta_decoder_apply(dec, stream.data(), stream.size()) != NBODY_OK) throw std::runtime_error(nbody_delta_decoder_error(dec));
+      }
+      std::vector<float> got(2 * world.particles.size()), pos;
+      std::vector<uint32_t> ids;
+      nbody_delta_decoder_positions_f32(dec, got.data());
+      world.rows(pos, ids);
+      size_t bad = 0;
+      for (size_t r = 0; r < ids.size(); ++r)
+        bad += std::memcmp(&got[2 * (size_t)ids[r]], &pos[2 * r], 8) != 0;
+      std::printf("delta streams: receiver state differs from the device in %zu of %zu bodies\n", bad, ids.size());
+      if (bad) throw std::runtime_error("delta round trip failed");
+    }
     const auto& ps = world.snapshot();
     double cx = 0, cy = 0;
     for (auto& q : ps) { cx += q.position.x; cy += q.position.y; }
     std::printf("centroid after %d steps: (%.3f, %.3f)\n", steps, cx / ps.size(), cy / ps.size());
   } catch (const std::exception& e) {
     std::fprintf(stderr, "nbody_run: %s\n", e.what());
+    nbody_delta_decoder_destroy(dec);
     return 1;
   }
+  nbody_delta_decoder_destroy(dec);
   return 0;
 }

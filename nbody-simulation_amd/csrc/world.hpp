@@ -67,6 +67,25 @@ class World {
     return particles;
   }
 
+  // The hand-off as a delta stream (the experiment of main.rs:107-134; nbody_delta_* in nbody_hip.h): positions in the
+  // order `init` had, as the change against the previous stream.  Returns `updates` at the time of the snapshot.
+  uint64_t delta_snapshot(std::vector<uint8_t>& stream) {
+    check(nbody_delta_begin(ctx_), "nbody_delta_begin");
+    stream.resize(nbody_delta_bound((int64_t)particles.size(), 0));
+    size_t bytes = 0;
+    uint64_t step = 0;
+    check(nbody_delta_end(ctx_, stream.data(), stream.size(), &bytes, &step), "nbody_delta_end");
+    stream.resize(bytes);
+    return step;
+  }
+
+  // Row r of the device image is the particle `init[ids[r]]` (the BVH build permutes the rows every step).
+  void rows(std::vector<float>& pos, std::vector<uint32_t>& ids) {
+    pos.resize(2 * particles.size());
+    ids.resize(particles.size());
+    check(nbody_download_f32(ctx_, pos.data(), nullptr, nullptr, ids.data()), "nbody_download_f32");
+  }
+
   // draw(&particles, frame), main.rs:41-72: the render_px x render_px RGBA frame of the current particles.
   void draw(std::vector<uint8_t>& frame, uint32_t height = 100000, uint32_t render_px = 1250) {
     frame.resize((size_t)render_px * render_px * 4);

@@ -142,3 +142,22 @@ def test_full_size_round_trip_and_ratio(nb):
         assert sizes[3] < 0.6 * raw, sizes
     finally:
         world.close()
+
+
+def test_headless_driver_prints_the_experiments_two_lines_and_round_trips(nb):
+    """nbody_run ... delta_every: "raw:" / "comp:" as the commented code of main.rs:124-133 would print them, and the
+    C++ receiver (nbody_delta_decoder_* through csrc/world.hpp) ends with the device's positions."""
+    import os
+    import re
+    import subprocess
+    exe = os.path.join(os.path.dirname(nb._capi.LIB_PATH), "nbody_run")
+    if not os.path.exists(exe):
+        pytest.skip("nbody_run not built")
+    r = subprocess.run([exe, "7", "bvh", "777", "0", "f", "2"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    n = int(re.search(r"len: (\d+)", r.stdout).group(1))
+    raw = [int(v) for v in re.findall(r"raw: (\d+)", r.stdout)]
+    comp = [int(v) for v in re.findall(r"comp: (\d+)", r.stdout)]
+    assert raw == [8 * n] * 3 and len(comp) == 3
+    assert comp[0] > 0.9 * raw[0] and comp[2] < 0.5 * raw[0]          # key frame, then deltas
+    assert f"differs from the device in 0 of {n} bodies" in r.stdout
