@@ -20,6 +20,7 @@
 #include "direct_kernels.h"
 #include "bvh_build.h"
 #include "delta_codec.h"
+#include "delta_decoder.hpp"
 #include "delta_snapshot.h"
 #include "exact_sum.h"
 #include "quad_build.h"
@@ -1304,101 +1305,26 @@ NB_API int nbody_delta_reset(nbody_ctx* c) {
 }
 NB_API size_t nbody_delta_bound(int64_t n, int is_f64) { return n < 0 ? 0 : delta_bound(n, is_f64 ? 64 : 32); }
 
-// The receiving side: plain host code (the consumer of a snapshot is a host thread, main.rs:147-150).
+// The receiving side: plain host code (delta_decoder.hpp; the consumer of a snapshot is a host thread, main.rs:147-150).
 struct nbody_delta_decoder {
-  int bits = 0;
-  int64_t n = -1;
-  uint64_t step = 0;
-  std::vector<uint64_t> prev, prev2, next;  // keys, x then y, 64 * ceil(n/64) each (u32 keys are stored widened)
-  std::string err;
+  DeltaDecoder d;
 };
-static int dec_fail(nbody_delta_decoder* d, const char* msg) {
-  d->err = msg;
-  return NBODY_ERR_INVALID;
-}
 NB_API nbody_delta_decoder* nbody_delta_decoder_create(void) { return new (std::nothrow) nbody_delta_decoder(); }
 NB_API void nbody_delta_decoder_destroy(nbody_delta_decoder* d) { delete d; }
-NB_API const char* nbody_delta_decoder_error(const nbody_delta_decoder* d) { return d ? d->err.c_str() : "null decoder"; }
-NB_API int64_t nbody_delta_decoder_count(const nbody_delta_decoder* d) { return d ? d->n : -1; }
-NB_API int nbody_delta_decoder_is_f64(const nbody_delta_decoder* d) { return d && d->bits == 64 ? 1 : 0; }
-NB_API uint64_t nbody_delta_decoder_step(const nbody_delta_decoder* d) { return d ? d->step : 0; }
+NB_API const char* nbody_delta_decoder_error(const nbody_delta_decoder* d) { return d ? d->d.err.c_str() : "null decoder"; }
+NB_API int64_t nbody_delta_decoder_count(const nbody_delta_decoder* d) { return d ? d->d.n : -1; }
+NB_API int nbody_delta_decoder_is_f64(const nbody_delta_decoder* d) { return d && d->d.bits == 64 ? 1 : 0; }
+NB_API uint64_t nbody_delta_decoder_step(const nbody_delta_decoder* d) { return d ? d->d.step : 0; }
 NB_API int nbody_delta_decoder_apply(nbody_delta_decoder* d, const uint8_t* stream, size_t bytes) {
   if (!d) return NBODY_ERR_INVALID;
-  if (!stream || bytes < kDeltaHeader) return dec_fail(d, "delta stream: shorter than its header");
-  if (std::memcmp(stream, "NBD1", 4) != 0) return dec_fail(d, "delta stream: bad magic");
-  const int bits = stream[4];
-  const int key = stream[5];
-  if ((bits != 32 && bits != 64) || key > 1 || stream[6] || stream[7]) return dec_fail(d, "delta stream: bad header");
-  uint64_t n64, step, total;
-  std::memcpy(&n64, stream + 8, 8);
-  std::memcpy(&step, stream + 16, 8);
-  std::memcpy(&total, stream + 24, 8);
-  if (n64 > 0x7fffffffULL) return dec_fail(d, "delta stream: body count out of range");
-  const int64_t n = (int64_t)n64;
-  const size_t nblk = delta_blocks(n), npad = nblk * 64, wb = delta_width_bytes(n);
-  if (total > 2 * nblk * (uint64_t)bits || bytes != kDeltaHeader + wb + (size_t)total * 8)
-    return dec_fail(d, "delta stream: size does not match its header");
-  if (!key && (d->n != n || d->bits != bits))
-    return dec_fail(d, d->n < 0 ? "delta stream: a delta before any key frame" : "delta stream: another body count or precision than the state");
-  const uint8_t* widths = stream + kDeltaHeader;
-  uint64_t sum = 0;
-  for (size_t i = 0; i < 2 * nblk; ++i) {
-    const int w = widths[i] & 127;
-    if (w > bits) return dec_fail(d, "delta stream: a width exceeds the element size");
-    sum += (uint64_t)w;
-  }
-  for (size_t i = 2 * nblk; i < wb; ++i)
-    if (widths[i]) return dec_fail(d, "delta stream: non-zero padding");
-  if (sum != total) return dec_fail(d, "delta stream: the widths do not add up to the payload");
-  // valid from here on: the state may change
-  if (key) {
-    d->prev.assign(2 * npad, 0);
-    d->prev2.assign(2 * npad, 0);
-  }
-  d->next.assign(2 * npad, 0);
-  const uint64_t mask = bits == 64 ? ~0ull : 0xFFFFFFFFull;
-  const uint8_t* pay = stream + kDeltaHeader + wb;
-  for (size_t blk = 0; blk < nblk; ++blk)
-    for (int co = 0; co < 2; ++co) {
-      const int wbyte = widths[2 * blk + co], w = wbyte & 127;
-      uint64_t z[64] = {0};
-      for (int b = 0; b < w; ++b) {
-        uint64_t plane;
-        std::memcpy(&plane, pay, 8);
-        pay += 8;
-        for (int l = 0; l < 64; ++l) z[l] |= ((plane >> l) & 1ull) << b;
-      }
-      const size_t base = (size_t)co * npad + blk * 64;
-      for (int l = 0; l < 64; ++l) {
-        const uint64_t p1 = d->prev[base + l], p2 = d->prev2[base + l];
-        const uint64_t pred = (wbyte & 128) ? (p1 + (p1 - p2)) : p1;
-        uint64_t r;
-        if (bits == 64) r = delta_unzigzag(z[l]);
-        else r = (uint64_t)delta_unzigzag((uint32_t)z[l]);
-        d->next[base + l] = (pred + r) & mask;
-      }
-    }
-  d->prev2.swap(d->prev);
-  d->prev.swap(d->next);
-  d->n = n;
-  d->bits = bits;
-  d->step = step;
-  d->err.clear();
-  return NBODY_OK;
+  return d->d.apply(stream, bytes) ? NBODY_OK : NBODY_ERR_INVALID;
 }
-template <class T, class K> static int decoder_positions(const nbody_delta_decoder* d, T* pos) {
-  if (!d || d->n < 0) return NBODY_ERR_INVALID;
-  if (d->bits != (int)sizeof(T) * 8 || (d->n > 0 && !pos)) return NBODY_ERR_INVALID;
-  const size_t npad = delta_blocks(d->n) * 64;
-  for (int64_t i = 0; i < d->n; ++i)
-    for (int co = 0; co < 2; ++co) {
-      const K u = delta_unkey((K)d->prev[(size_t)co * npad + (size_t)i]);
-      std::memcpy(&pos[2 * i + co], &u, sizeof(T));
-    }
-  return NBODY_OK;
+NB_API int nbody_delta_decoder_positions_f32(const nbody_delta_decoder* d, float* pos) {
+  return d && d->d.positions<float, uint32_t>(pos) ? NBODY_OK : NBODY_ERR_INVALID;
 }
-NB_API int nbody_delta_decoder_positions_f32(const nbody_delta_decoder* d, float* pos) { return decoder_positions<float, uint32_t>(d, pos); }
-NB_API int nbody_delta_decoder_positions_f64(const nbody_delta_decoder* d, double* pos) { return decoder_positions<double, uint64_t>(d, pos); }
+NB_API int nbody_delta_decoder_positions_f64(const nbody_delta_decoder* d, double* pos) {
+  return d && d->d.positions<double, uint64_t>(pos) ? NBODY_OK : NBODY_ERR_INVALID;
+}
 
 template <class T> int render_rows(nbody_ctx* c, State<T>& s, uint32_t height, uint32_t render_px, uint8_t* rgba_out) {
   auto& st = s.set[s.cur];

@@ -1,0 +1,147 @@
+// Host-only harness for the delta-stream decoder (nbody-simulation_amd/csrc/delta_decoder.hpp), built by
+// tests/test_native_sanitizers.py with -fsanitize=address,undefined.  The decoder reads bytes that come from outside:
+// it is fed valid streams (from a straight-line encoder written here for the purpose), then thousands of damaged ones
+// (bit flips, truncations, spliced headers, random bytes).  Checks: no sanitizer report; a valid stream decodes to the
+// input bit for bit; a rejected stream leaves the state exactly as it was; an accepted damaged stream leaves a
+// consistent state (sizes match the header it carried).
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+
+#include "../../nbody-simulation_amd/csrc/delta_decoder.hpp"
+
+using namespace nbody;
+
+template <class K> struct Enc {
+  std::vector<K> prev, prev2;
+  bool key_next = true;
+  std::vector<uint8_t> encode(const std::vector<K>& bits_xy, uint64_t step) {  // bits_xy: x y per body, raw float bits
+    const int64_t n = (int64_t)bits_xy.size() / 2;
+    const size_t nblk = delta_blocks(n), npad = nblk * 64, wb = delta_width_bytes(n);
+    std::vector<K> cur(2 * npad, 0);
+    for (int64_t i = 0; i < n; ++i)
+      for (int c = 0; c < 2; ++c) cur[(size_t)c * npad + (size_t)i] = delta_key(bits_xy[2 * (size_t)i + c]);
+    if (key_next || prev.size() != cur.size()) {
+      prev.assign(2 * npad, 0);
+      prev2.assign(2 * npad, 0);
+      key_next = true;
+    }
+    std::vector<uint8_t> widths(wb, 0);
+    std::vector<uint64_t> words;
+    for (size_t blk = 0; blk < nblk; ++blk)
+      for (int c = 0; c < 2; ++c) {
+        K z0[64], z1[64], m0 = 0, m1 = 0;
+        for (int l = 0; l < 64; ++l) {
+          const size_t at = (size_t)c * npad + blk * 64 + l;
+          z0[l] = delta_zigzag((K)(cur[at] - prev[at]));
+          z1[l] = delta_zigzag((K)(cur[at] - (K)(prev[at] + (K)(prev[at] - prev2[at]))));
+          m0 |= z0[l];
+          m1 |= z1[l];
+        }
+        int w0 = 0, w1 = 0;
+        while (w0 < (int)sizeof(K) * 8 && (m0 >> w0)) ++w0;
+        while (w1 < (int)sizeof(K) * 8 && (m1 >> w1)) ++w1;
+        const int pred = w1 < w0, w = pred ? w1 : w0;
+        const K* z = pred ? z1 : z0;
+        widths[2 * blk + c] = (uint8_t)(w | (pred << 7));
+        for (int b = 0; b < w; ++b) {
+          uint64_t plane = 0;
+          for (int l = 0; l < 64; ++l) plane |= (uint64_t)((z[l] >> b) & 1) << l;
+          words.push_back(plane);
+        }
+      }
+    std::vector<uint8_t> s(kDeltaHeader + wb + words.size() * 8, 0);
+    std::memcpy(s.data(), "NBD1", 4);
+    s[4] = (uint8_t)(sizeof(K) * 8);
+    s[5] = key_next ? 1 : 0;
+    const uint64_t n64 = (uint64_t)n, total = words.size();
+    std::memcpy(&s[8], &n64, 8);
+    std::memcpy(&s[16], &step, 8);
+    std::memcpy(&s[24], &total, 8);
+    if (wb) std::memcpy(&s[kDeltaHeader], widths.data(), wb);
+    if (total) std::memcpy(&s[kDeltaHeader + wb], words.data(), total * 8);
+    prev2.swap(prev);
+    prev = cur;
+    key_next = false;
+    return s;
+  }
+};
+
+template <class T, class K> static int run(int n, unsigned seed) {
+  std::mt19937_64 rng(seed);
+  std::vector<T> pos(2 * (size_t)n), vel(2 * (size_t)n), got(2 * (size_t)n + 2);
+  std::uniform_real_distribution<double> u(0.0, 1e5);
+  std::normal_distribution<double> g(0.0, 1.0);
+  for (auto& p : pos) p = (T)u(rng);
+  for (auto& v : vel) v = (T)g(rng);
+  Enc<K> enc;
+  DeltaDecoder dec;
+  std::vector<std::vector<uint8_t>> streams;
+  for (int k = 0; k < 4; ++k) {
+    std::vector<K> bits(2 * (size_t)n);
+    if (n) std::memcpy(bits.data(), pos.data(), bits.size() * sizeof(K));
+    streams.push_back(enc.encode(bits, (uint64_t)k));
+    if (!dec.apply(streams.back().data(), streams.back().size())) { std::printf("MISMATCH: valid stream refused: %s\n", dec.err.c_str()); return 1; }
+    if (!dec.positions<T, K>(got.data()) || (n && std::memcmp(got.data(), pos.data(), 2 * (size_t)n * sizeof(T)) != 0)) {
+      std::printf("MISMATCH: round trip n=%d k=%d\n", n, k);
+      return 1;
+    }
+    for (size_t i = 0; i < pos.size(); ++i) {
+      vel[i] = (T)(vel[i] + (T)(0.01 * g(rng)));
+      pos[i] = (T)(pos[i] + vel[i] * (T)0.1);
+    }
+  }
+  // damaged streams against a decoder holding the state after streams[0..2]
+  long refused = 0, accepted = 0;
+  for (int trial = 0; trial < 4000; ++trial) {
+    DeltaDecoder d;
+    for (int k = 0; k < 3; ++k) d.apply(streams[k].data(), streams[k].size());
+    const DeltaDecoder before = d;
+    std::vector<uint8_t> s = streams[3];
+    switch (trial % 6) {
+      case 0: if (!s.empty()) s[rng() % s.size()] ^= (uint8_t)(1u << (rng() % 8)); break;           // one bit anywhere
+      case 1: s.resize(rng() % (s.size() + 1)); break;                                                // truncated
+      case 2: if (s.size() > 8) s[4 + rng() % 28] = (uint8_t)rng(); break;                            // header byte
+      case 3: for (auto& b : s) if (rng() % 16 == 0) b = (uint8_t)rng(); break;                       // scattered noise
+      case 4: { const size_t wb = delta_width_bytes(n); if (wb) s[kDeltaHeader + rng() % wb] = (uint8_t)rng(); break; }  // a width byte
+      default: s.insert(s.end(), (size_t)(rng() % 64), (uint8_t)rng()); break;                        // trailing bytes
+    }
+    const bool ok = d.apply(s.empty() ? nullptr : s.data(), s.size());
+    if (!ok) {
+      ++refused;
+      if (d.n != before.n || d.bits != before.bits || d.step != before.step || d.prev != before.prev || d.prev2 != before.prev2) {
+        std::printf("MISMATCH: a refused stream changed the state (trial %d)\n", trial);
+        return 1;
+      }
+    } else {
+      ++accepted;
+      const size_t npad = delta_blocks(d.n) * 64;
+      if (d.prev.size() != 2 * npad || d.prev2.size() != 2 * npad) { std::printf("MISMATCH: inconsistent state (trial %d)\n", trial); return 1; }
+      std::vector<T> out(2 * (size_t)d.n + 2);
+      if (!d.positions<T, K>(out.data())) { std::printf("MISMATCH: positions after an accepted stream (trial %d)\n", trial); return 1; }
+    }
+  }
+  std::printf("n=%d %zu-bit: 4 valid streams round trip; 4000 damaged streams: %ld refused, %ld accepted\n", n, sizeof(K) * 8, refused, accepted);
+  return 0;
+}
+
+int main() {
+  int rc = 0;
+  for (int n : {0, 1, 64, 65, 1000}) {
+    rc |= run<float, uint32_t>(n, 100u + (unsigned)n);
+    rc |= run<double, uint64_t>(n, 200u + (unsigned)n);
+  }
+  // pure noise
+  std::mt19937_64 rng(7);
+  DeltaDecoder d;
+  for (int t = 0; t < 20000; ++t) {
+    std::vector<uint8_t> s((size_t)(rng() % 200));
+    for (auto& b : s) b = (uint8_t)rng();
+    if (s.size() >= 8 && t % 2) { std::memcpy(s.data(), "NBD1", 4); s[4] = (t % 4 == 1) ? 32 : 64; s[5] = (uint8_t)(t % 3 == 0); s[6] = s[7] = 0; }
+    if (s.size() >= 16 && t % 2) { uint64_t n = rng() % 300; std::memcpy(&s[8], &n, 8); }
+    d.apply(s.empty() ? nullptr : s.data(), s.size());
+  }
+  if (rc == 0) std::printf("OK\n");
+  return rc;
+}

@@ -1,5 +1,6 @@
 """CPU sanitizer runs (GPU AddressSanitizer is not available on the pool): the product's host-side tree builders
-under ASan+UBSan and under TSan (they run subtrees on std::threads), and the oracle under ASan+UBSan."""
+under ASan+UBSan and under TSan (they run subtrees on std::threads), the delta-stream decoder under ASan+UBSan on
+damaged input, and the oracle under ASan+UBSan."""
 import os
 import subprocess
 import sys
@@ -10,9 +11,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "tests", "native", "tree_build_sanitize.cpp")
 
 
-def _build_and_run(tmp_path, flags, env_extra=None):
-    exe = str(tmp_path / "tree_build_sanitize")
-    subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-ffp-contract=off", "-pthread", *flags, SRC, "-o", exe], check=True)
+def _build_and_run(tmp_path, flags, env_extra=None, src=SRC):
+    exe = str(tmp_path / os.path.basename(src)[:-4])
+    subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-ffp-contract=off", "-pthread", *flags, src, "-o", exe], check=True)
     env = dict(os.environ)
     env.update(env_extra or {})
     r = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=900)
@@ -28,6 +29,12 @@ def test_tree_builders_asan_ubsan(tmp_path):
 
 def test_tree_builders_tsan(tmp_path):
     _build_and_run(tmp_path, ["-fsanitize=thread"], {"TSAN_OPTIONS": "halt_on_error=1"})
+
+
+def test_delta_decoder_asan_ubsan_on_damaged_streams(tmp_path):
+    """The host decoder of the delta snapshots parses bytes from outside: valid streams, then 40 000 damaged ones."""
+    _build_and_run(tmp_path, ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"],
+                   src=os.path.join(ROOT, "tests", "native", "delta_decoder_sanitize.cpp"))
 
 
 def test_oracle_asan_ubsan(tmp_path):
