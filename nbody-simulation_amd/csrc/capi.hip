@@ -125,6 +125,10 @@ template <class T> struct State {
   void* ws_terms = nullptr;
   int64_t ws_capacity = 0;       // terms
   int ws_backoff = 0;            // steps for which the split walk is not tried (the last one needed too much memory)
+  // one-pass walk (walk_tile): the counts in ws_scratch are those of the last walk over the context's own particles
+  int64_t wt_hist_n = -1, wt_hist_begin = 0;
+  unsigned long long wt_total = 0;  // terms of that walk
+  uint32_t* wt_hist = nullptr;      // [n] per particle id: its terms in that walk
   std::vector<T> h_pos;
   std::vector<uint32_t> h_weight;  // current row order
   std::vector<uint32_t> h_tmp;
@@ -234,9 +238,9 @@ template <class P> void free_dev(P*& p) {
 template <class T> void free_state(State<T>& s) {
   for (auto& st : s.set) { free_dev(st.pos); free_dev(st.vel); free_dev(st.weight); free_dev(st.ids); free_dev(st.mass); }
   free_dev(s.pos_next); free_dev(s.acc); free_dev(s.geom0); free_dev(s.geom1); free_dev(s.link); free_dev(s.order_dev);
-  free_dev(s.node_depth); free_dev(s.node_mass); free_dev(s.node_size); free_dev(s.qb_scratch); free_dev(s.bb_scratch); free_dev(s.ws_scratch); free_dev(s.ws_terms);
+  free_dev(s.node_depth); free_dev(s.node_mass); free_dev(s.node_size); free_dev(s.qb_scratch); free_dev(s.bb_scratch); free_dev(s.ws_scratch); free_dev(s.ws_terms); free_dev(s.wt_hist);
   s.node_aux_cap = 0; s.qb_scratch_bytes = 0; s.bb_scratch_bytes = 0; s.h_weight_stale = false;
-  s.ws_scratch_bytes = 0; s.ws_capacity = 0; s.ws_backoff = 0; s.quad_depth_hint = 0;
+  s.ws_scratch_bytes = 0; s.ws_capacity = 0; s.ws_backoff = 0; s.quad_depth_hint = 0; s.wt_hist_n = -1;
   s.tree_host_stale = false; s.n_nodes = 0;
   s.node_cap = 0; s.n = 0; s.tree_valid = false; s.tree.clear();
   s.h_pos.clear(); s.h_weight.clear();
@@ -805,11 +809,58 @@ int tree_walk_phase(nbody_ctx* c, State<T>& s, int kind, const void* tgt_pos, in
   }
   bool done = false;
   if constexpr (std::is_same<T, float>::value) {
-    // Big leaves: count / terms / ordered sum (walk_split.hip) unless it would need more
-    // memory than it is worth.  NBODY_WALK_SPLIT: 0 never, 1 when it pays (default), 2 whenever it is possible.
+    // Big leaves: a leaf's terms are evaluated lane = particle (walk_split.hip): in one pass with the terms handed over
+    // through LDS (walk_tile), or in three passes through a term array.  NBODY_WALK_SPLIT: 0 never (fused walk), 1 one pass
+    // when it pays (default), 3 one pass whenever possible, 4 / 2 three passes when it pays / whenever possible.
     const int mode = env_int("NBODY_WALK_SPLIT", 1);
+    const bool tile_mode = mode == 3 || (mode == 1 && w.n_tgt >= 4096);
     const bool eligible = w.big_leaves && !w.stats && w.n_tgt > 0 && w.n_nodes > 0 && env_int("NBODY_WALK_PER_THREAD", 0) == 0;
-    if (eligible && mode != 0 && (mode == 2 || (w.n_tgt >= 4096 && s.ws_backoff == 0))) {
+    if (eligible && tile_mode && (mode == 3 || s.ws_backoff == 0)) {  // one pass, terms through LDS (walk_tile)
+      const WalkSplitLayout L = walk_split_layout(w.n_tgt);
+      if (s.ws_scratch_bytes < L.total) {
+        free_dev(s.ws_scratch);
+        s.ws_scratch_bytes = 0;
+        s.wt_hist_n = -1;
+        HIPCHK(c, hipMalloc((void**)&s.ws_scratch, L.total));
+        s.ws_scratch_bytes = L.total;
+      }
+      const bool self = tgt_pos == nullptr;
+      if (self && !s.wt_hist) {
+        HIPCHK(c, hipMalloc((void**)&s.wt_hist, (size_t)(s.n > 0 ? s.n : 1) * 4));
+        s.wt_hist_n = -1;
+      }
+      // the targets' particle ids (the snapshot's rows under AS_WRITTEN, the permuted rows otherwise)
+      const uint32_t* tgt_ids = !self ? nullptr
+                                : ((c->params.order == NBODY_ORDER_AS_WRITTEN) ? s.set[1 - s.cur].ids : s.set[s.cur].ids) + (slice_count >= 0 ? slice_begin : 0);
+      const bool hist = self && s.wt_hist_n == w.n_tgt && s.wt_hist_begin == slice_begin && env_int("NBODY_WALK_TILE_COUNT", 0) == 0;
+      int shift = 0;
+      while (hist && (s.wt_total >> shift) >= (1ull << 31)) ++shift;
+      int info[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      unsigned long long total = 0;
+      for (int estimate = hist ? 1 : 0; !done; estimate = 2) {
+        {
+          TimerScope ts(c->timer, c->stream);
+          HIPCHK(c, launch_tree_walk_tile(c->stream, w, s.ws_scratch, L, tgt_ids, self ? s.wt_hist : nullptr, estimate, shift));
+        }
+        HIPCHK(c, hipMemcpyAsync(info, s.ws_scratch + L.info, sizeof(info), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        std::memcpy(&total, &info[6], 8);
+        if (env_int("NBODY_TRACE", 0) != 0)
+          std::fprintf(stderr, "[nbody] tile walk: %llu terms, estimate %s (shift %d, total %d), %d per wave, overflow %d\n", total,
+                       estimate == 1 ? "from the last walk" : (estimate == 0 ? "counted" : "none"), shift, info[0], info[3], info[1]);
+        // a counted estimate that does not fit 32 bits: walk without one (the counts it leaves behind are scaled next time)
+        done = info[1] == 0;
+        if (!done && estimate != 0) return fail(c, NBODY_ERR_HIP, "tile walk: overflow flag without a counted estimate");
+      }
+      s.wt_hist_n = self ? w.n_tgt : -1;
+      s.wt_hist_begin = slice_begin;
+      s.wt_total = total;
+      // a walk in which the average target takes a sixteenth of all particles (small theta on the needle boxes) is nearly
+      // the direct sum: every lane wants every leaf and the fused walk's lane = target is the cheaper arrangement; look
+      // again in 64 walks
+      if (mode != 3 && (double)total > (double)w.n_tgt * (double)s.n / 16.0) s.ws_backoff = 64;
+    } else if (eligible && (mode == 2 || (mode == 4 && w.n_tgt >= 4096 && s.ws_backoff == 0))) {
+      s.wt_hist_n = -1;
       const int64_t hard_cap = ((int64_t)1 << 31) - 65536;  // terms (16 GB; the offsets are 32 bits wide); past that the fused walk
       const WalkSplitLayout L = walk_split_layout(w.n_tgt);
       if (s.ws_scratch_bytes < L.total) {

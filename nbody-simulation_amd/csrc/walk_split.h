@@ -20,4 +20,14 @@ WalkSplitLayout walk_split_layout(int64_t n_tgt);
 hipError_t launch_tree_walk_split(hipStream_t s, const WalkArgs<float>& a, char* scratch, const WalkSplitLayout& L, void* terms,
                                   int64_t term_capacity);
 
+// The same walk in one pass, the terms handed from "lane = particle" to "lane = target" through LDS (walk_tile): no term
+// array.  The waves are cut by an estimate of each target's work.  estimate 1: hist[tgt_ids[t]] holds the term count of
+// target t's particle in the previous walk (scaled down by `shift` bits so that the sum stays below 2^31); 0: a counting
+// traversal runs first; 2: none (64 targets per wave; for walks whose counts overflow 32 bits and have no history yet).
+// hist (may be null: nothing is recorded) receives this walk's counts, by particle id.
+// info afterwards: [1] != 0: nothing was written to acc (the counted estimate overflowed 32 bits: use the fused walk);
+// info[6..7]: this walk's total terms (unsigned long long).
+hipError_t launch_tree_walk_tile(hipStream_t s, const WalkArgs<float>& a, char* scratch, const WalkSplitLayout& L, const uint32_t* tgt_ids,
+                                 uint32_t* hist, int estimate, int shift);
+
 }  // namespace nbody

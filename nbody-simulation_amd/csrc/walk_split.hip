@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "walk_split.h"
 
@@ -30,6 +31,11 @@ namespace {
 constexpr int kCountTPW = 64;
 constexpr uint32_t kTermBudget = 8192;  // terms a wave of the term pass writes, about (at least: see walk_total)
 constexpr uint32_t kBudgetTargets = 12; // ... or this many average targets' worth, if that is more
+constexpr uint32_t kTileBudget = 8192;        // smallest budget of a wave of the one-pass walk (walk_tile)
+constexpr int64_t kTileWaves = 16384;         // waves it aims at: twice what the chip holds (256 CUs x 32), unless the
+                                              // targets need more anyway (then a quarter more than n / 64)
+constexpr int kTileRoundCost = 66;            // instructions a target costs at a leaf, lane = particle (a round + its share of the adds)
+constexpr int kFusedPairCost = 48;            // ... and a particle costs the wave, lane = target
 
 __device__ __forceinline__ float lane_f(float v, int k) {  // k uniform
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), k));
@@ -242,7 +248,190 @@ __global__ __launch_bounds__(256) void walk_sum(const WalkArgs<float> a, const u
   }
 }
 
+
+// ---- the walk in ONE pass, terms through LDS (walk_tile) --------------------------------------------------------------
+// Same idea as the three passes above - a leaf's terms are evaluated lane = particle, so a leaf step costs what its
+// takers cost - but the terms never leave the CU: up to TT acting targets of the wave are evaluated against the leaf
+// (one round each, a row of the wave's LDS tile), then every one of those targets' own lanes adds its row in slice
+// order (lane = target again: TT independent chains at once).  No term array (8 B per pair written and read back), no
+// sum pass, no capacity to outgrow.  Waves are still cut by work; the estimate is the scan of the targets' term counts
+// of the PREVIOUS walk over the same target set (position t in tree order: a spatial neighbourhood that changes little
+// from step to step) or, when there is none, of a counting traversal.  A bad estimate costs balance, never correctness:
+// each target's additions are the fused walk's, in its order.
+template <bool FAST, int TT>
+__global__ __launch_bounds__(256) void walk_tile(const WalkArgs<float> a, const uint32_t* __restrict__ off, const int* __restrict__ info,
+                                                 const uint32_t* __restrict__ tgt_ids, uint32_t* __restrict__ hist,
+                                                 unsigned long long* __restrict__ total_out) {
+  constexpr int kStride = 65;  // float2 per row: rows of different targets start in different banks
+  __shared__ float2 tile_all[4][TT * kStride];
+  const int lane = threadIdx.x & 63;
+  float2* __restrict__ tile = tile_all[threadIdx.x >> 6];
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (info[1] != 0) return;  // the estimate's scan wrapped: the caller takes the fused walk
+  const uint32_t budget = (uint32_t)info[3];
+  int64_t lo = 0, hi = a.n_tgt;
+  while (lo < hi) {  // first t with g(t) >= wave, g(t) = off[t] / budget + t / 64 (see walk_pass)
+    const int64_t mid = (lo + hi) >> 1;
+    if ((int64_t)(off[mid] / budget) + (mid >> 6) < wave) lo = mid + 1; else hi = mid;
+  }
+  const int64_t t0 = lo;
+  hi = t0 + 64 < a.n_tgt ? t0 + 64 : a.n_tgt;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if ((int64_t)(off[mid] / budget) + (mid >> 6) <= wave) lo = mid + 1; else hi = mid;
+  }
+  if (lo == t0) return;
+  const int64_t t = t0 + lane;
+  const bool live = t < lo;
+  const int64_t row = live ? (a.tgt_index ? (int64_t)a.tgt_index[t] : t) : 0;
+  const float2 p = live ? reinterpret_cast<const float2*>(a.tgt_pos)[row] : make_float2(0.f, 0.f);
+  const float4* __restrict__ g0 = reinterpret_cast<const float4*>(a.geom0);
+  const float4* __restrict__ g1 = reinterpret_cast<const float4*>(a.geom1);
+  const int4* __restrict__ lk = reinterpret_cast<const int4*>(a.link);
+  const float2* __restrict__ lpos = reinterpret_cast<const float2*>(a.leaf_pos);
+  const float* __restrict__ lmass = a.leaf_mass;
+  const float theta = a.theta, clamp = a.clamp;
+  const int n_nodes = a.n_nodes;
+  int resume = live ? 0 : n_nodes;
+  uint32_t n_terms = 0;
+  float ax = 0.f, ay = 0.f;  // Vec2::zero(), main.rs:409
+  int i = 0;
+  while (i < n_nodes) {  // i is wave-uniform
+    const int4 l = lk[i];
+    const float4 b = g0[i];
+    const float4 c = g1[i];
+#ifndef NB_TILE_LATE_GEOM
+    asm volatile("" : : "s"(b.x), "s"(c.w));  // the three records together: one latency per step (the compiler sinks the two
+                                              // it needs in the node arm only into that arm, behind the first one's wait)
+#endif
+    const bool act = resume <= i;
+    int next;
+    if (l.w) {  // Leaf arm, main.rs:351-363
+      const unsigned long long mask = __builtin_amdgcn_ballot_w64(act);
+      if (mask) {
+        const int takers = __builtin_popcountll(mask);
+        for (int k0 = 0; k0 < l.z; k0 += 64) {  // 64 particles at a time
+          const int mine = k0 + lane;
+          const int left = l.z - k0;
+          const int rounds8 = ((left < 64 ? left : 64) + 7) >> 3;
+          float2 q = make_float2(0.f, 0.f);
+          float m = 0.f;
+          if (mine < l.z) {
+            q = lpos[l.y + mine];
+            m = lmass[l.y + mine];
+          }
+          if (takers * kTileRoundCost > (left < 64 ? left : 64) * kFusedPairCost) {
+            // most of the wave wants this leaf: lane = target, the particles one after the other (the fused walk's
+            // arm; the same additions in the same order, so the two arms mix freely)
+            const int mc = left < 64 ? left : 64;
+            for (int j = 0; j < mc; ++j) {
+              const float qx = lane_f(q.x, j), qy = lane_f(q.y, j), qm = lane_f(m, j);
+              if (act) {
+                const float2 term = term_of<FAST>(p.x, p.y, qx, qy, qm, clamp);
+                ax = ax + term.x;
+                ay = ay + term.y;
+              }
+            }
+            continue;
+          }
+          unsigned long long todo = mask;
+          while (todo) {
+            int slot = 0, myslot = -1;
+            while (todo && slot < TT) {  // lane = particle: one acting target per round, its terms into row `slot`
+              const int tl = __builtin_ctzll(todo);
+              todo &= todo - 1;
+              const float tx = lane_f(p.x, tl), ty = lane_f(p.y, tl);
+              const float2 term = term_of<FAST>(tx, ty, q.x, q.y, m, clamp);
+              tile[slot * kStride + lane] = mine < l.z ? term : make_float2(-0.0f, -0.0f);  // past the leaf: the identity of addition
+              if (lane == tl) myslot = slot;
+              ++slot;
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (myslot >= 0) {  // lane = target: its row, in slice order
+              const float2* __restrict__ r = tile + myslot * kStride;
+              for (int j0 = 0; j0 < rounds8; ++j0) {
+                float2 v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = r[j0 * 8 + j];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                  ax = ax + v[j].x;
+                  ay = ay + v[j].y;
+                }
+              }
+            }
+            __builtin_amdgcn_wave_barrier();
+          }
+        }
+      }
+      if (act) {
+        n_terms += (uint32_t)l.z;
+        resume = l.x;
+      }
+      next = l.x;
+    } else {
+      bool descend = false;
+      if (act) {
+        const bool contains = p.y > b.y && p.x > b.x && p.x < b.z && p.y < b.w;  // bvh_tree.rs:15-20 (all strict)
+        const float ddx = p.x - c.x, ddy = p.y - c.y;                              // dist2(p, cog), main.rs:228-232
+        const float d2 = ddx * ddx + ddy * ddy;
+        if (!contains && c.w < d2 * theta * theta) {                               // :370-372
+          const float2 term = term_of<FAST>(p.x, p.y, c.x, c.y, c.z, clamp);       // :374-379
+          ax = ax + term.x;
+          ay = ay + term.y;
+          ++n_terms;
+          resume = l.x;
+        } else {
+          descend = true;                                                          // :381-382
+          resume = i + 1;
+        }
+      }
+      next = __builtin_amdgcn_ballot_w64(descend) != 0 ? i + 1 : l.x;
+    }
+    i = __builtin_amdgcn_readfirstlane(next);
+  }
+  if (live) {
+    reinterpret_cast<float2*>(a.acc)[row] = make_float2(ax, ay);
+    if (hist) hist[tgt_ids[t]] = n_terms;  // by particle id: the rows are permuted by every build
+  }
+  unsigned long long sum = live ? n_terms : 0ull;  // what this walk cost, for the next estimate's scale
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) sum += (unsigned long long)__shfl_xor((long long)sum, d, 64);
+  if (lane == 0) atomicAdd(total_out, sum);
+}
+
+struct EstimateOf {  // target t's terms in the last walk, scaled
+  const uint32_t* hist;
+  const uint32_t* ids;
+  int shift;
+  __host__ __device__ __forceinline__ uint32_t operator()(int t) const { return hist ? hist[ids[t]] >> shift : 0u; }
+};
+// budget of walk_tile's waves from the estimate's total (see walk_total)
+__global__ void walk_tile_total(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off, int64_t n, const uint32_t* __restrict__ tgt_ids,
+                                const uint32_t* __restrict__ hist, int shift, int64_t extra_waves, int* __restrict__ info) {
+  const uint32_t last = n > 0 ? (cnt ? cnt[n - 1] : (hist ? hist[tgt_ids[n - 1]] >> shift : 0u)) : 0u;
+  const unsigned long long total = n > 0 ? (unsigned long long)off[n - 1] + last : 0ull;
+  info[0] = (int)(total > 0x7fffffffull ? 0x7fffffffull : total);
+  // g(t) = off[t] / budget + t / 64 ends near total / budget + n / 64: `extra_waves` more than the head count alone
+  unsigned long long want = total / (unsigned long long)extra_waves;
+  uint32_t budget = kTileBudget >> shift;
+  if (budget < 64) budget = 64;
+  while (budget < want && budget < (1u << 30)) budget <<= 1;
+  info[3] = (int)budget;
+  info[6] = info[7] = 0;  // this walk's total terms (unsigned long long), accumulated by walk_tile
+}
+
 inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
+inline uint32_t tile_budget_targets() {
+  const char* e = getenv("NBODY_WALK_TILE_BUDGET_TARGETS");
+  const int v = e ? atoi(e) : 0;
+  return (uint32_t)(v < 1 ? 0 : (v > 4096 ? 4096 : v));
+}
+inline int tile_targets() {
+  const char* e = getenv("NBODY_WALK_TILE_TARGETS");
+  const int v = e ? atoi(e) : 8;  // 8 rows keep the tile at 4 KB per wave: eight waves per SIMD
+  return (v == 16 || v == 32) ? v : 8;
+}
 
 }  // namespace
 
@@ -282,6 +471,47 @@ hipError_t launch_tree_walk_split(hipStream_t s, const WalkArgs<float>& a, char*
   else walk_pass<true, 64, false><<<dim3((unsigned)((twaves + 3) / 4)), dim3(256), 0, s>>>(a, cnt, off, (float2*)terms, info, term_capacity);
   const int64_t sum_waves = (a.n_tgt + 3) / 4;
   walk_sum<<<dim3((unsigned)((sum_waves + 3) / 4)), dim3(256), 0, s>>>(a, cnt, off, (const float2*)terms, info);
+  return hipGetLastError();
+}
+
+
+hipError_t launch_tree_walk_tile(hipStream_t s, const WalkArgs<float>& a, char* scratch, const WalkSplitLayout& L, const uint32_t* tgt_ids,
+                                 uint32_t* hist, int estimate, int shift) {
+  const bool have_history = estimate != 0;  // 1: from hist; 2: none at all (every wave takes 64 targets)
+  if (a.n_tgt <= 0) return hipSuccess;
+  uint32_t* cnt = (uint32_t*)(scratch + L.cnt);
+  uint32_t* off = (uint32_t*)(scratch + L.off);
+  int* info = (int*)(scratch + L.info);
+  hipError_t e = hipMemsetAsync(info, 0, 32, s);
+  if (e != hipSuccess) return e;
+  size_t tb = L.cub_temp_bytes;
+  if (!have_history) {  // no counts of an earlier walk over these targets: count (exact, so shift 0)
+    shift = 0;
+    const int64_t cwaves = (a.n_tgt + kCountTPW - 1) / kCountTPW;
+    walk_pass<false, kCountTPW, false><<<dim3((unsigned)((cwaves + 3) / 4)), dim3(256), 0, s>>>(a, cnt, nullptr, nullptr, info, 0);
+    e = hipcub::DeviceScan::ExclusiveSum((void*)(scratch + L.cub_temp), tb, (const uint32_t*)cnt, off, (int)a.n_tgt, s);
+    if (e != hipSuccess) return e;
+    walk_check_wrap<<<dim3((unsigned)((a.n_tgt + 255) / 256)), dim3(256), 0, s>>>(cnt, off, a.n_tgt, info);
+  } else {
+    hipcub::CountingInputIterator<int> idx(0);
+    hipcub::TransformInputIterator<uint32_t, EstimateOf, hipcub::CountingInputIterator<int>> est(idx, EstimateOf{estimate == 1 ? hist : nullptr, tgt_ids, shift});
+    e = hipcub::DeviceScan::ExclusiveSum((void*)(scratch + L.cub_temp), tb, est, off, (int)a.n_tgt, s);
+    if (e != hipSuccess) return e;
+  }
+  int64_t extra = kTileWaves - a.n_tgt / 64;
+  if (extra < a.n_tgt / 256) extra = a.n_tgt / 256;
+  const uint32_t bt = tile_budget_targets();  // development override: a budget of this many average targets
+  if (bt) extra = a.n_tgt / bt;
+  if (extra < 1) extra = 1;
+  walk_tile_total<<<dim3(1), dim3(1), 0, s>>>(have_history ? nullptr : cnt, off, a.n_tgt, tgt_ids, estimate == 1 ? hist : nullptr, shift, extra, info);
+  const int64_t twaves = extra + a.n_tgt / 64 + 4;  // upper bound of g(t) + 1 (budget >= total / extra)
+  unsigned long long* total_out = (unsigned long long*)(info + 6);
+  const int tt = tile_targets();
+  const dim3 grid((unsigned)((twaves + 3) / 4));
+#define NB_TILE(F, T) walk_tile<F, T><<<grid, dim3(256), 0, s>>>(a, off, info, tgt_ids, hist, total_out)
+  if (a.fast) { if (tt == 16) NB_TILE(true, 16); else if (tt == 32) NB_TILE(true, 32); else NB_TILE(true, 8); }
+  else { if (tt == 16) NB_TILE(false, 16); else if (tt == 32) NB_TILE(false, 32); else NB_TILE(false, 8); }
+#undef NB_TILE
   return hipGetLastError();
 }
 

@@ -379,9 +379,10 @@ def test_device_bvh_build_with_long_nodes_left_after_the_blind_levels(nb, orc, c
 
 
 # ------------------------------------------------------------------ split walk (walk_split.hip)
-@pytest.mark.parametrize("mode", ["0", "2"])
+@pytest.mark.parametrize("mode", ["0", "2", "3"])
 def test_split_and_fused_walks_are_the_same_walk(nb, orc, ctx, monkeypatch, mode):
-    """count / emit / ordered-sum (NBODY_WALK_SPLIT=2) and the fused wave walk (=0) against the CPU recursion: the
+    """count / emit / ordered-sum (NBODY_WALK_SPLIT=2), the one-pass walk with the terms through LDS (=3) and the fused
+    wave walk (=0) against the CPU recursion: the
     same nodes, pairs, operations and order of additions, so the same bits — targets = the particles (tree order), a
     strided subset of arbitrary targets, coincident and out-of-box targets, several thetas."""
     C = nb._capi
@@ -403,7 +404,7 @@ def test_split_and_fused_walks_are_the_same_walk(nb, orc, ctx, monkeypatch, mode
 def test_split_walk_steps_equal_fused_walk_steps(nb, monkeypatch):
     pos, vel, w = nb.scenes.galaxy()
     res = []
-    for mode in ("0", "2"):
+    for mode in ("0", "2", "3", "1"):
         monkeypatch.setenv("NBODY_WALK_SPLIT", mode)
         world = nb.World(pos, vel, w, method="bvh")
         cnt = nb.Counting()
@@ -411,23 +412,25 @@ def test_split_walk_steps_equal_fused_walk_steps(nb, monkeypatch):
             world.update(0.1, cnt)
         res.append(world.particles())
         world.close()
-    for a, b in zip(*res):
-        assert np.array_equal(a, b)
+    for other in res[1:]:
+        for a, b in zip(res[0], other):
+            assert np.array_equal(a, b)
 
 
 def test_split_walk_backs_off_when_the_terms_do_not_fit(nb, monkeypatch):
-    """N = 2^21 on the reference's needle-box BVH needs more terms than 32-bit offsets hold: the step must fall back to
-    the fused walk and give the same accelerations as with the split walk switched off."""
+    """N = 2^21 on the reference's needle-box BVH needs more terms than 32-bit offsets hold: the three-pass walk must fall
+    back to the fused walk, the one-pass walk must go on without a counted estimate, and both must give the same
+    accelerations as the fused walk."""
     C = nb._capi
     pos, vel, w = nb.scenes.plummer(1 << 21, seed=0x5EED0009)
     out = []
-    for mode in ("1", "0"):
+    for mode in ("1", "4", "0"):
         monkeypatch.setenv("NBODY_WALK_SPLIT", mode)
         with C.Context(0) as c:
             c.set_params(theta=50.0)
             c.upload(pos, vel, w)
             out.append(c.accel_tree(C.TREE_BVH))
-    assert np.array_equal(out[0], out[1])
+    assert np.array_equal(out[0], out[2]) and np.array_equal(out[1], out[2])
 
 
 def test_device_quad_build_sorts_by_the_previous_depth_and_recovers_when_the_tree_got_deeper(nb, orc):
