@@ -259,6 +259,134 @@ __global__ __launch_bounds__(256) void tree_walk_wave(const WalkArgs<T> a) {
 }
 
 // out[i] = in[perm[i]] for the particle arrays (the device-side image of the in-place partition permutation).
+// calculate_gravity (main.rs:234-253) up to, but not including, the `+=`: a pair the reference skips is -0.0, the
+// identity of IEEE addition.
+template <class T> __device__ __forceinline__ typename V2<T>::type pair_term_t(T px, T py, T qx, T qy, T force, T clamp) {
+  using T2 = typename V2<T>::type;
+  const T dx = qx - px;
+  const T dy = qy - py;
+  const T sum = __builtin_fabs(dx) + __builtin_fabs(dy);
+  if (!is_normal_t(sum)) return T2{(T)-0.0, (T)-0.0};
+  T distance = dx * dx + dy * dy;
+  if (distance < clamp) distance = clamp;
+  const T den = sum * distance;
+  return T2{(dx * force) / den, (dy * force) / den};
+}
+
+// The wave-uniform walk for trees with SMALL leaves (the quad tree: at most 8 particles per leaf), as-written
+// arithmetic.  In tree_walk_wave a leaf step costs one pair evaluation per particle for the whole wave, however few
+// of its lanes take part: on config 4 (4 M bodies, theta 0.5) 21 of 64 lanes act at the average leaf step and the
+// leaf holds 4.2 particles.  Here the (acting target, particle) PAIRS of a leaf step are dealt to the lanes: acting
+// lanes put their positions into LDS by rank; lane L evaluates target rank L / m against particle L % m (m = the
+// leaf's size, floor(64 / m) targets per round) and stores the term; then each target's own lane adds its m terms in
+// slice order.  Same pairs, same operations, same order of additions per target as tree_walk_wave (a skipped pair is
+// stored as -0.0), so the same bits.  Taken when it needs fewer rounds than the leaf has particles.
+template <class T>
+__global__ __launch_bounds__(256) void tree_walk_small(const WalkArgs<T> a, const int rule) {
+  using T2 = typename V2<T>::type;
+  using T4 = typename V4<T>::type;
+  __shared__ T2 s_pos_all[4][64];
+  __shared__ T2 s_term_all[4][64];
+  T2* __restrict__ s_pos = s_pos_all[threadIdx.x >> 6];
+  T2* __restrict__ s_term = s_term_all[threadIdx.x >> 6];
+  const int lane = threadIdx.x & 63;
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool live = t < a.n_tgt;
+  const int64_t row = live ? (a.tgt_index ? (int64_t)a.tgt_index[t] : t) : 0;
+  const T2 p = live ? reinterpret_cast<const T2*>(a.tgt_pos)[row] : T2{0, 0};
+  const T4* __restrict__ g0 = reinterpret_cast<const T4*>(a.geom0);
+  const T4* __restrict__ g1 = reinterpret_cast<const T4*>(a.geom1);
+  const int4* __restrict__ lk = reinterpret_cast<const int4*>(a.link);
+  const T2* __restrict__ lpos = reinterpret_cast<const T2*>(a.leaf_pos);
+  const T* __restrict__ lmass = a.leaf_mass;
+  const T theta = a.theta, clamp = a.clamp;
+  const int n_nodes = a.n_nodes;
+  T ax = 0, ay = 0;
+  int resume = live ? 0 : n_nodes;
+  int i = 0;
+  while (i < n_nodes) {  // i is wave-uniform
+    const int4 l = lk[i];
+    const T4 b = g0[i], c = g1[i];
+    const bool act = resume <= i;
+    int next;
+    if (l.w) {  // Leaf arm, main.rs:351-363
+      const int m = l.z;
+      const unsigned long long mask = __builtin_amdgcn_ballot_w64(act);
+      const int takers = __builtin_popcountll(mask);
+      const int tpr = m > 0 && m <= 64 ? 64 / m : 0;  // targets per round
+      const int rounds = tpr ? (takers + tpr - 1) / tpr : 0;
+      const bool pays = rule == 2 ? rounds < m : (rule == 3 ? rounds * 2 < m : rounds * 4 + 1 < m * 3);
+      if (tpr && pays) {  // a round costs about a third more than a plain pair step
+        const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+        if (act) s_pos[rank] = p;
+        // lane -> (slot, j) = (lane / m, lane % m); (lane + 0.5) / m is at least 1/16 away from an integer
+        const int slot = (int)(((float)lane + 0.5f) * __builtin_amdgcn_rcpf((float)m));
+        const int j = lane - slot * m;
+        T2 q = T2{0, 0};
+        T qm = 0;
+        if (slot < tpr) {
+          q = lpos[l.y + j];
+          qm = lmass[l.y + j];
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int r = 0; r < rounds; ++r) {
+          const int tr = r * tpr + slot;
+          if (slot < tpr && tr < takers) {
+            const T2 tp = s_pos[tr];
+            s_term[lane] = pair_term_t<T>(tp.x, tp.y, q.x, q.y, qm, clamp);
+          }
+          __builtin_amdgcn_wave_barrier();
+          const int mine = rank - r * tpr;
+          if (act && mine >= 0 && mine < tpr) {  // this target's m terms, in slice order
+            const T2* __restrict__ row_terms = s_term + mine * m;
+            for (int jj = 0; jj < m; ++jj) {
+              const T2 v = row_terms[jj];
+              ax = ax + v.x;
+              ay = ay + v.y;
+            }
+          }
+          __builtin_amdgcn_wave_barrier();
+        }
+      } else {
+        const int end = l.y + m;
+        for (int k0 = l.y; k0 < end; k0 += 4) {
+          T2 q[4];
+          T qm[4];
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {  // the arrays are padded: reading past a leaf's end is safe
+            q[jj] = lpos[k0 + jj];
+            qm[jj] = lmass[k0 + jj];
+          }
+          if (act) {
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+              if (k0 + jj < end) pair_as_written<T>(p.x, p.y, q[jj].x, q[jj].y, qm[jj], clamp, ax, ay);
+          }
+        }
+      }
+      if (act) resume = l.x;
+      next = l.x;
+    } else {
+      bool descend = false;
+      if (act) {
+        const bool contains = p.y > b.y && p.x > b.x && p.x < b.z && p.y < b.w;  // bvh_tree.rs:15-20
+        const T ddx = p.x - c.x, ddy = p.y - c.y;
+        const T d2 = ddx * ddx + ddy * ddy;                                        // main.rs:228-232
+        if (!contains && c.w < d2 * theta * theta) {                               // :370-372
+          pair_as_written<T>(p.x, p.y, c.x, c.y, c.z, clamp, ax, ay);              // :374-379
+          resume = l.x;
+        } else {
+          descend = true;                                                          // :381-382
+          resume = i + 1;
+        }
+      }
+      next = __builtin_amdgcn_ballot_w64(descend) != 0 ? i + 1 : l.x;
+    }
+    i = __builtin_amdgcn_readfirstlane(next);
+  }
+  if (live) reinterpret_cast<T2*>(a.acc)[row] = T2{ax, ay};
+}
+
 template <class T>
 __global__ __launch_bounds__(256) void gather_particles(const GatherArgs<T> a) {
   using T2 = typename V2<T>::type;
@@ -364,6 +492,12 @@ template <class T> hipError_t launch_tree_walk(hipStream_t s, const WalkArgs<T>&
   const dim3 grid((unsigned)((a.n_tgt + 255) / 256));
   if (!wave_uniform) {
     hipLaunchKernelGGL((tree_walk<T>), grid, dim3(256), 0, s, a);
+    return hipGetLastError();
+  }
+  // small leaves (quad tree), as-written arithmetic: the pairs of a leaf step dealt to the lanes (tree_walk_small)
+  const int compact = getenv("NBODY_WALK_COMPACT") ? atoi(getenv("NBODY_WALK_COMPACT")) : 1;
+  if (!a.big_leaves && !a.fast && !a.stats && a.n_nodes > 0 && compact != 0) {
+    hipLaunchKernelGGL((tree_walk_small<T>), grid, dim3(256), 0, s, a, compact);
     return hipGetLastError();
   }
   // leaf batch / successor prefetch, measured in profiles/r01_walk_kernels_ab.txt: big leaves (BVH, 64) want 8
