@@ -498,7 +498,8 @@ hipError_t launch_tree_walk_tile(hipStream_t s, const WalkArgs<float>& a, char* 
     e = hipcub::DeviceScan::ExclusiveSum((void*)(scratch + L.cub_temp), tb, est, off, (int)a.n_tgt, s);
     if (e != hipSuccess) return e;
   }
-  int64_t extra = kTileWaves - a.n_tgt / 64;
+  const char* ew = getenv("NBODY_WALK_TILE_WAVES");  // development override of kTileWaves
+  int64_t extra = (ew && atoi(ew) > 0 ? (int64_t)atoi(ew) : kTileWaves) - a.n_tgt / 64;
   if (extra < a.n_tgt / 256) extra = a.n_tgt / 256;
   const uint32_t bt = tile_budget_targets();  // development override: a budget of this many average targets
   if (bt) extra = a.n_tgt / bt;
