@@ -455,3 +455,83 @@ def test_device_quad_build_sorts_by_the_previous_depth_and_recovers_when_the_tre
             assert t["max_depth"] == int(o.depth.max())
         d_shallow, d_deep = int(orc.Quad(shallow, w).flat().depth.max()), int(orc.Quad(deep, w).flat().depth.max())
         assert d_deep > d_shallow + 3
+
+
+# ------------------------------------------------------------------ leaf sizes through the two lane-dealing walks
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("leaf", [1, 3, 8, 15, 16, 40, 64, 100, 200])
+def test_bvh_walk_bit_exact_for_every_leaf_size(nb, orc, ctx, monkeypatch, dtype, leaf):
+    """leaf_size < 16 takes tree_walk_small (pairs dealt to the lanes, rounds of floor(64 / m) targets), >= 16 in f32 the
+    one-pass walk with the LDS tile (leaves longer than 64 particles go through it 64 at a time); f64 big leaves the fused
+    walk.  Particles themselves and arbitrary targets (fewer than a wave, not a multiple of 64, outside every box)."""
+    C = nb._capi
+    monkeypatch.setenv("NBODY_WALK_SPLIT", "3")
+    n = 9000
+    pos, vel, _ = nb.scenes.plummer(n, seed=61)
+    pos, vel = pos.astype(dtype), vel.astype(dtype)
+    if leaf >= 2:
+        pos[200] = pos[201]                               # a pair the reference skips
+    w = (np.arange(n) % 5 + 1).astype(np.uint32)
+    prm = C.default_params()
+    prm.leaf_size = leaf
+    if C.host_tree(C.TREE_BVH, pos, w, prm)["overflow"]:
+        pytest.skip("degenerate for this leaf size")
+    bvh = orc.BVH(pos, w, leaf_size=leaf)
+    for theta in (50.0, 3.0):
+        ctx.set_params(theta=theta, leaf_size=leaf, order=C.ORDER_CONSISTENT)
+        ctx.upload(pos, vel, w)
+        assert np.array_equal(ctx.accel_tree(C.TREE_BVH), bvh.walk(bvh.flat().pos_perm, theta=theta, nthreads=8))
+        for tg in (pos[:37], np.concatenate([pos[5::11], np.array([[1e7, -1e7], [0, 0]], dtype)])):
+            ctx.upload(pos, vel, w)
+            assert np.array_equal(ctx.accel_tree(C.TREE_BVH, tg), bvh.walk(tg, theta=theta, nthreads=8))
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_quad_walk_with_full_and_sparse_leaves(nb, orc, ctx, dtype):
+    """tree_walk_small on leaves of every size 1..8 (clumps of k points far apart) and on a lattice whose leaves are
+    all full, theta 0.5 and 0 (everything opened)."""
+    C = nb._capi
+    rng = np.random.default_rng(8)
+    clumps = []
+    for k in range(1, 9):
+        for _ in range(40):
+            centre = rng.random(2) * 9e4 + 5e3
+            clumps.append(centre + rng.random((k, 2)) * 0.5)
+    sparse = np.concatenate(clumps).astype(dtype)
+    g = np.arange(64, dtype=np.float64) * 1500.0 + 700.0
+    lattice = np.stack(np.meshgrid(g, g), -1).reshape(-1, 2)
+    lattice = (lattice + rng.random(lattice.shape) * 3.0).astype(dtype)
+    for pos in (sparse, lattice):
+        w = (np.arange(pos.shape[0]) % 4 + 1).astype(np.uint32)
+        for theta in (0.5, 0.0):
+            ctx.set_params(theta=theta)
+            ctx.upload(pos, np.zeros_like(pos), w)
+            ref = orc.Quad(pos, w).walk(pos, theta=theta, nthreads=8)
+            assert np.array_equal(ctx.accel_tree(C.TREE_QUAD), ref)
+            assert np.array_equal(ctx.accel_tree(C.TREE_QUAD, pos[3::5]), ref[3::5])
+
+
+def test_one_pass_walk_history_survives_changes_between_steps(nb, orc, monkeypatch):
+    """The wave cutting of the one-pass walk uses the previous walk's per-particle counts: they may be stale (theta, the
+    application order or the arithmetic changed in between) or absent (new bodies) without changing a bit."""
+    C = nb._capi
+    pos, vel, w = nb.scenes.galaxy()
+    pos, vel, w = pos[::4].copy(), vel[::4].copy(), w[::4].copy()
+    with C.Context(0) as c:
+        c.upload(pos, vel, w)
+        p, v = pos, vel
+        for theta, order in ((50.0, C.ORDER_AS_WRITTEN), (50.0, C.ORDER_AS_WRITTEN), (8.0, C.ORDER_AS_WRITTEN),
+                             (50.0, C.ORDER_CONSISTENT), (50.0, C.ORDER_CONSISTENT)):
+            c.set_params(theta=theta, order=order)
+            c.update_tree(C.TREE_BVH, 0.1, 1)
+            got = c.download()
+            mode = orc.AS_WRITTEN if order == C.ORDER_AS_WRITTEN else orc.CONSISTENT
+            p, v, w, ids, _ = orc.update_bvh(p, v, w, delta=0.1, theta=theta, mode=mode, nsteps=1, nthreads=8)
+            assert np.array_equal(got[0], p) and np.array_equal(got[1], v) and np.array_equal(got[2], w)
+        c.upload(pos[:5000], vel[:5000], w[:5000] * 0 + 1)         # other bodies: no history
+        c.set_params(theta=50.0, order=C.ORDER_AS_WRITTEN)
+        c.update_tree(C.TREE_BVH, 0.1, 2)
+        p2, v2, _, _, _ = orc.update_bvh(pos[:5000], vel[:5000], np.ones(5000, np.uint32), delta=0.1, theta=50.0, mode=orc.AS_WRITTEN,
+                                         nsteps=2, nthreads=8)
+        got = c.download()
+        assert np.array_equal(got[0], p2) and np.array_equal(got[1], v2)
