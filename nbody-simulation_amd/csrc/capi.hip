@@ -808,7 +808,7 @@ int tree_walk_phase(nbody_ctx* c, State<T>& s, int kind, const void* tgt_pos, in
     else { w.tgt_pos = s.set[s.cur].pos; w.n_tgt = s.n; w.tgt_index = s.order_dev; }
   }
   bool done = false;
-  if constexpr (std::is_same<T, float>::value) {
+  {
     // Big leaves: a leaf's terms are evaluated lane = particle (walk_split.hip): in one pass with the terms handed over
     // through LDS (walk_tile), or in three passes through a term array.  NBODY_WALK_SPLIT: 0 never (fused walk), 1 one pass
     // when it pays (default), 3 one pass whenever possible, 4 / 2 three passes when it pays / whenever possible.
@@ -859,7 +859,7 @@ int tree_walk_phase(nbody_ctx* c, State<T>& s, int kind, const void* tgt_pos, in
       // the direct sum: every lane wants every leaf and the fused walk's lane = target is the cheaper arrangement; look
       // again in 64 walks
       if (mode != 3 && (double)total > (double)w.n_tgt * (double)s.n / 16.0) s.ws_backoff = 64;
-    } else if (eligible && (mode == 2 || (mode == 4 && w.n_tgt >= 4096 && s.ws_backoff == 0))) {
+    } else if (std::is_same<T, float>::value && eligible && (mode == 2 || (mode == 4 && w.n_tgt >= 4096 && s.ws_backoff == 0))) {
       s.wt_hist_n = -1;
       const int64_t hard_cap = ((int64_t)1 << 31) - 65536;  // terms (16 GB; the offsets are 32 bits wide); past that the fused walk
       const WalkSplitLayout L = walk_split_layout(w.n_tgt);
@@ -873,7 +873,8 @@ int tree_walk_phase(nbody_ctx* c, State<T>& s, int kind, const void* tgt_pos, in
         int info[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         {
           TimerScope ts(c->timer, c->stream);
-          HIPCHK(c, launch_tree_walk_split(c->stream, w, s.ws_scratch, L, s.ws_terms, s.ws_capacity));
+          if constexpr (std::is_same<T, float>::value)
+            HIPCHK(c, launch_tree_walk_split(c->stream, w, s.ws_scratch, L, s.ws_terms, s.ws_capacity));
         }
         HIPCHK(c, hipMemcpyAsync(info, s.ws_scratch + L.info, sizeof(info), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -27,7 +27,8 @@ hipError_t launch_tree_walk_split(hipStream_t s, const WalkArgs<float>& a, char*
 // hist (may be null: nothing is recorded) receives this walk's counts, by particle id.
 // info afterwards: [1] != 0: nothing was written to acc (the counted estimate overflowed 32 bits: use the fused walk);
 // info[6..7]: this walk's total terms (unsigned long long).
-hipError_t launch_tree_walk_tile(hipStream_t s, const WalkArgs<float>& a, char* scratch, const WalkSplitLayout& L, const uint32_t* tgt_ids,
+template <class T>
+hipError_t launch_tree_walk_tile(hipStream_t s, const WalkArgs<T>& a, char* scratch, const WalkSplitLayout& L, const uint32_t* tgt_ids,
                                  uint32_t* hist, int estimate, int shift);
 
 }  // namespace nbody

@@ -67,6 +67,100 @@ template <bool FAST> __device__ __forceinline__ float2 term_of(float px, float p
   else return pair_term(px, py, qx, qy, force, clamp);
 }
 
+// ---- the same pieces for either precision (walk_tile) ---------------------------------------------------------------
+template <class T> struct Vec2Of;
+template <> struct Vec2Of<float> { using type = float2; };
+template <> struct Vec2Of<double> { using type = double2; };
+template <class T> struct Vec4Of;
+template <> struct Vec4Of<float> { using type = float4; };
+template <> struct Vec4Of<double> { using type = double4; };
+__device__ __forceinline__ float lane_t(float v, int k) { return lane_f(v, k); }
+__device__ __forceinline__ double lane_t(double v, int k) {  // k uniform
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, k), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), k);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ double2 pair_term(double px, double py, double qx, double qy, double force, double clamp) {
+  const double dx = qx - px;                                       // main.rs:236
+  const double dy = qy - py;
+  const double sum = __builtin_fabs(dx) + __builtin_fabs(dy);      // :238
+  if (!__builtin_isnormal(sum)) return make_double2(-0.0, -0.0);   // :241-243
+  double distance = dx * dx + dy * dy;                             // :245
+  if (distance < clamp) distance = clamp;                          // :247-249
+  const double den = sum * distance;
+  return make_double2((dx * force) / den, (dy * force) / den);     // :252
+}
+__device__ __forceinline__ double2 pair_term_fast(double px, double py, double qx, double qy, double force, double clamp) {
+  const double dx = qx - px, dy = qy - py;
+  const double sum = __builtin_fabs(dx) + __builtin_fabs(dy);
+  const double d2 = __builtin_fmax(__builtin_fma(dy, dy, dx * dx), clamp);
+  const double den = __builtin_fma(sum, d2, 0x1p-700);
+  double r = __builtin_amdgcn_rcp(den);
+  r = __builtin_fma(__builtin_fma(-den, r, 1.0), r, r);
+  const double sc = force * r;
+  return make_double2(dx * sc, dy * sc);
+}
+template <bool FAST> __device__ __forceinline__ double2 term_of(double px, double py, double qx, double qy, double force, double clamp) {
+  if constexpr (FAST) return pair_term_fast(px, py, qx, qy, force, clamp);
+  else return pair_term(px, py, qx, qy, force, clamp);
+}
+template <class T> __device__ __forceinline__ typename Vec2Of<T>::type neg_zero2() {
+  typename Vec2Of<T>::type v;
+  v.x = (T)-0.0;
+  v.y = (T)-0.0;
+  return v;
+}
+
+// The counting traversal for either precision: node tests only (walk_pass<false> is its f32 twin).
+template <class T>
+__global__ __launch_bounds__(256) void walk_count(const WalkArgs<T> a, uint32_t* __restrict__ cnt) {
+  using T2 = typename Vec2Of<T>::type;
+  using T4 = typename Vec4Of<T>::type;
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool live = t < a.n_tgt;
+  const int64_t row = live ? (a.tgt_index ? (int64_t)a.tgt_index[t] : t) : 0;
+  const T2 p = live ? reinterpret_cast<const T2*>(a.tgt_pos)[row] : T2{0, 0};
+  const T4* __restrict__ g0 = reinterpret_cast<const T4*>(a.geom0);
+  const T4* __restrict__ g1 = reinterpret_cast<const T4*>(a.geom1);
+  const int4* __restrict__ lk = reinterpret_cast<const int4*>(a.link);
+  const T theta = a.theta;
+  const int n_nodes = a.n_nodes;
+  int resume = live ? 0 : n_nodes;
+  uint32_t n_terms = 0;
+  int i = 0;
+  while (i < n_nodes) {
+    const int4 l = lk[i];
+    const T4 b = g0[i];
+    const T4 c = g1[i];
+    const bool act = resume <= i;
+    int next;
+    if (l.w) {
+      if (act) {
+        n_terms += (uint32_t)l.z;
+        resume = l.x;
+      }
+      next = l.x;
+    } else {
+      bool descend = false;
+      if (act) {
+        const bool contains = p.y > b.y && p.x > b.x && p.x < b.z && p.y < b.w;
+        const T ddx = p.x - c.x, ddy = p.y - c.y;
+        const T d2 = ddx * ddx + ddy * ddy;
+        if (!contains && c.w < d2 * theta * theta) {
+          ++n_terms;
+          resume = l.x;
+        } else {
+          descend = true;
+          resume = i + 1;
+        }
+      }
+      next = __builtin_amdgcn_ballot_w64(descend) != 0 ? i + 1 : l.x;
+    }
+    i = __builtin_amdgcn_readfirstlane(next);
+  }
+  if (live) cnt[t] = n_terms;
+}
+
 // The traversal both passes share.  F: what to do with an accepted node / a leaf.
 template <bool EMIT, int kTPW, bool FAST>
 __global__ __launch_bounds__(256) void walk_pass(const WalkArgs<float> a, uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off,
@@ -254,18 +348,20 @@ __global__ __launch_bounds__(256) void walk_sum(const WalkArgs<float> a, const u
 // takers cost - but the terms never leave the CU: up to TT acting targets of the wave are evaluated against the leaf
 // (one round each, a row of the wave's LDS tile), then every one of those targets' own lanes adds its row in slice
 // order (lane = target again: TT independent chains at once).  No term array (8 B per pair written and read back), no
-// sum pass, no capacity to outgrow.  Waves are still cut by work; the estimate is the scan of the targets' term counts
-// of the PREVIOUS walk over the same target set (position t in tree order: a spatial neighbourhood that changes little
-// from step to step) or, when there is none, of a counting traversal.  A bad estimate costs balance, never correctness:
-// each target's additions are the fused walk's, in its order.
-template <bool FAST, int TT>
-__global__ __launch_bounds__(256) void walk_tile(const WalkArgs<float> a, const uint32_t* __restrict__ off, const int* __restrict__ info,
+// sum pass, no capacity to outgrow.  Waves are still cut by work; the estimate is the scan of the term counts the
+// targets' particles (by id: the build permutes the rows) had in the PREVIOUS walk or, when there is none, of a
+// counting traversal.  A bad estimate costs balance, never correctness: each target's additions are the fused
+// walk's, in its order.  f32 and f64 (rows of 16-byte terms: half as many waves stay resident).
+template <class T, bool FAST, int TT>
+__global__ __launch_bounds__(256) void walk_tile(const WalkArgs<T> a, const uint32_t* __restrict__ off, const int* __restrict__ info,
                                                  const uint32_t* __restrict__ tgt_ids, uint32_t* __restrict__ hist,
                                                  unsigned long long* __restrict__ total_out) {
-  constexpr int kStride = 65;  // float2 per row: rows of different targets start in different banks
-  __shared__ float2 tile_all[4][TT * kStride];
+  using T2 = typename Vec2Of<T>::type;
+  using T4 = typename Vec4Of<T>::type;
+  constexpr int kStride = 65;  // terms per row + 1: rows of different targets start in different banks
+  __shared__ T2 tile_all[4][TT * kStride];
   const int lane = threadIdx.x & 63;
-  float2* __restrict__ tile = tile_all[threadIdx.x >> 6];
+  T2* __restrict__ tile = tile_all[threadIdx.x >> 6];
   const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (info[1] != 0) return;  // the estimate's scan wrapped: the caller takes the fused walk
   const uint32_t budget = (uint32_t)info[3];
@@ -284,22 +380,22 @@ __global__ __launch_bounds__(256) void walk_tile(const WalkArgs<float> a, const 
   const int64_t t = t0 + lane;
   const bool live = t < lo;
   const int64_t row = live ? (a.tgt_index ? (int64_t)a.tgt_index[t] : t) : 0;
-  const float2 p = live ? reinterpret_cast<const float2*>(a.tgt_pos)[row] : make_float2(0.f, 0.f);
-  const float4* __restrict__ g0 = reinterpret_cast<const float4*>(a.geom0);
-  const float4* __restrict__ g1 = reinterpret_cast<const float4*>(a.geom1);
+  const T2 p = live ? reinterpret_cast<const T2*>(a.tgt_pos)[row] : T2{0, 0};
+  const T4* __restrict__ g0 = reinterpret_cast<const T4*>(a.geom0);
+  const T4* __restrict__ g1 = reinterpret_cast<const T4*>(a.geom1);
   const int4* __restrict__ lk = reinterpret_cast<const int4*>(a.link);
-  const float2* __restrict__ lpos = reinterpret_cast<const float2*>(a.leaf_pos);
-  const float* __restrict__ lmass = a.leaf_mass;
-  const float theta = a.theta, clamp = a.clamp;
+  const T2* __restrict__ lpos = reinterpret_cast<const T2*>(a.leaf_pos);
+  const T* __restrict__ lmass = a.leaf_mass;
+  const T theta = a.theta, clamp = a.clamp;
   const int n_nodes = a.n_nodes;
   int resume = live ? 0 : n_nodes;
   uint32_t n_terms = 0;
-  float ax = 0.f, ay = 0.f;  // Vec2::zero(), main.rs:409
+  T ax = 0, ay = 0;  // Vec2::zero(), main.rs:409
   int i = 0;
   while (i < n_nodes) {  // i is wave-uniform
     const int4 l = lk[i];
-    const float4 b = g0[i];
-    const float4 c = g1[i];
+    const T4 b = g0[i];
+    const T4 c = g1[i];
 #ifndef NB_TILE_LATE_GEOM
     asm volatile("" : : "s"(b.x), "s"(c.w));  // the three records together: one latency per step (the compiler sinks the two
                                               // it needs in the node arm only into that arm, behind the first one's wait)
@@ -314,8 +410,8 @@ __global__ __launch_bounds__(256) void walk_tile(const WalkArgs<float> a, const 
           const int mine = k0 + lane;
           const int left = l.z - k0;
           const int rounds8 = ((left < 64 ? left : 64) + 7) >> 3;
-          float2 q = make_float2(0.f, 0.f);
-          float m = 0.f;
+          T2 q = T2{0, 0};
+          T m = 0;
           if (mine < l.z) {
             q = lpos[l.y + mine];
             m = lmass[l.y + mine];
@@ -325,9 +421,9 @@ __global__ __launch_bounds__(256) void walk_tile(const WalkArgs<float> a, const 
             // arm; the same additions in the same order, so the two arms mix freely)
             const int mc = left < 64 ? left : 64;
             for (int j = 0; j < mc; ++j) {
-              const float qx = lane_f(q.x, j), qy = lane_f(q.y, j), qm = lane_f(m, j);
+              const T qx = lane_t(q.x, j), qy = lane_t(q.y, j), qm = lane_t(m, j);
               if (act) {
-                const float2 term = term_of<FAST>(p.x, p.y, qx, qy, qm, clamp);
+                const T2 term = term_of<FAST>(p.x, p.y, qx, qy, qm, clamp);
                 ax = ax + term.x;
                 ay = ay + term.y;
               }
@@ -340,17 +436,17 @@ __global__ __launch_bounds__(256) void walk_tile(const WalkArgs<float> a, const 
             while (todo && slot < TT) {  // lane = particle: one acting target per round, its terms into row `slot`
               const int tl = __builtin_ctzll(todo);
               todo &= todo - 1;
-              const float tx = lane_f(p.x, tl), ty = lane_f(p.y, tl);
-              const float2 term = term_of<FAST>(tx, ty, q.x, q.y, m, clamp);
-              tile[slot * kStride + lane] = mine < l.z ? term : make_float2(-0.0f, -0.0f);  // past the leaf: the identity of addition
+              const T tx = lane_t(p.x, tl), ty = lane_t(p.y, tl);
+              const T2 term = term_of<FAST>(tx, ty, q.x, q.y, m, clamp);
+              tile[slot * kStride + lane] = mine < l.z ? term : neg_zero2<T>();  // past the leaf: the identity of addition
               if (lane == tl) myslot = slot;
               ++slot;
             }
             __builtin_amdgcn_wave_barrier();
             if (myslot >= 0) {  // lane = target: its row, in slice order
-              const float2* __restrict__ r = tile + myslot * kStride;
+              const T2* __restrict__ r = tile + myslot * kStride;
               for (int j0 = 0; j0 < rounds8; ++j0) {
-                float2 v[8];
+                T2 v[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = r[j0 * 8 + j];
 #pragma unroll
@@ -373,10 +469,10 @@ __global__ __launch_bounds__(256) void walk_tile(const WalkArgs<float> a, const 
       bool descend = false;
       if (act) {
         const bool contains = p.y > b.y && p.x > b.x && p.x < b.z && p.y < b.w;  // bvh_tree.rs:15-20 (all strict)
-        const float ddx = p.x - c.x, ddy = p.y - c.y;                              // dist2(p, cog), main.rs:228-232
-        const float d2 = ddx * ddx + ddy * ddy;
+        const T ddx = p.x - c.x, ddy = p.y - c.y;                              // dist2(p, cog), main.rs:228-232
+        const T d2 = ddx * ddx + ddy * ddy;
         if (!contains && c.w < d2 * theta * theta) {                               // :370-372
-          const float2 term = term_of<FAST>(p.x, p.y, c.x, c.y, c.z, clamp);       // :374-379
+          const T2 term = term_of<FAST>(p.x, p.y, c.x, c.y, c.z, clamp);           // :374-379
           ax = ax + term.x;
           ay = ay + term.y;
           ++n_terms;
@@ -391,7 +487,7 @@ __global__ __launch_bounds__(256) void walk_tile(const WalkArgs<float> a, const 
     i = __builtin_amdgcn_readfirstlane(next);
   }
   if (live) {
-    reinterpret_cast<float2*>(a.acc)[row] = make_float2(ax, ay);
+    reinterpret_cast<T2*>(a.acc)[row] = T2{ax, ay};
     if (hist) hist[tgt_ids[t]] = n_terms;  // by particle id: the rows are permuted by every build
   }
   unsigned long long sum = live ? n_terms : 0ull;  // what this walk cost, for the next estimate's scale
@@ -430,7 +526,12 @@ inline uint32_t tile_budget_targets() {
 inline int tile_targets() {
   const char* e = getenv("NBODY_WALK_TILE_TARGETS");
   const int v = e ? atoi(e) : 8;  // 8 rows keep the tile at 4 KB per wave: eight waves per SIMD
-  return (v == 16 || v == 32) ? v : 8;
+  return (v == 16 || v == 4) ? v : 8;
+}
+inline int tile_targets_f64() {  // rows are twice as wide: 4 rows for eight waves per SIMD, 8 for four
+  const char* e = getenv("NBODY_WALK_TILE_TARGETS");
+  const int v = e ? atoi(e) : 8;
+  return (v == 16 || v == 4) ? v : 8;
 }
 
 }  // namespace
@@ -475,7 +576,8 @@ hipError_t launch_tree_walk_split(hipStream_t s, const WalkArgs<float>& a, char*
 }
 
 
-hipError_t launch_tree_walk_tile(hipStream_t s, const WalkArgs<float>& a, char* scratch, const WalkSplitLayout& L, const uint32_t* tgt_ids,
+template <class T>
+hipError_t launch_tree_walk_tile(hipStream_t s, const WalkArgs<T>& a, char* scratch, const WalkSplitLayout& L, const uint32_t* tgt_ids,
                                  uint32_t* hist, int estimate, int shift) {
   const bool have_history = estimate != 0;  // 1: from hist; 2: none at all (every wave takes 64 targets)
   if (a.n_tgt <= 0) return hipSuccess;
@@ -488,7 +590,7 @@ hipError_t launch_tree_walk_tile(hipStream_t s, const WalkArgs<float>& a, char* 
   if (!have_history) {  // no counts of an earlier walk over these targets: count (exact, so shift 0)
     shift = 0;
     const int64_t cwaves = (a.n_tgt + kCountTPW - 1) / kCountTPW;
-    walk_pass<false, kCountTPW, false><<<dim3((unsigned)((cwaves + 3) / 4)), dim3(256), 0, s>>>(a, cnt, nullptr, nullptr, info, 0);
+    walk_count<T><<<dim3((unsigned)((cwaves + 3) / 4)), dim3(256), 0, s>>>(a, cnt);
     e = hipcub::DeviceScan::ExclusiveSum((void*)(scratch + L.cub_temp), tb, (const uint32_t*)cnt, off, (int)a.n_tgt, s);
     if (e != hipSuccess) return e;
     walk_check_wrap<<<dim3((unsigned)((a.n_tgt + 255) / 256)), dim3(256), 0, s>>>(cnt, off, a.n_tgt, info);
@@ -507,13 +609,16 @@ hipError_t launch_tree_walk_tile(hipStream_t s, const WalkArgs<float>& a, char* 
   walk_tile_total<<<dim3(1), dim3(1), 0, s>>>(have_history ? nullptr : cnt, off, a.n_tgt, tgt_ids, estimate == 1 ? hist : nullptr, shift, extra, info);
   const int64_t twaves = extra + a.n_tgt / 64 + 4;  // upper bound of g(t) + 1 (budget >= total / extra)
   unsigned long long* total_out = (unsigned long long*)(info + 6);
-  const int tt = tile_targets();
+  const int tt = sizeof(T) == 8 ? tile_targets_f64() : tile_targets();
   const dim3 grid((unsigned)((twaves + 3) / 4));
-#define NB_TILE(F, T) walk_tile<F, T><<<grid, dim3(256), 0, s>>>(a, off, info, tgt_ids, hist, total_out)
-  if (a.fast) { if (tt == 16) NB_TILE(true, 16); else if (tt == 32) NB_TILE(true, 32); else NB_TILE(true, 8); }
-  else { if (tt == 16) NB_TILE(false, 16); else if (tt == 32) NB_TILE(false, 32); else NB_TILE(false, 8); }
+#define NB_TILE(F, R) walk_tile<T, F, R><<<grid, dim3(256), 0, s>>>(a, off, info, tgt_ids, hist, total_out)
+  if (a.fast) { if (tt == 16) NB_TILE(true, 16); else if (tt == 4) NB_TILE(true, 4); else NB_TILE(true, 8); }
+  else { if (tt == 16) NB_TILE(false, 16); else if (tt == 4) NB_TILE(false, 4); else NB_TILE(false, 8); }
 #undef NB_TILE
   return hipGetLastError();
 }
+
+template hipError_t launch_tree_walk_tile<float>(hipStream_t, const WalkArgs<float>&, char*, const WalkSplitLayout&, const uint32_t*, uint32_t*, int, int);
+template hipError_t launch_tree_walk_tile<double>(hipStream_t, const WalkArgs<double>&, char*, const WalkSplitLayout&, const uint32_t*, uint32_t*, int, int);
 
 }  // namespace nbody
