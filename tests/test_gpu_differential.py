@@ -46,9 +46,14 @@ def test_direct_exact_differential(nb, orc, seed):
     assert np.array_equal(p, rp, equal_nan=True) and np.array_equal(v, rv, equal_nan=True)
 
 
+@pytest.mark.parametrize("walk", ["default", "one pass forced", "three passes forced"])
 @pytest.mark.parametrize("order", ["as_written", "consistent"])
 @pytest.mark.parametrize("seed", range(10))
-def test_bvh_step_differential(nb, orc, seed, order):
+def test_bvh_step_differential(nb, orc, monkeypatch, seed, order, walk):
+    """`walk`: these inputs are too small for the lane = particle walks to be chosen by themselves; forcing them puts
+    duplicates, wrapped and zero masses, infinite and NaN terms through the LDS tile / the term array as well."""
+    if walk != "default":
+        monkeypatch.setenv("NBODY_WALK_SPLIT", "3" if walk.startswith("one") else "2")
     n = 500 + 211 * seed
     pos, vel, w = _case(seed, n)
     theta = [50.0, 0.5, 2.0][seed % 3]
