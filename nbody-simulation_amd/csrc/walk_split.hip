@@ -597,6 +597,10 @@ hipError_t launch_tree_walk_tile(hipStream_t s, const WalkArgs<T>& a, char* scra
   } else {
     hipcub::CountingInputIterator<int> idx(0);
     hipcub::TransformInputIterator<uint32_t, EstimateOf, hipcub::CountingInputIterator<int>> est(idx, EstimateOf{estimate == 1 ? hist : nullptr, tgt_ids, shift});
+    size_t need = 0;  // the layout sized the scan's scratch for plain pointers: make sure this iterator asks for no more
+    e = hipcub::DeviceScan::ExclusiveSum(nullptr, need, est, off, (int)a.n_tgt, s);
+    if (e != hipSuccess) return e;
+    if (need > tb) return hipErrorInvalidValue;
     e = hipcub::DeviceScan::ExclusiveSum((void*)(scratch + L.cub_temp), tb, est, off, (int)a.n_tgt, s);
     if (e != hipSuccess) return e;
   }
