@@ -30,10 +30,7 @@ cases = [("reference scene", nb.scenes.galaxy(), 50.0), ("plummer 1M", nb.scenes
          ("plummer 256k th 5", nb.scenes.plummer(1 << 18, seed=5, dtype=np.float32), 5.0),
          ("plummer 64k th 0.5", nb.scenes.plummer(1 << 16, seed=6, dtype=np.float32), 0.5),
          ("uniform 1M", ((np.random.default_rng(1).random((1 << 20, 2)) * 1e5).astype(np.float32), np.zeros((1 << 20, 2), np.float32), np.ones(1 << 20, np.uint32)), 50.0)]
-variants = [("three passes (NBODY_WALK_SPLIT=4)", {"NBODY_WALK_SPLIT": "4"}), ("one pass (default)", {}), ("one pass, budget of 48 targets", {"NBODY_WALK_TILE_BUDGET_TARGETS": "48"}),
-            ("one pass, aiming at 6144 waves", {"NBODY_WALK_TILE_WAVES": "6144"}), ("one pass, aiming at 8192 waves", {"NBODY_WALK_TILE_WAVES": "8192"}),
-            ("one pass, aiming at 12288 waves", {"NBODY_WALK_TILE_WAVES": "12288"}), ("one pass, aiming at 32768 waves", {"NBODY_WALK_TILE_WAVES": "32768"}),
-            ("fused", {"NBODY_WALK_SPLIT": "0"})]
+variants = [("three passes (NBODY_WALK_SPLIT=4)", {"NBODY_WALK_SPLIT": "4"}), ("one pass (default)", {}), ("fused", {"NBODY_WALK_SPLIT": "0"})]
 for name, (pos, vel, w), theta in cases:
     ref = None
     for vname, env in variants:
