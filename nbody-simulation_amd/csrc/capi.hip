@@ -827,6 +827,7 @@ int tree_walk_phase(nbody_ctx* c, State<T>& s, int kind, const void* tgt_pos, in
       const bool self = tgt_pos == nullptr;
       if (self && !s.wt_hist) {
         HIPCHK(c, hipMalloc((void**)&s.wt_hist, (size_t)(s.n > 0 ? s.n : 1) * 4));
+        HIPCHK(c, hipMemsetAsync(s.wt_hist, 0, (size_t)(s.n > 0 ? s.n : 1) * 4, c->stream));  // a shard's slice never writes the other ids
         s.wt_hist_n = -1;
       }
       // the targets' particle ids (the snapshot's rows under AS_WRITTEN, the permuted rows otherwise)
@@ -835,6 +836,8 @@ int tree_walk_phase(nbody_ctx* c, State<T>& s, int kind, const void* tgt_pos, in
       const bool hist = self && s.wt_hist_n == w.n_tgt && s.wt_hist_begin == slice_begin && env_int("NBODY_WALK_TILE_COUNT", 0) == 0;
       int shift = 0;
       while (hist && (s.wt_total >> shift) >= (1ull << 31)) ++shift;
+      if (hist && env_int("NBODY_WALK_TILE_POISON", 0) != 0)  // test hook: a history whose scan wraps must be noticed
+        HIPCHK(c, hipMemsetAsync(s.wt_hist, 0xFF, (size_t)s.n * 4, c->stream));
       int info[8] = {0, 0, 0, 0, 0, 0, 0, 0};
       unsigned long long total = 0;
       for (int estimate = hist ? 1 : 0; !done; estimate = 2) {
@@ -848,9 +851,10 @@ int tree_walk_phase(nbody_ctx* c, State<T>& s, int kind, const void* tgt_pos, in
         if (env_int("NBODY_TRACE", 0) != 0)
           std::fprintf(stderr, "[nbody] tile walk: %llu terms, estimate %s (shift %d, total %d), %d per wave, overflow %d\n", total,
                        estimate == 1 ? "from the last walk" : (estimate == 0 ? "counted" : "none"), shift, info[0], info[3], info[1]);
-        // a counted estimate that does not fit 32 bits: walk without one (the counts it leaves behind are scaled next time)
+        // an estimate whose scan does not fit (a counted one past 2^32 terms; counts of older walks under another theta
+        // in a shard's new slice): walk without one (the counts it leaves behind are scaled next time)
         done = info[1] == 0;
-        if (!done && estimate != 0) return fail(c, NBODY_ERR_HIP, "tile walk: overflow flag without a counted estimate");
+        if (!done && estimate == 2) return fail(c, NBODY_ERR_HIP, "tile walk: overflow flag without an estimate");
       }
       s.wt_hist_n = self ? w.n_tgt : -1;
       s.wt_hist_begin = slice_begin;

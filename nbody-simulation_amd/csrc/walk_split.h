@@ -25,7 +25,7 @@ hipError_t launch_tree_walk_split(hipStream_t s, const WalkArgs<float>& a, char*
 // target t's particle in the previous walk (scaled down by `shift` bits so that the sum stays below 2^31); 0: a counting
 // traversal runs first; 2: none (64 targets per wave; for walks whose counts overflow 32 bits and have no history yet).
 // hist (may be null: nothing is recorded) receives this walk's counts, by particle id.
-// info afterwards: [1] != 0: nothing was written to acc (the counted estimate overflowed 32 bits: use the fused walk);
+// info afterwards: [1] != 0: nothing was written to acc (the estimate's scan overflowed: call again with estimate 2);
 // info[6..7]: this walk's total terms (unsigned long long).
 template <class T>
 hipError_t launch_tree_walk_tile(hipStream_t s, const WalkArgs<T>& a, char* scratch, const WalkSplitLayout& L, const uint32_t* tgt_ids,

@@ -502,6 +502,16 @@ struct EstimateOf {  // target t's terms in the last walk, scaled
   int shift;
   __host__ __device__ __forceinline__ uint32_t operator()(int t) const { return hist ? hist[ids[t]] >> shift : 0u; }
 };
+// the scan of a history estimate must not wrap either: the shift is sized from the last walk's total, but a target set
+// that is not the last one (a shard's slice moves with the tree order) may hold counts of older walks
+__global__ __launch_bounds__(256) void walk_check_wrap_est(EstimateOf est, const uint32_t* __restrict__ off, int64_t n, int* __restrict__ info) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i + 1 < n && (unsigned long long)off[i] + est((int)i) != (unsigned long long)off[i + 1]) {
+    info[1] = 1;
+    info[2] = 1;
+  }
+  if (i + 1 == n && (unsigned long long)off[i] + est((int)i) > 0x7fffffffull) info[1] = 1;  // the budget arithmetic is 31 bits wide
+}
 // budget of walk_tile's waves from the estimate's total (see walk_total)
 __global__ void walk_tile_total(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off, int64_t n, const uint32_t* __restrict__ tgt_ids,
                                 const uint32_t* __restrict__ hist, int shift, int64_t extra_waves, int* __restrict__ info) {
@@ -603,6 +613,8 @@ hipError_t launch_tree_walk_tile(hipStream_t s, const WalkArgs<T>& a, char* scra
     if (need > tb) return hipErrorInvalidValue;
     e = hipcub::DeviceScan::ExclusiveSum((void*)(scratch + L.cub_temp), tb, est, off, (int)a.n_tgt, s);
     if (e != hipSuccess) return e;
+    if (estimate == 1)
+      walk_check_wrap_est<<<dim3((unsigned)((a.n_tgt + 255) / 256)), dim3(256), 0, s>>>(EstimateOf{hist, tgt_ids, shift}, off, a.n_tgt, info);
   }
   const char* ew = getenv("NBODY_WALK_TILE_WAVES");  // development override of kTileWaves
   int64_t extra = (ew && atoi(ew) > 0 ? (int64_t)atoi(ew) : kTileWaves) - a.n_tgt / 64;

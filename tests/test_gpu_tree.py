@@ -535,3 +535,25 @@ def test_one_pass_walk_history_survives_changes_between_steps(nb, orc, monkeypat
                                          nsteps=2, nthreads=8)
         got = c.download()
         assert np.array_equal(got[0], p2) and np.array_equal(got[1], v2)
+
+
+def test_one_pass_walk_notices_a_history_whose_scan_wraps(nb, monkeypatch, capfd):
+    """A shard's slice can meet counts of older walks (another theta) whose scaled sum no longer fits 32 bits: the walk
+    must notice and go on without an estimate, not cut its waves by a wrapped scan.  The test hook fills the history
+    with 0xFFFFFFFF before every walk that would use it."""
+    C = nb._capi
+    pos, vel, w = nb.scenes.galaxy()
+    pos, vel, w = pos[::3].copy(), vel[::3].copy(), w[::3].copy()
+    res = []
+    for poison in ("0", "1"):
+        monkeypatch.setenv("NBODY_WALK_TILE_POISON", poison)
+        monkeypatch.setenv("NBODY_TRACE", "1")
+        with C.Context(0) as c:
+            c.upload(pos, vel, w)
+            c.update_tree(C.TREE_BVH, 0.1, 4)
+            res.append(c.download())
+        err = capfd.readouterr().err
+        assert ("estimate none" in err) == (poison == "1"), err[-600:]
+        assert "estimate from the last walk" in err
+    for a, b in zip(*res):
+        assert np.array_equal(a, b)
