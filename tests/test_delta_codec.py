@@ -145,3 +145,19 @@ def test_bound_is_the_worst_case(nb):
     e = dc.Encoder()
     e.encode(np.zeros((128, 2), np.float32))
     assert len(e.encode(bits.view(np.float32))) <= lib.nbody_delta_bound(128, 0)
+
+
+def test_golden_streams_pin_the_format(nb):
+    """tests/golden/delta_nbd1.npz (make_golden_delta.py): the statement of the format still encodes the committed
+    frames to the committed bytes, and the library's decoder reads those bytes back to the frames."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "delta_nbd1.npz"))
+    for name in ("f32", "f64"):
+        enc, cdec, dec = dc.Encoder(), nb.DeltaDecoder(), dc.Decoder()
+        for k in range(int(g[f"{name}_steps"])):
+            frame, stream = g[f"{name}_frame{k}"], g[f"{name}_stream{k}"].tobytes()
+            assert enc.encode(frame, step=7 * k) == stream, (name, k)
+            cdec.apply(stream)
+            dec.apply(stream)
+            assert cdec.step == 7 * k
+            assert _same_bits(cdec.positions(), frame) and _same_bits(dec.positions(), frame), (name, k)
