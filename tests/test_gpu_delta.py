@@ -161,3 +161,19 @@ def test_headless_driver_prints_the_experiments_two_lines_and_round_trips(nb):
     assert raw == [8 * n] * 3 and len(comp) == 3
     assert comp[0] > 0.9 * raw[0] and comp[2] < 0.5 * raw[0]          # key frame, then deltas
     assert f"differs from the device in 0 of {n} bodies" in r.stdout
+
+
+@pytest.mark.parametrize("name,dtype", [("f32", np.float32), ("f64", np.float64)])
+def test_device_key_frame_equals_the_committed_golden_stream(nb, name, dtype):
+    """tests/golden/delta_nbd1.npz: the device encoder produces the committed bytes for the committed frame (a key
+    frame: the first stream after an upload)."""
+    import os
+    C = nb._capi
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "delta_nbd1.npz"))
+    frame = g[f"{name}_frame0"]
+    assert frame.dtype == dtype
+    with C.Context(0) as ctx:
+        ctx.upload(frame, np.zeros_like(frame), np.ones(frame.shape[0], np.uint32))
+        ctx.delta_begin()
+        stream, step = ctx.delta_end()
+    assert step == 0 and stream == g[f"{name}_stream0"].tobytes()
