@@ -238,6 +238,10 @@ void nbody_delta_decoder_destroy(nbody_delta_decoder* dec);
 /* Applies one stream.  A malformed, truncated or out-of-sequence stream (a delta before any key frame, another n or
  * element size than the state) fails with NBODY_ERR_INVALID and leaves the decoder as it was. */
 int nbody_delta_decoder_apply(nbody_delta_decoder* dec, const uint8_t* stream, size_t bytes);
+/* The stream is untrusted input: a header may claim up to 2^31 - 1 bodies with an all-zero-width payload of a few MB,
+ * i.e. ~100 GB of decoder state.  A stream claiming more than max_bodies is refused before anything is allocated
+ * (default 2^31 - 1; a failed allocation is also a refusal, with the state untouched). */
+int nbody_delta_decoder_set_max_bodies(nbody_delta_decoder* dec, int64_t max_bodies);
 const char* nbody_delta_decoder_error(const nbody_delta_decoder* dec);
 int64_t nbody_delta_decoder_count(const nbody_delta_decoder* dec);   /* bodies of the current state, -1 before a key frame */
 int nbody_delta_decoder_is_f64(const nbody_delta_decoder* dec);

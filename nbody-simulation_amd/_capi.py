@@ -96,6 +96,7 @@ _SIGS = {
     "nbody_delta_decoder_create": (_vp, []),
     "nbody_delta_decoder_destroy": (None, [_vp]),
     "nbody_delta_decoder_apply": (C.c_int, [_vp, _vp, _sz]),
+    "nbody_delta_decoder_set_max_bodies": (C.c_int, [_vp, _i64]),
     "nbody_delta_decoder_error": (C.c_char_p, [_vp]),
     "nbody_delta_decoder_count": (_i64, [_vp]),
     "nbody_delta_decoder_is_f64": (C.c_int, [_vp]),
@@ -238,6 +239,12 @@ class DeltaDecoder:
             self.h = None
 
     __del__ = close
+
+    def set_max_bodies(self, n: int):
+        """Refuse streams whose header claims more than n bodies (the stream is untrusted input)."""
+        rc = self.lib.nbody_delta_decoder_set_max_bodies(self.h, int(n))
+        if rc != 0:
+            raise NBodyError(rc, "delta decoder: set_max_bodies")
 
     def apply(self, stream: bytes):
         buf = np.frombuffer(bytes(stream), np.uint8)

@@ -1373,7 +1373,16 @@ NB_API int nbody_delta_decoder_is_f64(const nbody_delta_decoder* d) { return d &
 NB_API uint64_t nbody_delta_decoder_step(const nbody_delta_decoder* d) { return d ? d->d.step : 0; }
 NB_API int nbody_delta_decoder_apply(nbody_delta_decoder* d, const uint8_t* stream, size_t bytes) {
   if (!d) return NBODY_ERR_INVALID;
-  return d->d.apply(stream, bytes) ? NBODY_OK : NBODY_ERR_INVALID;
+  try {  // nothing may unwind through the C ABI (the decoder itself already turns a failed allocation into a refusal)
+    return d->d.apply(stream, bytes) ? NBODY_OK : NBODY_ERR_INVALID;
+  } catch (...) {
+    return NBODY_ERR_NOMEM;
+  }
+}
+NB_API int nbody_delta_decoder_set_max_bodies(nbody_delta_decoder* d, int64_t max_bodies) {
+  if (!d || max_bodies < 0) return NBODY_ERR_INVALID;
+  d->d.max_bodies = (uint64_t)max_bodies;
+  return NBODY_OK;
 }
 NB_API int nbody_delta_decoder_positions_f32(const nbody_delta_decoder* d, float* pos) {
   return d && d->d.positions<float, uint32_t>(pos) ? NBODY_OK : NBODY_ERR_INVALID;

@@ -4,6 +4,7 @@
 #pragma once
 #include <cstdint>
 #include <cstring>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -15,7 +16,8 @@ struct DeltaDecoder {
   int bits = 0;
   int64_t n = -1;  // -1: no key frame applied yet
   uint64_t step = 0;
-  std::vector<uint64_t> prev, prev2, next;  // keys, x then y, 64 * ceil(n/64) each (u32 keys are stored widened)
+  std::vector<uint64_t> prev, prev2;  // keys, x then y, 64 * ceil(n/64) each (u32 keys are stored widened)
+  uint64_t max_bodies = 0x7fffffffULL;  // caller-set cap on the body count a header may claim (the stream is untrusted)
   std::string err;
 
   bool fail(const char* msg) {
@@ -34,7 +36,7 @@ struct DeltaDecoder {
     std::memcpy(&n64, stream + 8, 8);
     std::memcpy(&sstep, stream + 16, 8);
     std::memcpy(&total, stream + 24, 8);
-    if (n64 > 0x7fffffffULL) return fail("delta stream: body count out of range");
+    if (n64 > 0x7fffffffULL || n64 > max_bodies) return fail("delta stream: body count out of range");
     const int64_t sn = (int64_t)n64;
     const size_t nblk = delta_blocks(sn), npad = nblk * 64, wb = delta_width_bytes(sn);
     if (total > 2 * nblk * (uint64_t)sbits || bytes != kDeltaHeader + wb + (size_t)total * 8)
@@ -52,12 +54,17 @@ struct DeltaDecoder {
     for (size_t i = 2 * nblk; i < wb; ++i)
       if (widths[i]) return fail("delta stream: non-zero padding");
     if (sum != total) return fail("delta stream: the widths do not add up to the payload");
-    // valid from here on: the state may change
-    if (key) {
-      prev.assign(2 * npad, 0);
-      prev2.assign(2 * npad, 0);
+    // valid from here on.  The new state is built aside and swapped in at the end, so that a failed allocation (a
+    // header may claim 2^31 bodies with an all-zero-width payload of a few MB) leaves the decoder as it was.
+    std::vector<uint64_t> next, zeros;
+    try {
+      next.assign(2 * npad, 0);
+      if (key) zeros.assign(2 * npad, 0);
+    } catch (const std::bad_alloc&) {
+      return fail("delta stream: out of memory for the body count its header claims");
     }
-    next.assign(2 * npad, 0);
+    const std::vector<uint64_t>& old1 = key ? zeros : prev;
+    const std::vector<uint64_t>& old2 = key ? zeros : prev2;
     const uint64_t mask = sbits == 64 ? ~0ull : 0xFFFFFFFFull;
     const uint8_t* pay = stream + kDeltaHeader + wb;
     for (size_t blk = 0; blk < nblk; ++blk)
@@ -72,13 +79,13 @@ struct DeltaDecoder {
         }
         const size_t base = (size_t)co * npad + blk * 64;
         for (int l = 0; l < 64; ++l) {
-          const uint64_t p1 = prev[base + l], p2 = prev2[base + l];
+          const uint64_t p1 = old1[base + l], p2 = old2[base + l];
           const uint64_t pred = (wbyte & 128) ? (p1 + (p1 - p2)) : p1;
           const uint64_t r = sbits == 64 ? delta_unzigzag(z[l]) : (uint64_t)delta_unzigzag((uint32_t)z[l]);
           next[base + l] = (pred + r) & mask;
         }
       }
-    prev2.swap(prev);
+    if (key) prev2.swap(zeros); else prev2.swap(prev);
     prev.swap(next);
     n = sn;
     bits = sbits;

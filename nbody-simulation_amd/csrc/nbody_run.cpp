@@ -52,6 +52,18 @@ static std::vector<Particle> scene(uint64_t seed) {
 }
 
 int main(int argc, char** argv) {
+  // nbody_run dump <path> [seed]: the generated scene as raw little-endian rows {x, y, vx, vy: f32, weight: u32} — no
+  // device involved; tests/test_scene_statistics.py checks it against what World::new (main.rs:276-346) prescribes
+  if (argc > 2 && !std::strcmp(argv[1], "dump")) {
+    const uint64_t dseed = argc > 3 ? std::strtoull(argv[3], nullptr, 0) : 0xC0FFEEull;
+    const std::vector<Particle> p = scene(dseed);
+    static_assert(sizeof(Particle) == 20, "Particle is five 4-byte fields");
+    FILE* f = std::fopen(argv[2], "wb");
+    if (!f || std::fwrite(p.data(), sizeof(Particle), p.size(), f) != p.size()) { std::perror("nbody_run dump"); return 1; }
+    std::fclose(f);
+    std::printf("len: %zu\n", p.size());
+    return 0;
+  }
   int steps = argc > 1 ? std::atoi(argv[1]) : 100;
   Method method = Method::Bvh;
   if (argc > 2 && !std::strcmp(argv[2], "quad")) method = Method::Quad;

@@ -5,6 +5,17 @@
 
 namespace nbody {
 
+// LDS written by some lanes of a wave and read by other lanes of the same wave: wave_barrier alone is a scheduling
+// barrier (IntrNoMem), not a memory fence, so the hand-off is release -> barrier -> acquire at wavefront scope
+// (the form bvh_build.hip's group_sync<1> uses).  Costs nothing at run time: a wave's LDS accesses complete in order.
+__device__ __forceinline__ void wave_lds_handoff() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
+}
+
 template <class T> struct WalkArgs {
   const void* geom0;      // T4[n_nodes]  lo.x lo.y hi.x hi.y
   const void* geom1;      // T4[n_nodes]  cog.x cog.y mass s2

@@ -328,14 +328,14 @@ __global__ __launch_bounds__(256) void tree_walk_small(const WalkArgs<T> a, cons
           q = lpos[l.y + j];
           qm = lmass[l.y + j];
         }
-        __builtin_amdgcn_wave_barrier();
+        wave_lds_handoff();
         for (int r = 0; r < rounds; ++r) {
           const int tr = r * tpr + slot;
           if (slot < tpr && tr < takers) {
             const T2 tp = s_pos[tr];
             s_term[lane] = pair_term_t<T>(tp.x, tp.y, q.x, q.y, qm, clamp);
           }
-          __builtin_amdgcn_wave_barrier();
+          wave_lds_handoff();
           const int mine = rank - r * tpr;
           if (act && mine >= 0 && mine < tpr) {  // this target's m terms, in slice order
             const T2* __restrict__ row_terms = s_term + mine * m;
@@ -345,7 +345,7 @@ __global__ __launch_bounds__(256) void tree_walk_small(const WalkArgs<T> a, cons
               ay = ay + v.y;
             }
           }
-          __builtin_amdgcn_wave_barrier();
+          wave_lds_handoff();
         }
       } else {
         const int end = l.y + m;

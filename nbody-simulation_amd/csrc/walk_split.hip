@@ -442,7 +442,7 @@ __global__ __launch_bounds__(256) void walk_tile(const WalkArgs<T> a, const uint
               if (lane == tl) myslot = slot;
               ++slot;
             }
-            __builtin_amdgcn_wave_barrier();
+            wave_lds_handoff();
             if (myslot >= 0) {  // lane = target: its row, in slice order
               const T2* __restrict__ r = tile + myslot * kStride;
               for (int j0 = 0; j0 < rounds8; ++j0) {
@@ -456,7 +456,7 @@ __global__ __launch_bounds__(256) void walk_tile(const WalkArgs<T> a, const uint
                 }
               }
             }
-            __builtin_amdgcn_wave_barrier();
+            wave_lds_handoff();
           }
         }
       }
@@ -514,16 +514,21 @@ __global__ __launch_bounds__(256) void walk_check_wrap_est(EstimateOf est, const
 }
 // budget of walk_tile's waves from the estimate's total (see walk_total)
 __global__ void walk_tile_total(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off, int64_t n, const uint32_t* __restrict__ tgt_ids,
-                                const uint32_t* __restrict__ hist, int shift, int64_t extra_waves, int* __restrict__ info) {
+                                const uint32_t* __restrict__ hist, int shift, int64_t extra_waves, int64_t grid_waves,
+                                int* __restrict__ info) {
   const uint32_t last = n > 0 ? (cnt ? cnt[n - 1] : (hist ? hist[tgt_ids[n - 1]] >> shift : 0u)) : 0u;
   const unsigned long long total = n > 0 ? (unsigned long long)off[n - 1] + last : 0ull;
   info[0] = (int)(total > 0x7fffffffull ? 0x7fffffffull : total);
   // g(t) = off[t] / budget + t / 64 ends near total / budget + n / 64: `extra_waves` more than the head count alone
-  unsigned long long want = total / (unsigned long long)extra_waves;
+  // (ceiling: with the floor, total / budget could reach extra_waves + extra_waves / want, past the grid)
+  unsigned long long want = (total + (unsigned long long)extra_waves - 1) / (unsigned long long)extra_waves;
   uint32_t budget = kTileBudget >> shift;
   if (budget < 64) budget = 64;
   while (budget < want && budget < (1u << 30)) budget <<= 1;
   info[3] = (int)budget;
+  // belt and braces: a wave index the grid does not hold would leave its targets unwalked — flag it like a wrapped scan,
+  // the host then repeats the walk without an estimate (64 targets per wave, which always fits)
+  if (total / budget + (unsigned long long)(n / 64) + 1 >= (unsigned long long)grid_waves) info[1] = 1;
   info[6] = info[7] = 0;  // this walk's total terms (unsigned long long), accumulated by walk_tile
 }
 
@@ -622,8 +627,9 @@ hipError_t launch_tree_walk_tile(hipStream_t s, const WalkArgs<T>& a, char* scra
   const uint32_t bt = tile_budget_targets();  // development override: a budget of this many average targets
   if (bt) extra = a.n_tgt / bt;
   if (extra < 1) extra = 1;
-  walk_tile_total<<<dim3(1), dim3(1), 0, s>>>(have_history ? nullptr : cnt, off, a.n_tgt, tgt_ids, estimate == 1 ? hist : nullptr, shift, extra, info);
-  const int64_t twaves = extra + a.n_tgt / 64 + 4;  // upper bound of g(t) + 1 (budget >= total / extra)
+  const int64_t twaves = extra + a.n_tgt / 64 + 4;  // upper bound of g(t) + 1 (budget >= ceil(total / extra))
+  walk_tile_total<<<dim3(1), dim3(1), 0, s>>>(have_history ? nullptr : cnt, off, a.n_tgt, tgt_ids, estimate == 1 ? hist : nullptr, shift, extra,
+                                              twaves, info);
   unsigned long long* total_out = (unsigned long long*)(info + 6);
   const int tt = sizeof(T) == 8 ? tile_targets_f64() : tile_targets();
   const dim3 grid((unsigned)((twaves + 3) / 4));

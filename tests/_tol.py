@@ -12,11 +12,13 @@ sum_j |term_j|, the GPU (two-level summation over 256-source blocks) by up to 2.
 With  a_ref64 = every term evaluated in f32 exactly as main.rs:252 writes it, accumulated in double,
       a_cpu32 = the reference order: the same terms accumulated sequentially in f32 (ascending j),
       norm(i) = sum_j | term_ij |_1,
-and e_gpu(i) = | a_gpu(i) - a_ref64(i) |_1 / norm(i), e_cpu(i) likewise for a_cpu32, the checks are, per test:
-      p99_i e_gpu(i)  <=  max(ACC_RTOL, p99_i e_cpu(i))
-      max_i e_gpu(i)  <=  max(ACC_RTOL, max_i e_cpu(i))
-i.e. the GPU is within 2e-5 of the exactly accumulated sum, or else it is still at least as close to it as the
-reference's own summation order is.  EXACT arithmetic is not subject to any tolerance: it is bit-identical.
+and e_gpu(i) = | a_gpu(i) - a_ref64(i) |_1 / norm(i), the checks are, per test and FROZEN (round 2):
+      p99_i e_gpu(i)  <=  ACC_RTOL
+      max_i e_gpu(i)  <=  ACC_RTOL
+i.e. the GPU is within 2e-5 of the exactly accumulated sum for every body.  e_cpu(i), the same figure for the
+reference's own summation order a_cpu32, is printed beside it as a comparison only; it no longer widens the bound
+(round 1 accepted max(ACC_RTOL, e_cpu), which at N = 1M would have let a 250x regression through).
+EXACT arithmetic is not subject to any tolerance: it is bit-identical.
 """
 import numpy as np
 
@@ -30,7 +32,7 @@ def fast_error(acc, ref64, norm):
 
 
 def check_fast(acc, ref64, norm, cpu32=None, label=""):
-    """Asserts the two inequalities above; returns (max e_gpu, max e_cpu or None)."""
+    """Asserts the two inequalities above; returns (max e_gpu, max e_cpu or None).  cpu32 is only printed."""
     r = fast_error(acc, ref64, norm)
     assert np.all(np.isfinite(r)), "non-finite acceleration"
     cap99 = capmax = ACC_RTOL
@@ -38,7 +40,6 @@ def check_fast(acc, ref64, norm, cpu32=None, label=""):
     if cpu32 is not None:
         c = fast_error(cpu32, ref64, norm)
         rc = float(c.max())
-        cap99, capmax = max(cap99, float(np.percentile(c, 99))), max(capmax, rc)
         print(f"[tol]{label} n_tgt={len(r)} e_gpu: median {np.median(r):.2e} p99 {np.percentile(r, 99):.2e} max {r.max():.2e}"
               f" | e_cpu32: median {np.median(c):.2e} p99 {np.percentile(c, 99):.2e} max {rc:.2e}")
     assert np.percentile(r, 99) <= cap99, f"p99 {np.percentile(r, 99):.3e} > {cap99:.3e}"

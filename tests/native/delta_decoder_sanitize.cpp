@@ -142,6 +142,26 @@ int main() {
     if (s.size() >= 16 && t % 2) { uint64_t n = rng() % 300; std::memcpy(&s[8], &n, 8); }
     d.apply(s.empty() ? nullptr : s.data(), s.size());
   }
+  // a forged key-frame header claiming 2^31 - 1 bodies with all-zero widths is a valid 67 MB stream whose state would
+  // need ~100 GB: the caller-set cap refuses it before anything is allocated, and the decoder's state survives
+  {
+    DeltaDecoder dd;
+    Enc<uint32_t> enc;
+    std::vector<uint32_t> bits(2 * 100, 0x42000000u);
+    std::vector<uint8_t> good = enc.encode(bits, 0);
+    if (!dd.apply(good.data(), good.size())) { std::printf("MISMATCH: cap test: valid stream refused\n"); return 1; }
+    const DeltaDecoder before = dd;
+    dd.max_bodies = 1u << 20;
+    const uint64_t huge = 0x7fffffffULL;
+    const size_t wb = delta_width_bytes((int64_t)huge);
+    std::vector<uint8_t> forged(kDeltaHeader + wb, 0);
+    std::memcpy(forged.data(), "NBD1", 4);
+    forged[4] = 32; forged[5] = 1;
+    std::memcpy(&forged[8], &huge, 8);
+    if (dd.apply(forged.data(), forged.size())) { std::printf("MISMATCH: cap test: forged header accepted\n"); return 1; }
+    if (dd.n != before.n || dd.prev != before.prev || dd.prev2 != before.prev2) { std::printf("MISMATCH: cap test: state changed\n"); return 1; }
+    std::printf("cap test: %zu-byte forged key frame for 2^31-1 bodies refused (%s)\n", forged.size(), dd.err.c_str());
+  }
   if (rc == 0) std::printf("OK\n");
   return rc;
 }

@@ -133,6 +133,28 @@ def test_host_decoder_rejects_bad_streams_and_keeps_its_state(nb):
         C.DeltaDecoder().positions()
 
 
+def test_host_decoder_caps_the_body_count_a_header_may_claim(nb):
+    """An untrusted key-frame header may claim 2^31 - 1 bodies with all-zero widths: a valid 67 MB stream that would
+    need ~100 GB of decoder state.  With a caller-set cap it is refused before anything is allocated."""
+    C = nb._capi
+    rng = np.random.default_rng(12)
+    frames = _walk(rng, 100, np.float32, 1)
+    d = nb.DeltaDecoder()
+    d.apply(dc.Encoder().encode(frames[0], step=7))
+    d.set_max_bodies(1 << 20)
+    huge = (1 << 31) - 1
+    nblk = (huge + 63) // 64
+    wb = (2 * nblk + 7) // 8 * 8
+    forged = b"NBD1" + bytes([32, 1, 0, 0]) + struct.pack("<QQQ", huge, 0, 0) + bytes(wb)
+    with pytest.raises(C.NBodyError, match="out of range"):
+        d.apply(forged)
+    assert d.step == 7 and d.n == 100 and _same_bits(d.positions(), frames[0])
+    d.set_max_bodies(99)                                   # the cap also binds honest streams
+    with pytest.raises(C.NBodyError, match="out of range"):
+        d.apply(dc.Encoder().encode(frames[0], step=8))
+    assert d.step == 7
+
+
 def test_bound_is_the_worst_case(nb):
     lib = nb._capi.load()
     for n in (0, 1, 64, 65, 1000):
