@@ -18,8 +18,10 @@
  *   - A context belongs to one host thread at a time (the reference calls update from one dedicated
  *     thread only, main.rs:110-141).  Calls are synchronous unless the name ends in _dev (those enqueue
  *     on the given hipStream_t and return).
- *   - One context = one GPU = one process rank.  Multi-GPU runs shard targets over ranks; the only
- *     exchange is an all-gather of positions per step, done by the host (RCCL) between *_dev calls.
+ *   - nbody_create: one context = one GPU.  nbody_create_multi: one context = several GPUs of one node; every
+ *     nbody_update_* on it shards the step's targets over them and does the step's one exchange (an all-gather
+ *     over xGMI, RCCL) inside the library, so the host keeps its single `world.update` call (main.rs:120).
+ *     A host that runs one process per GPU instead uses the *_dev / *_shard calls and its own collective.
  *   - There is no CPU fallback: without a gfx950 device nbody_create fails with NBODY_ERR_NO_DEVICE.
  */
 #ifndef NBODY_HIP_H
@@ -97,6 +99,25 @@ typedef struct nbody_params {
 /* ---- lifetime ------------------------------------------------------------------------------------- */
 int nbody_abi_version(void);
 int nbody_create(nbody_ctx** out, int device_id);
+/* Several GPUs behind one handle: device_ids[n_devices] (NULL: 0 .. n_devices-1).  Every call of this
+ * header works on the handle as on a single-GPU one — same arguments, same results (bit-identical for tree steps and
+ * EXACT arithmetic; FAST direct sums differ by summation order only) — except the *_shard / export / import calls,
+ * which belong to hosts that shard by themselves.  The caller still drives it from one thread; the library runs one
+ * worker thread per device.
+ *   direct steps: device d owns target blocks {c*G + d}; each chunk of G blocks is all-gathered in place (ncclAllGather)
+ *     on a communication stream while the next chunk computes;
+ *   tree steps: every device builds the same tree, walks and integrates one slice of the tree-ordered targets, one
+ *     packed all-gather of {row, position, velocity} per step.
+ * nbody_create_multi takes RCCL (NBODY_MULTI_EXCHANGE=peer in the environment selects the peer copies).
+ * nbody_create_multi_ex: exchange = NBODY_EXCHANGE_RCCL, or NBODY_EXCHANGE_PEER (hipMemcpyPeerAsync of every block to
+ * every peer; also accepts one physical device listed several times — a rehearsal of the sharding on one GPU);
+ * chunks = 0 picks the number of chunks per step by size (1 .. 8), 1 .. 16 forces it. */
+typedef enum nbody_exchange { NBODY_EXCHANGE_RCCL = 0, NBODY_EXCHANGE_PEER = 1 } nbody_exchange;
+int nbody_create_multi(nbody_ctx** out, int n_devices, const int* device_ids);
+int nbody_create_multi_ex(nbody_ctx** out, int n_devices, const int* device_ids, int exchange, int chunks);
+/* Layout of a context: devices, exchange (-1 for a single-GPU context), chunks per direct step and bodies per target
+ * block of the current upload.  Any pointer may be NULL. */
+int nbody_multi_info(const nbody_ctx* ctx, int* n_devices, int* exchange, int* chunks, int64_t* block);
 void nbody_destroy(nbody_ctx* ctx);
 const char* nbody_last_error(const nbody_ctx* ctx);
 int nbody_default_params(nbody_params* out);
@@ -194,6 +215,22 @@ int nbody_direct_step_dev(void* stream, int64_t n_sources, const void* pos_all, 
                           float uniform_mass, int64_t target_begin, int64_t n_targets, void* vel, void* pos_out, void* acc_out,
                           float delta, float clamp, int arith, void* workspace, size_t workspace_bytes,
                           nbody_timer* timer /* may be NULL */);
+/* The same step in two parts, for hosts that cut a rank's targets into several blocks (to start the exchange of one
+ * block while the next computes): ONE preparation over all positions (hazard scan, near/far split, decision word),
+ * then one run per block.  n_targets_total = all targets this rank computes in the step (decides whether the near/far
+ * split pays), n_targets_max = the largest block (sizes the workspace: nbody_direct_workspace_bytes(n_sources,
+ * n_targets_max)); both calls must be given the same two values.  nbody_direct_step_dev = prep + one run. */
+int nbody_direct_prep_dev(void* stream, int64_t n_sources, const void* pos_all, const void* mass_all, float uniform_mass,
+                          int64_t n_targets_total, int64_t n_targets_max, float clamp, int arith, void* workspace,
+                          size_t workspace_bytes);
+int nbody_direct_run_dev(void* stream, int64_t n_sources, const void* pos_all, const void* mass_all, float uniform_mass,
+                         int64_t target_begin, int64_t n_targets, void* vel, void* pos_out, void* acc_out, float delta,
+                         float clamp, int arith, int64_t n_targets_total, int64_t n_targets_max, void* workspace,
+                         size_t workspace_bytes, nbody_timer* timer /* may be NULL */);
+/* The hipStream_t a context enqueues its steps on (a multi context: its first device's).  A host that mixes the
+ * context's calls with its own stream-ordered work (a collective on the exported slice, say) runs that work on this
+ * stream, or orders against it with events, instead of synchronising the device. */
+void* nbody_get_stream(const nbody_ctx* ctx);
 /* Decision words of the last nbody_direct_step_dev call on that workspace (waits for the stream):
  * out = {hazard flag, split fallback flag, number of near sources, state} with state 0 = near/far split (the main
  * pass skips the clamp for sources proven far from every other body, the near ones are added with it), 1 = one

@@ -20,6 +20,7 @@ OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_DEGENERATE, ERR_NOMEM = 0, -1, -2, 
 ARITH_AUTO, ARITH_FAST, ARITH_EXACT = 0, 1, 2
 ORDER_AS_WRITTEN, ORDER_CONSISTENT = 0, 1
 TREE_BVH, TREE_QUAD = 0, 1
+EXCHANGE_RCCL, EXCHANGE_PEER = 0, 1
 
 
 class NBodyError(RuntimeError):
@@ -49,6 +50,12 @@ _vp, _i64, _i32, _f32, _f64, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.
 _SIGS = {
     "nbody_abi_version": (C.c_int, []),
     "nbody_create": (C.c_int, [C.POINTER(_vp), _i32]),
+    "nbody_create_multi": (C.c_int, [C.POINTER(_vp), _i32, _vp]),
+    "nbody_create_multi_ex": (C.c_int, [C.POINTER(_vp), _i32, _vp, _i32, _i32]),
+    "nbody_multi_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(_i64)]),
+    "nbody_get_stream": (_vp, [_vp]),
+    "nbody_direct_prep_dev": (C.c_int, [_vp, _i64, _vp, _vp, _f32, _i64, _i64, _f32, _i32, _vp, _sz]),
+    "nbody_direct_run_dev": (C.c_int, [_vp, _i64, _vp, _vp, _f32, _i64, _i64, _vp, _vp, _vp, _f32, _f32, _i32, _i64, _i64, _vp, _sz, _vp]),
     "nbody_destroy": (None, [_vp]),
     "nbody_last_error": (C.c_char_p, [_vp]),
     "nbody_default_params": (C.c_int, [C.POINTER(Params)]),
@@ -320,6 +327,17 @@ class Context:
         self.dtype = None
         self.n = 0
 
+    @property
+    def stream(self) -> int:
+        """The hipStream_t the context enqueues its steps on, as an integer (torch.cuda.ExternalStream takes it)."""
+        return int(self.lib.nbody_get_stream(self.h) or 0)
+
+    def multi_info(self):
+        """-> (devices, exchange or -1, chunks per direct step, bodies per target block)."""
+        g, x, c, b = C.c_int(0), C.c_int(0), C.c_int(0), _i64(0)
+        check(self.h, self.lib.nbody_multi_info(self.h, C.byref(g), C.byref(x), C.byref(c), C.byref(b)))
+        return g.value, x.value, c.value, b.value
+
     def close(self):
         if getattr(self, "h", None):
             self.lib.nbody_destroy(self.h)
@@ -493,6 +511,25 @@ class Context:
         return c
 
 
+class MultiContext(Context):
+    """Several GPUs of one node behind one handle (nbody_create_multi): the same calls as Context; the library shards
+    every update over the devices and does the exchange itself (RCCL all-gather, or peer copies)."""
+
+    def __init__(self, devices, exchange: int | None = None, chunks: int = 0):
+        self.lib = load()
+        self.h = _vp()
+        ids = (C.c_int * len(devices))(*[int(d) for d in devices])
+        if exchange is None:
+            rc = self.lib.nbody_create_multi(C.byref(self.h), len(devices), ids)
+        else:
+            rc = self.lib.nbody_create_multi_ex(C.byref(self.h), len(devices), ids, int(exchange), int(chunks))
+        if rc != OK:
+            self.h = None
+            raise _err(None, rc)
+        self.dtype = None
+        self.n = 0
+
+
 # ---- device-pointer level (raw addresses; used with torch tensors by sharding.py / bench.py)
 def direct_workspace_bytes(n_sources: int, n_targets: int) -> int:
     return int(load().nbody_direct_workspace_bytes(int(n_sources), int(n_targets)))
@@ -505,6 +542,25 @@ def direct_step_dev(stream, n_sources, pos_all, mass_all, target_begin, n_target
                                       int(n_targets), _vp(vel) if vel else None, _vp(pos_out) if pos_out else None,
                                       _vp(acc_out) if acc_out else None, float(delta), float(clamp), int(arith),
                                       _vp(workspace), int(workspace_bytes), timer.h if timer else None)
+    check(None, rc)
+
+
+def direct_prep_dev(stream, n_sources, pos_all, mass_all, n_targets_total, n_targets_max, clamp, arith, workspace,
+                    workspace_bytes, uniform_mass: float = 0.0):
+    """One preparation per step over all positions (hazard scan, near/far split); direct_run_dev per target block."""
+    check(None, load().nbody_direct_prep_dev(_vp(stream), int(n_sources), _vp(pos_all), _vp(mass_all), float(uniform_mass),
+                                             int(n_targets_total), int(n_targets_max), float(clamp), int(arith),
+                                             _vp(workspace), int(workspace_bytes)))
+
+
+def direct_run_dev(stream, n_sources, pos_all, mass_all, target_begin, n_targets, vel, pos_out, acc_out, delta, clamp,
+                   arith, n_targets_total, n_targets_max, workspace, workspace_bytes, timer: Timer | None = None,
+                   uniform_mass: float = 0.0):
+    rc = load().nbody_direct_run_dev(_vp(stream), int(n_sources), _vp(pos_all), _vp(mass_all), float(uniform_mass),
+                                     int(target_begin), int(n_targets), _vp(vel) if vel else None,
+                                     _vp(pos_out) if pos_out else None, _vp(acc_out) if acc_out else None, float(delta),
+                                     float(clamp), int(arith), int(n_targets_total), int(n_targets_max), _vp(workspace),
+                                     int(workspace_bytes), timer.h if timer else None)
     check(None, rc)
 
 

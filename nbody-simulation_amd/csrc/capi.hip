@@ -75,6 +75,8 @@ nbody_timer::~nbody_timer() {
 }
 
 // ------------------------------------------------------------------------------------------------ context
+#include "ctx.h"
+
 namespace {
 
 thread_local std::string g_create_error;
@@ -83,132 +85,7 @@ double now_s() {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-template <class T> struct State {
-  using T2 = typename Vec2T<T>::type;
-  struct Set {
-    T2* pos = nullptr;
-    T2* vel = nullptr;
-    uint32_t* weight = nullptr;
-    uint32_t* ids = nullptr;
-    T* mass = nullptr;
-  };
-  int64_t n = 0;
-  Set set[2];
-  int cur = 0;
-  T2* pos_next = nullptr;  // direct step output, swapped with set[cur].pos
-  float uniform_mass = 0.f;  // > 0 when every weight is the same value (checked on upload)
-  T2* acc = nullptr;
-  // tree
-  void* geom0 = nullptr;
-  void* geom1 = nullptr;
-  void* link = nullptr;
-  size_t node_cap = 0;
-  uint32_t* order_dev = nullptr;
-  TreeHost<T> tree;          // host image of the last build (filled lazily after a device build)
-  bool tree_valid = false;
-  bool tree_host_stale = false;  // the last build ran on the device and has not been downloaded
-  int n_nodes = 0, tree_kind = 0, tree_max_depth = 0;
-  int shard_kind = 0;            // tree kind of the last sharded step (decides how a slice maps to rows)
-  int* node_depth = nullptr;     // device build: depth of every node
-  uint32_t* node_mass = nullptr; // device build: u32 mass of every node
-  float2* node_size = nullptr;   // device BVH build: boundary.size of every node
-  size_t node_aux_cap = 0;
-  char* qb_scratch = nullptr;
-  size_t qb_scratch_bytes = 0;
-  char* bb_scratch = nullptr;    // device BVH build
-  size_t bb_scratch_bytes = 0;
-  bool h_weight_stale = false;   // a device BVH build permuted the rows without touching h_weight
-  int quad_depth_hint = 0;       // depth of the last device-built quad tree (how many levels the next build sorts by)
-  // split walk (walk_split.hip): counts/offsets scratch and the term array
-  char* ws_scratch = nullptr;
-  size_t ws_scratch_bytes = 0;
-  void* ws_terms = nullptr;
-  int64_t ws_capacity = 0;       // terms
-  int ws_backoff = 0;            // steps for which the split walk is not tried (the last one needed too much memory)
-  // one-pass walk (walk_tile): the counts in ws_scratch are those of the last walk over the context's own particles
-  int64_t wt_hist_n = -1, wt_hist_begin = 0;
-  unsigned long long wt_total = 0;  // terms of that walk
-  uint32_t* wt_hist = nullptr;      // [n] per particle id: its terms in that walk
-  std::vector<T> h_pos;
-  std::vector<uint32_t> h_weight;  // current row order
-  std::vector<uint32_t> h_tmp;
-};
-
 }  // namespace
-
-// Two consecutive direct steps (A -> B -> A position buffers) captured once as a hipGraph and replayed: a small-N step
-// is ~15 launches (hazard scan, near/far split, gated kernels), i.e. launch-bound (N = 1024: 78 us per eager step
-// against 13 us of kernels).  The graph is rebuilt when anything it baked in changes.
-struct DirectGraph {
-  hipGraphExec_t exec = nullptr;
-  int64_t n = -1;
-  const void *pos_a = nullptr, *pos_b = nullptr, *vel = nullptr, *mass = nullptr, *ws = nullptr;
-  float delta = 0.f, clamp = 0.f, uniform = 0.f;
-  int arith = -1;
-  std::string env;  // the NBODY_DIRECT_* switches read at capture time
-  void reset() {
-    if (exec) (void)hipGraphExecDestroy(exec);
-    exec = nullptr;
-    n = -1;
-  }
-};
-static inline std::string direct_env_signature() {
-  std::string sig;
-  for (const char* k : {"NBODY_DIRECT_ASM", "NBODY_DIRECT_NEARFAR", "NBODY_DIRECT_TPT", "NBODY_DIRECT_GSPLIT", "NBODY_DIRECT_NO_UNIFORM"}) {
-    const char* v = getenv(k);
-    sig += v ? v : "-";
-    sig += ';';
-  }
-  return sig;
-}
-
-struct nbody_ctx {
-  DirectGraph direct_graph;
-  int device = 0;
-  hipStream_t stream = nullptr;
-  std::string err;
-  nbody_params params{};
-  nbody_counting counting{};
-  nbody_timer* timer = nullptr;
-  bool has_f32 = false, has_f64 = false;
-  State<float> sf;
-  State<double> sd;
-  void* workspace = nullptr;
-  int bvh_stops = 0;  // exact-sum restarts of the last device BVH build (diagnostic)
-  bool last_build_device = false;
-  size_t workspace_bytes = 0;
-  unsigned long long* stats_dev = nullptr;
-  uint32_t* frame_work = nullptr;  // render: per-pixel counters
-  hipStream_t copy_stream = nullptr;  // snapshot transfers, concurrent with the steps on `stream`
-  hipEvent_t snap_event = nullptr;
-  bool snap_pending = false;
-  uint64_t steps_done = 0, snap_step = 0;
-  // snapshot staging: device copy of the rows, pinned host image
-  void *snap_pos = nullptr, *snap_vel = nullptr, *snap_hpos = nullptr, *snap_hvel = nullptr;
-  uint32_t *snap_w = nullptr, *snap_ids = nullptr, *snap_hw = nullptr, *snap_hids = nullptr;
-  size_t snap_bytes2 = 0;  // bytes of one position array the staging holds
-  int64_t snap_n = 0;
-  bool snap_f64 = false;
-  // delta snapshots (delta_snapshot.hip): three key arrays in rotation (this / previous / the one before), the pieces
-  // of the stream on the device, the assembled stream in pinned memory
-  void* dl_keys[3] = {nullptr, nullptr, nullptr};
-  int dl_cur = 0;
-  uint8_t* dl_widths = nullptr;
-  uint32_t *dl_words = nullptr, *dl_offsets = nullptr;
-  void* dl_scan = nullptr;
-  size_t dl_scan_bytes = 0;
-  uint64_t *dl_payload = nullptr, *dl_total = nullptr, *dl_htotal = nullptr;
-  uint8_t* dl_host = nullptr;
-  int64_t dl_n = -1;
-  int dl_bits = 0;
-  bool dl_key_next = true, dl_pending = false;
-  size_t dl_stream_bytes = 0;
-  uint64_t dl_step = 0;
-  uint8_t* frame_rgba = nullptr;
-  uint32_t frame_px = 0;
-  unsigned long long last_stats[3] = {0, 0, 0};
-  bool want_stats = false;
-};
 
 struct nbody_host_tree {
   bool is_f64 = false;
@@ -303,23 +180,77 @@ size_t direct_ws_bytes(int64_t n_src, int64_t n_tgt) {
   return kFlagBytes + direct_partial_bytes(n_src, n_tgt) + nearfar_layout(n_src).total;
 }
 
-int direct_step_dev(nbody_ctx* c, hipStream_t stream, int64_t n_src, const void* pos_all, const void* mass_all,
-                    float uniform_mass, int64_t tgt_begin, int64_t n_tgt, void* vel, void* pos_out, void* acc_out,
-                    float delta, float clamp, int arith, void* ws, size_t ws_bytes, nbody_timer* timer) {
-  if (n_src < 0 || n_tgt < 0 || tgt_begin < 0 || tgt_begin + n_tgt > n_src || n_src > 0x7fffffffLL)
+// A direct step = one preparation over ALL positions (hazard scan, near/far split, the decision word) followed by one
+// or more runs, each over a block of targets.  `n_tgt_total` (all targets this device computes in the step) decides
+// whether the near/far split pays; `n_tgt_max` (the largest block of one run) sizes the partial-sum area, so that
+// preparation and runs agree on the workspace layout.
+struct DirectPlan {
+  int arith = 0;
+  bool uni = false;
+  bool nearfar = false;
+  int use_hazard = 0;
+  size_t partial_bytes = 0;
+};
+int direct_plan(nbody_ctx* c, int64_t n_src, float uniform_mass, int64_t n_tgt_total, int64_t n_tgt_max, float clamp, int arith,
+                const void* ws, size_t ws_bytes, DirectPlan* out) {
+  if (n_src < 0 || n_tgt_total < 0 || n_tgt_max < 0 || n_tgt_max > n_tgt_total || n_tgt_total > n_src || n_src > 0x7fffffffLL)
+    return fail(c, NBODY_ERR_INVALID, "direct_step: bad target/source counts");
+  if (arith < NBODY_ARITH_AUTO || arith > NBODY_ARITH_EXACT) return fail(c, NBODY_ERR_INVALID, "direct_step: bad arith");
+  if (!ws || ws_bytes < direct_ws_bytes(n_src, n_tgt_max)) return fail(c, NBODY_ERR_INVALID, "direct_step: workspace too small");
+  // FAST's zero-distance bias needs clamp >= 2^-19 (DESIGN.md); smaller clamps always take EXACT.
+  if (arith != NBODY_ARITH_EXACT && !(clamp >= 1.9073486328125e-06f)) arith = NBODY_ARITH_EXACT;
+  DirectPlan p;
+  p.arith = arith;
+  p.uni = uniform_mass > 0.f && env_int("NBODY_DIRECT_NO_UNIFORM", 0) == 0;
+  p.nearfar = choose_direct_config(n_src, n_tgt_total, p.uni).nearfar;
+  p.use_hazard = arith == NBODY_ARITH_AUTO;
+  p.partial_bytes = direct_partial_bytes(n_src, n_tgt_max);
+  *out = p;
+  return NBODY_OK;
+}
+
+// Decides, on the stream, which kernels of this step do the work (flags[kFlagState]).
+int direct_prep(nbody_ctx* c, hipStream_t stream, int64_t n_src, const void* pos_all, const void* mass_all, float uniform_mass,
+                int64_t n_tgt_total, int64_t n_tgt_max, float clamp, int arith, void* ws, size_t ws_bytes) {
+  DirectPlan p;
+  int rc = direct_plan(c, n_src, uniform_mass, n_tgt_total, n_tgt_max, clamp, arith, ws, ws_bytes, &p);
+  if (rc) return rc;
+  if (n_tgt_total == 0 || p.arith == NBODY_ARITH_EXACT) return NBODY_OK;
+  if (!pos_all || !mass_all) return fail(c, NBODY_ERR_INVALID, "direct_step: null pos_all/mass_all");
+  int* flags = (int*)ws;
+  HIPCHK(c, hipMemsetAsync(flags, 0, kFlagBytes, stream));
+  if (p.use_hazard) HIPCHK(c, launch_hazard_scan(stream, (const float*)pos_all, 2 * n_src, flags));
+  if (p.nearfar) {
+    char* nf_scratch = (char*)ws + kFlagBytes + p.partial_bytes;
+    NearFarLayout L = nearfar_layout(n_src);
+    const float2* pos_far = nullptr;
+    const uint32_t* near_list = nullptr;
+    HIPCHK(c, launch_nearfar(stream, (const float2*)pos_all, (int)n_src, clamp, p.use_hazard, flags, nf_scratch, L, &pos_far, &near_list));
+  } else {
+    HIPCHK(c, launch_decide_simple(stream, p.use_hazard, flags));
+  }
+  return NBODY_OK;
+}
+
+// Force + integration for the targets [tgt_begin, tgt_begin + n_tgt) under the decision direct_prep left in `ws`.
+int direct_run(nbody_ctx* c, hipStream_t stream, int64_t n_src, const void* pos_all, const void* mass_all, float uniform_mass,
+               int64_t tgt_begin, int64_t n_tgt, void* vel, void* pos_out, void* acc_out, float delta, float clamp, int arith,
+               int64_t n_tgt_total, int64_t n_tgt_max, void* ws, size_t ws_bytes, nbody_timer* timer) {
+  if (n_tgt < 0 || tgt_begin < 0 || tgt_begin + n_tgt > n_src || n_tgt > n_tgt_max)
     return fail(c, NBODY_ERR_INVALID, "direct_step: bad target/source range");
+  DirectPlan p;
+  int rc = direct_plan(c, n_src, uniform_mass, n_tgt_total, n_tgt_max, clamp, arith, ws, ws_bytes, &p);
+  if (rc) return rc;
   if (n_tgt == 0) return NBODY_OK;
   if (!pos_all || !mass_all) return fail(c, NBODY_ERR_INVALID, "direct_step: null pos_all/mass_all");
   if ((vel == nullptr) != (pos_out == nullptr))
     return fail(c, NBODY_ERR_INVALID, "direct_step: vel and pos_out must both be given or both be NULL");
   if (!vel && !acc_out) return fail(c, NBODY_ERR_INVALID, "direct_step: nothing to compute");
-  if (arith < NBODY_ARITH_AUTO || arith > NBODY_ARITH_EXACT) return fail(c, NBODY_ERR_INVALID, "direct_step: bad arith");
-  if (!ws || ws_bytes < direct_ws_bytes(n_src, n_tgt)) return fail(c, NBODY_ERR_INVALID, "direct_step: workspace too small");
-  // FAST's zero-distance bias needs clamp >= 2^-19 (DESIGN.md); smaller clamps always take EXACT.
-  if (arith != NBODY_ARITH_EXACT && !(clamp >= 1.9073486328125e-06f)) arith = NBODY_ARITH_EXACT;
 
-  const bool uni = uniform_mass > 0.f && env_int("NBODY_DIRECT_NO_UNIFORM", 0) == 0;
-  DirectConfig cfg = choose_direct_config(n_src, n_tgt, uni);
+  DirectConfig cfg = choose_direct_config(n_src, n_tgt, p.uni);
+  cfg.nearfar = p.nearfar;
+  if ((size_t)cfg.gsplit * (size_t)n_tgt * sizeof(float2) > p.partial_bytes)
+    return fail(c, NBODY_ERR_INVALID, "direct_step: the partial sums of this block do not fit the workspace's layout");
   int* flags = (int*)ws;
   DirectArgs a{};
   a.pos_all = (const float2*)pos_all;
@@ -334,27 +265,22 @@ int direct_step_dev(nbody_ctx* c, hipStream_t stream, int64_t n_src, const void*
   a.partial = (float2*)((char*)ws + kFlagBytes);
   a.delta = delta;
   a.clamp = clamp;
-  a.uniform_mass = uni ? uniform_mass : 0.f;
+  a.uniform_mass = p.uni ? uniform_mass : 0.f;
   a.flags = flags;
   a.run_state = -1;
 
-  if (arith == NBODY_ARITH_EXACT) {
+  if (p.arith == NBODY_ARITH_EXACT) {
     TimerScope ts(timer, stream);
     HIPCHK(c, launch_direct_exact(stream, a));
     return NBODY_OK;
   }
-  // ---- decide, on the stream, which kernels of this step do the work (flags[kFlagState])
-  const int use_hazard = arith == NBODY_ARITH_AUTO;
-  HIPCHK(c, hipMemsetAsync(flags, 0, kFlagBytes, stream));
-  if (use_hazard) HIPCHK(c, launch_hazard_scan(stream, (const float*)pos_all, 2 * n_src, flags));
-  char* nf_scratch = (char*)ws + kFlagBytes + direct_partial_bytes(n_src, n_tgt);
   const float2* pos_far = nullptr;
   const uint32_t* near_list = nullptr;
   if (cfg.nearfar) {
+    char* nf_scratch = (char*)ws + kFlagBytes + p.partial_bytes;
     NearFarLayout L = nearfar_layout(n_src);
-    HIPCHK(c, launch_nearfar(stream, a.pos_all, a.n_src, clamp, use_hazard, flags, nf_scratch, L, &pos_far, &near_list));
-  } else {
-    HIPCHK(c, launch_decide_simple(stream, use_hazard, flags));
+    pos_far = (const float2*)(nf_scratch + L.pos_far);
+    near_list = (const uint32_t*)(nf_scratch + L.near_list);
   }
   {
     TimerScope ts(timer, stream);
@@ -382,12 +308,28 @@ int direct_step_dev(nbody_ctx* c, hipStream_t stream, int64_t n_src, const void*
     a1.run_state = 1;
     HIPCHK(c, launch_direct_finish(stream, a1, cfg.gsplit, false));
   }
-  if (use_hazard) {  // state 2
+  if (p.use_hazard) {  // state 2
     DirectArgs a2 = a;
     a2.run_state = 2;
     HIPCHK(c, launch_direct_exact(stream, a2));
   }
   return NBODY_OK;
+}
+
+int direct_step_dev(nbody_ctx* c, hipStream_t stream, int64_t n_src, const void* pos_all, const void* mass_all,
+                    float uniform_mass, int64_t tgt_begin, int64_t n_tgt, void* vel, void* pos_out, void* acc_out,
+                    float delta, float clamp, int arith, void* ws, size_t ws_bytes, nbody_timer* timer) {
+  if (n_src < 0 || n_tgt < 0 || tgt_begin < 0 || tgt_begin + n_tgt > n_src || n_src > 0x7fffffffLL)
+    return fail(c, NBODY_ERR_INVALID, "direct_step: bad target/source range");
+  if (n_tgt == 0) return NBODY_OK;
+  if (!pos_all || !mass_all) return fail(c, NBODY_ERR_INVALID, "direct_step: null pos_all/mass_all");
+  if ((vel == nullptr) != (pos_out == nullptr))
+    return fail(c, NBODY_ERR_INVALID, "direct_step: vel and pos_out must both be given or both be NULL");
+  if (!vel && !acc_out) return fail(c, NBODY_ERR_INVALID, "direct_step: nothing to compute");
+  int rc = direct_prep(c, stream, n_src, pos_all, mass_all, uniform_mass, n_tgt, n_tgt, clamp, arith, ws, ws_bytes);
+  if (rc) return rc;
+  return direct_run(c, stream, n_src, pos_all, mass_all, uniform_mass, tgt_begin, n_tgt, vel, pos_out, acc_out, delta, clamp, arith,
+                    n_tgt, n_tgt, ws, ws_bytes, timer);
 }
 
 int ensure_workspace(nbody_ctx* c, size_t bytes) {
@@ -412,7 +354,8 @@ template <class T> int upload(nbody_ctx* c, int64_t n, const T* pos, const T* ve
   State<T>& s = state_of<T>(c);
   using T2 = typename State<T>::T2;
   s.n = n;
-  const size_t nn = (size_t)(n > 0 ? n : 1) + 16;  // tree_walk_wave reads leaf particles 8 at a time: padded
+  // tree_walk_wave reads leaf particles 8 at a time: padded; a multi-device context asks for whole blocks (row_capacity)
+  const size_t nn = (size_t)std::max<int64_t>(n > 0 ? n : 1, c->row_capacity) + 16;
   for (auto& st : s.set) {
     HIPCHK(c, hipMalloc((void**)&st.pos, nn * sizeof(T2)));
     HIPCHK(c, hipMalloc((void**)&st.vel, nn * sizeof(T2)));
@@ -1097,7 +1040,9 @@ NB_API int nbody_default_params(nbody_params* p) {
   return NBODY_OK;
 }
 
-NB_API int nbody_create(nbody_ctx** out, int device_id) {
+NB_API int nbody_create(nbody_ctx** out, int device_id) { return nbody::ctx_create_single(out, device_id); }
+
+int nbody::ctx_create_single(nbody_ctx** out, int device_id) {
   if (!out) return fail(nullptr, NBODY_ERR_INVALID, "nbody_create: out is NULL");
   *out = nullptr;
   int count = 0;
@@ -1135,6 +1080,11 @@ static void free_snapshot(nbody_ctx* c);
 static void free_delta(nbody_ctx* c);
 NB_API void nbody_destroy(nbody_ctx* c) {
   if (!c) return;
+  if (c->multi) { nbody::multi_destroy(c); return; }
+  nbody::ctx_destroy_single(c);
+}
+void nbody::ctx_destroy_single(nbody_ctx* c) {
+  if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   c->direct_graph.reset();
@@ -1161,6 +1111,7 @@ NB_API int nbody_set_params(nbody_ctx* c, const nbody_params* p) {
   if (p->order != NBODY_ORDER_AS_WRITTEN && p->order != NBODY_ORDER_CONSISTENT) return fail(c, NBODY_ERR_INVALID, "set_params: bad order");
   if (p->arith < NBODY_ARITH_AUTO || p->arith > NBODY_ARITH_EXACT) return fail(c, NBODY_ERR_INVALID, "set_params: bad arith");
   c->params = *p;
+  if (c->multi) return nbody::multi_set_params(c);
   return NBODY_OK;
 }
 NB_API int nbody_get_params(const nbody_ctx* c, nbody_params* out) {
@@ -1169,16 +1120,36 @@ NB_API int nbody_get_params(const nbody_ctx* c, nbody_params* out) {
   return NBODY_OK;
 }
 
+// A handle made by nbody_create_multi fronts several devices.  Calls that only read or that act on "the current rows"
+// are served by the first device once the replicas agree (multi_primary brings them up to date); `mutates` marks the
+// calls after which the other replicas must be refreshed from it (multi_replicate).
+#define NB_VIA_PRIMARY(c, mutates, expr)                    \
+  do {                                                      \
+    if ((c) && (c)->multi) {                                \
+      nbody_ctx* front__ = (c);                             \
+      nbody_ctx* p = nullptr;                               \
+      int rc__ = nbody::multi_primary(front__, &p);         \
+      if (rc__) return rc__;                                \
+      rc__ = (expr);                                        \
+      if (rc__) { front__->err = p->err; return rc__; }     \
+      return (mutates) ? nbody::multi_replicate(front__) : NBODY_OK; \
+    }                                                       \
+  } while (0)
+
 NB_API int nbody_upload_f32(nbody_ctx* c, int64_t n, const float* pos, const float* vel, const uint32_t* w) {
+  if (c && c->multi) return nbody::multi_upload(c, false, n, pos, vel, w);
   return upload<float>(c, n, pos, vel, w);
 }
 NB_API int nbody_upload_f64(nbody_ctx* c, int64_t n, const double* pos, const double* vel, const uint32_t* w) {
+  if (c && c->multi) return nbody::multi_upload(c, true, n, pos, vel, w);
   return upload<double>(c, n, pos, vel, w);
 }
 NB_API int nbody_download_f32(nbody_ctx* c, float* pos, float* vel, uint32_t* w, uint32_t* ids) {
+  NB_VIA_PRIMARY(c, false, download<float>(p, pos, vel, w, ids));
   return download<float>(c, pos, vel, w, ids);
 }
 NB_API int nbody_download_f64(nbody_ctx* c, double* pos, double* vel, uint32_t* w, uint32_t* ids) {
+  NB_VIA_PRIMARY(c, false, download<double>(p, pos, vel, w, ids));
   return download<double>(c, pos, vel, w, ids);
 }
 // ---- snapshot hand-off (main.rs:136-139) --------------------------------------------------------------------------
@@ -1234,14 +1205,24 @@ template <class T> int snapshot_begin(nbody_ctx* c, State<T>& s) {
 }
 NB_API int nbody_snapshot_begin(nbody_ctx* c) {
   if (!c) return NBODY_ERR_INVALID;
+  NB_VIA_PRIMARY(c, false, nbody_snapshot_begin(p));
   if (!c->has_f32 && !c->has_f64) return fail(c, NBODY_ERR_INVALID, "snapshot_begin: no particles uploaded");
   if (c->snap_pending) return fail(c, NBODY_ERR_INVALID, "snapshot_begin: a snapshot is still pending (take it with nbody_snapshot_end)");
   HIPCHK(c, hipSetDevice(c->device));
   return c->has_f32 ? snapshot_begin<float>(c, c->sf) : snapshot_begin<double>(c, c->sd);
 }
-NB_API int nbody_snapshot_pending(const nbody_ctx* c) { return c && c->snap_pending ? 1 : 0; }
+NB_API int nbody_snapshot_pending(const nbody_ctx* c) {
+  if (c && c->multi) return nbody_snapshot_pending(nbody::multi_peek(c));
+  return c && c->snap_pending ? 1 : 0;
+}
 static int snapshot_end(nbody_ctx* c, bool f64, void* pos, void* vel, uint32_t* w, uint32_t* ids, uint64_t* step) {
   if (!c) return NBODY_ERR_INVALID;
+  if (c->multi) {  // the pending snapshot lives on the first device; taking it does not need the replicas to agree
+    nbody_ctx* p = nbody::multi_peek(c);
+    int rc = snapshot_end(p, f64, pos, vel, w, ids, step);
+    if (rc) c->err = p->err;
+    return rc;
+  }
   if (!c->snap_pending) return fail(c, NBODY_ERR_INVALID, "snapshot_end: no snapshot pending");
   if (c->snap_f64 != f64) return fail(c, NBODY_ERR_INVALID, "snapshot_end: the pending snapshot has the other precision");
   HIPCHK(c, hipSetDevice(c->device));
@@ -1335,14 +1316,24 @@ template <class T> int delta_begin(nbody_ctx* c, State<T>& s) {
 }
 NB_API int nbody_delta_begin(nbody_ctx* c) {
   if (!c) return NBODY_ERR_INVALID;
+  NB_VIA_PRIMARY(c, false, nbody_delta_begin(p));
   if (!c->has_f32 && !c->has_f64) return fail(c, NBODY_ERR_INVALID, "delta_begin: no particles uploaded");
   if (c->dl_pending) return fail(c, NBODY_ERR_INVALID, "delta_begin: a stream is still pending (take it with nbody_delta_end)");
   HIPCHK(c, hipSetDevice(c->device));
   return c->has_f32 ? delta_begin<float>(c, c->sf) : delta_begin<double>(c, c->sd);
 }
-NB_API int nbody_delta_pending(const nbody_ctx* c) { return c && c->dl_pending ? 1 : 0; }
+NB_API int nbody_delta_pending(const nbody_ctx* c) {
+  if (c && c->multi) return nbody_delta_pending(nbody::multi_peek(c));
+  return c && c->dl_pending ? 1 : 0;
+}
 NB_API int nbody_delta_end(nbody_ctx* c, uint8_t* out, size_t cap, size_t* bytes_out, uint64_t* step_out) {
   if (!c) return NBODY_ERR_INVALID;
+  if (c->multi) {
+    nbody_ctx* p = nbody::multi_peek(c);
+    int rc = nbody_delta_end(p, out, cap, bytes_out, step_out);
+    if (rc) c->err = p->err;
+    return rc;
+  }
   if (!c->dl_pending) return fail(c, NBODY_ERR_INVALID, "delta_end: no stream pending");
   if (bytes_out) *bytes_out = c->dl_stream_bytes;
   if (step_out) *step_out = c->dl_step;
@@ -1355,6 +1346,12 @@ NB_API int nbody_delta_end(nbody_ctx* c, uint8_t* out, size_t cap, size_t* bytes
 }
 NB_API int nbody_delta_reset(nbody_ctx* c) {
   if (!c) return NBODY_ERR_INVALID;
+  if (c->multi) {
+    nbody_ctx* p = nbody::multi_peek(c);
+    int rc = nbody_delta_reset(p);
+    if (rc) c->err = p->err;
+    return rc;
+  }
   if (c->dl_pending) return fail(c, NBODY_ERR_INVALID, "delta_reset: a stream is still pending");
   c->dl_key_next = true;
   return NBODY_OK;
@@ -1400,6 +1397,7 @@ template <class T> int render_rows(nbody_ctx* c, State<T>& s, uint32_t height, u
 }
 NB_API int nbody_render_rgba(nbody_ctx* c, uint32_t height, uint32_t render_px, uint8_t* rgba_out) {
   if (!c) return NBODY_ERR_INVALID;
+  NB_VIA_PRIMARY(c, false, nbody_render_rgba(p, height, render_px, rgba_out));
   if (!rgba_out) return fail(c, NBODY_ERR_INVALID, "render: null output");
   if (!c->has_f32 && !c->has_f64) return fail(c, NBODY_ERR_INVALID, "render: no particles uploaded");
   // main.rs:51-52 divide by HEIGHT / RENDER_HEIGHT: a cell of 0 world units or a last cell past the frame is an
@@ -1432,11 +1430,13 @@ NB_API int nbody_render_rgba_dev(void* stream, int64_t n, int is_f64, const void
 
 NB_API int64_t nbody_num_particles(const nbody_ctx* c) {
   if (!c) return NBODY_ERR_INVALID;
+  if (c->multi) return nbody_num_particles(nbody::multi_peek(c));
   return c->has_f32 ? c->sf.n : (c->has_f64 ? c->sd.n : 0);
 }
 
 NB_API int nbody_update_direct_f32(nbody_ctx* c, float delta, int n_steps, nbody_counting* counter) {
   if (!c) return NBODY_ERR_INVALID;
+  if (c->multi) return nbody::multi_update_direct(c, delta, n_steps, counter);
   if (!c->has_f32) return fail(c, NBODY_ERR_INVALID, "update_direct_f32: no f32 particles uploaded");
   if (n_steps < 0) return fail(c, NBODY_ERR_INVALID, "update_direct_f32: n_steps < 0");
   HIPCHK(c, hipSetDevice(c->device));
@@ -1501,6 +1501,7 @@ NB_API int nbody_update_direct_f32(nbody_ctx* c, float delta, int n_steps, nbody
 
 NB_API int nbody_accel_direct_f32(nbody_ctx* c, float* acc_xy) {
   if (!c) return NBODY_ERR_INVALID;
+  NB_VIA_PRIMARY(c, false, nbody_accel_direct_f32(p, acc_xy));
   if (!c->has_f32) return fail(c, NBODY_ERR_INVALID, "accel_direct_f32: no f32 particles uploaded");
   if (!acc_xy) return fail(c, NBODY_ERR_INVALID, "accel_direct_f32: acc_xy is NULL");
   HIPCHK(c, hipSetDevice(c->device));
@@ -1517,36 +1518,49 @@ NB_API int nbody_accel_direct_f32(nbody_ctx* c, float* acc_xy) {
 }
 
 NB_API int nbody_update_tree_f32(nbody_ctx* c, int kind, float delta, int n_steps, nbody_counting* counter) {
+  if (c && c->multi) return nbody::multi_update_tree(c, false, kind, (double)delta, n_steps, counter);
   return update_tree<float>(c, kind, delta, n_steps, counter);
 }
 NB_API int nbody_update_tree_f64(nbody_ctx* c, int kind, double delta, int n_steps, nbody_counting* counter) {
+  if (c && c->multi) return nbody::multi_update_tree(c, true, kind, delta, n_steps, counter);
   return update_tree<double>(c, kind, delta, n_steps, counter);
 }
+static int not_on_multi(nbody_ctx* c, const char* what) {
+  return fail(c, NBODY_ERR_INVALID, std::string(what) + ": a context made by nbody_create_multi shards its steps itself");
+}
 NB_API int nbody_update_tree_shard_f32(nbody_ctx* c, int kind, float delta, int64_t begin, int64_t count, nbody_counting* counter) {
+  if (c && c->multi) return not_on_multi(c, "update_tree_shard");
   return update_tree_shard<float>(c, kind, delta, begin, count, counter);
 }
 NB_API int nbody_update_tree_shard_f64(nbody_ctx* c, int kind, double delta, int64_t begin, int64_t count, nbody_counting* counter) {
+  if (c && c->multi) return not_on_multi(c, "update_tree_shard");
   return update_tree_shard<double>(c, kind, delta, begin, count, counter);
 }
 NB_API int nbody_export_slice_dev(nbody_ctx* c, int64_t begin, int64_t count, void* rows_u32, void* pos_xy, void* vel_xy) {
   if (!c) return NBODY_ERR_INVALID;
+  if (c->multi) return not_on_multi(c, "export_slice");
   return c->has_f64 ? export_slice<double>(c, begin, count, rows_u32, pos_xy, vel_xy)
                     : export_slice<float>(c, begin, count, rows_u32, pos_xy, vel_xy);
 }
 NB_API int nbody_import_rows_dev(nbody_ctx* c, int64_t n_rows, const void* rows_u32, const void* pos_xy, const void* vel_xy) {
   if (!c) return NBODY_ERR_INVALID;
+  if (c->multi) return not_on_multi(c, "import_rows");
   return c->has_f64 ? import_rows_api<double>(c, n_rows, rows_u32, pos_xy, vel_xy)
                     : import_rows_api<float>(c, n_rows, rows_u32, pos_xy, vel_xy);
 }
+// (a BVH build permutes the rows of the device that ran it: the other replicas are refreshed afterwards)
 NB_API int nbody_accel_tree_f32(nbody_ctx* c, int kind, int64_t n_targets, const float* target_xy, float* acc_xy) {
+  NB_VIA_PRIMARY(c, true, accel_tree<float>(p, kind, n_targets, target_xy, acc_xy));
   return accel_tree<float>(c, kind, n_targets, target_xy, acc_xy);
 }
 NB_API int nbody_accel_tree_f64(nbody_ctx* c, int kind, int64_t n_targets, const double* target_xy, double* acc_xy) {
+  NB_VIA_PRIMARY(c, true, accel_tree<double>(p, kind, n_targets, target_xy, acc_xy));
   return accel_tree<double>(c, kind, n_targets, target_xy, acc_xy);
 }
 
 NB_API int nbody_tree_info(const nbody_ctx* c, nbody_tree_view* out) {
   if (!c || !out) return NBODY_ERR_INVALID;
+  if (c->multi) return nbody_tree_info(nbody::multi_peek(c), out);
   nbody_ctx* mc = const_cast<nbody_ctx*>(c);
   if (c->has_f32 && c->sf.tree_valid) {
     out->n_nodes = c->sf.n_nodes; out->kind = c->sf.tree_kind; out->max_depth = c->sf.tree_max_depth;
@@ -1560,10 +1574,12 @@ NB_API int nbody_tree_info(const nbody_ctx* c, nbody_tree_view* out) {
 }
 NB_API int nbody_tree_export_f32(const nbody_ctx* c, float* geom, uint32_t* mass, int32_t* is_leaf, int64_t* first,
                                  int64_t* count, int64_t* skip, uint32_t* order) {
+  if (c && c->multi) c = nbody::multi_peek(c);
   return tree_export<float>(c, geom, mass, is_leaf, first, count, skip, order);
 }
 NB_API int nbody_tree_export_f64(const nbody_ctx* c, double* geom, uint32_t* mass, int32_t* is_leaf, int64_t* first,
                                  int64_t* count, int64_t* skip, uint32_t* order) {
+  if (c && c->multi) c = nbody::multi_peek(c);
   return tree_export<double>(c, geom, mass, is_leaf, first, count, skip, order);
 }
 template <class T>
@@ -1616,6 +1632,7 @@ NB_API int nbody_host_tree_export_f64(const nbody_host_tree* t, double* geom, ui
 
 NB_API int nbody_tree_walk_stats(nbody_ctx* c, int enable, uint64_t* node_visits, uint64_t* accepted, uint64_t* leaf_pairs) {
   if (!c) return NBODY_ERR_INVALID;
+  if (c->multi) return not_on_multi(c, "tree_walk_stats (each device walks a slice)");
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (node_visits) *node_visits = c->last_stats[0];
   if (accepted) *accepted = c->last_stats[1];
@@ -1667,8 +1684,14 @@ NB_API int nbody_selftest_exact_sum_chunked(const float* x, int64_t n, int chunk
   *out_sum = xsum::emulate_fold_chunked2(x, n, chunk, chunk >= 8 ? 8 : 1, out_runs_used);
   return NBODY_OK;
 }
-NB_API int nbody_bvh_build_restarts(const nbody_ctx* ctx) { return ctx ? ctx->bvh_stops : 0; }
-NB_API int nbody_last_build_on_device(const nbody_ctx* ctx) { return ctx && ctx->last_build_device ? 1 : 0; }
+NB_API int nbody_bvh_build_restarts(const nbody_ctx* ctx) {
+  if (ctx && ctx->multi) ctx = nbody::multi_peek(ctx);
+  return ctx ? ctx->bvh_stops : 0;
+}
+NB_API int nbody_last_build_on_device(const nbody_ctx* ctx) {
+  if (ctx && ctx->multi) ctx = nbody::multi_peek(ctx);
+  return ctx && ctx->last_build_device ? 1 : 0;
+}
 
 NB_API int nbody_timer_create(nbody_timer** out) {
   if (!out) return NBODY_ERR_INVALID;
@@ -1687,6 +1710,55 @@ NB_API int nbody_timer_read(nbody_timer* t, int reset, double* avg_ms, int64_t* 
 }
 NB_API int nbody_set_timer(nbody_ctx* c, nbody_timer* t) {
   if (!c) return NBODY_ERR_INVALID;
+  if (c->multi) nbody::multi_peek(c)->timer = t;  // the first device's kernels are the ones timed
   c->timer = t;
   return NBODY_OK;
 }
+
+NB_API int nbody_direct_prep_dev(void* stream, int64_t n_sources, const void* pos_all, const void* mass_all, float uniform_mass,
+                                 int64_t n_targets_total, int64_t n_targets_max, float clamp, int arith, void* workspace,
+                                 size_t workspace_bytes) {
+  return direct_prep(nullptr, (hipStream_t)stream, n_sources, pos_all, mass_all, uniform_mass, n_targets_total, n_targets_max, clamp,
+                     arith, workspace, workspace_bytes);
+}
+NB_API int nbody_direct_run_dev(void* stream, int64_t n_sources, const void* pos_all, const void* mass_all, float uniform_mass,
+                                int64_t target_begin, int64_t n_targets, void* vel, void* pos_out, void* acc_out, float delta,
+                                float clamp, int arith, int64_t n_targets_total, int64_t n_targets_max, void* workspace,
+                                size_t workspace_bytes, nbody_timer* timer) {
+  return direct_run(nullptr, (hipStream_t)stream, n_sources, pos_all, mass_all, uniform_mass, target_begin, n_targets, vel, pos_out,
+                    acc_out, delta, clamp, arith, n_targets_total, n_targets_max, workspace, workspace_bytes, timer);
+}
+NB_API void* nbody_get_stream(const nbody_ctx* c) {
+  if (c && c->multi) c = nbody::multi_peek(c);
+  return c ? (void*)c->stream : nullptr;
+}
+
+// ---- what multi.hip needs of this translation unit (ctx.h)
+namespace nbody {
+int ctx_fail(nbody_ctx* c, int code, const std::string& msg) { return fail(c, code, msg); }
+int ctx_upload(nbody_ctx* c, bool f64, int64_t n, const void* pos, const void* vel, const uint32_t* w) {
+  return f64 ? upload<double>(c, n, (const double*)pos, (const double*)vel, w) : upload<float>(c, n, (const float*)pos, (const float*)vel, w);
+}
+int ctx_update_tree_shard(nbody_ctx* c, bool f64, int kind, double delta, int64_t begin, int64_t count, nbody_counting* counter) {
+  return f64 ? update_tree_shard<double>(c, kind, delta, begin, count, counter)
+             : update_tree_shard<float>(c, kind, (float)delta, begin, count, counter);
+}
+int ctx_export_slice(nbody_ctx* c, int64_t begin, int64_t count, void* rows, void* pos, void* vel) {
+  return c->has_f64 ? export_slice<double>(c, begin, count, rows, pos, vel) : export_slice<float>(c, begin, count, rows, pos, vel);
+}
+int ctx_import_rows(nbody_ctx* c, int64_t n_rows, const void* rows, const void* pos, const void* vel) {
+  return c->has_f64 ? import_rows_api<double>(c, n_rows, rows, pos, vel) : import_rows_api<float>(c, n_rows, rows, pos, vel);
+}
+size_t ctx_direct_ws_bytes(int64_t n_src, int64_t n_tgt) { return direct_ws_bytes(n_src, n_tgt); }
+int ctx_ensure_workspace(nbody_ctx* c, size_t bytes) { return ensure_workspace(c, bytes); }
+int ctx_direct_prep(nbody_ctx* c, hipStream_t stream, int64_t n_src, const void* pos_all, const void* mass_all, float uniform_mass,
+                    int64_t n_tgt_total, int64_t n_tgt_max, float clamp, int arith, void* ws, size_t ws_bytes) {
+  return direct_prep(c, stream, n_src, pos_all, mass_all, uniform_mass, n_tgt_total, n_tgt_max, clamp, arith, ws, ws_bytes);
+}
+int ctx_direct_run(nbody_ctx* c, hipStream_t stream, int64_t n_src, const void* pos_all, const void* mass_all, float uniform_mass,
+                   int64_t tgt_begin, int64_t n_tgt, void* vel, void* pos_out, void* acc_out, float delta, float clamp, int arith,
+                   int64_t n_tgt_total, int64_t n_tgt_max, void* ws, size_t ws_bytes, nbody_timer* timer) {
+  return direct_run(c, stream, n_src, pos_all, mass_all, uniform_mass, tgt_begin, n_tgt, vel, pos_out, acc_out, delta, clamp, arith,
+                    n_tgt_total, n_tgt_max, ws, ws_bytes, timer);
+}
+}  // namespace nbody

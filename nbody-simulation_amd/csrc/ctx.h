@@ -1,0 +1,176 @@
+// Internal: the context of libnbody_hip and the functions its translation units share (capi.hip: one device;
+// multi.hip: several devices behind the same handle).  Not part of the C ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "tree_build.hpp"
+
+namespace nbody {
+
+struct Multi;  // multi.hip: the devices of a context made by nbody_create_multi
+
+template <class T> struct State {
+  using T2 = typename Vec2T<T>::type;
+  struct Set {
+    T2* pos = nullptr;
+    T2* vel = nullptr;
+    uint32_t* weight = nullptr;
+    uint32_t* ids = nullptr;
+    T* mass = nullptr;
+  };
+  int64_t n = 0;
+  Set set[2];
+  int cur = 0;
+  T2* pos_next = nullptr;  // direct step output, swapped with set[cur].pos
+  float uniform_mass = 0.f;  // > 0 when every weight is the same value (checked on upload)
+  T2* acc = nullptr;
+  // tree
+  void* geom0 = nullptr;
+  void* geom1 = nullptr;
+  void* link = nullptr;
+  size_t node_cap = 0;
+  uint32_t* order_dev = nullptr;
+  TreeHost<T> tree;          // host image of the last build (filled lazily after a device build)
+  bool tree_valid = false;
+  bool tree_host_stale = false;  // the last build ran on the device and has not been downloaded
+  int n_nodes = 0, tree_kind = 0, tree_max_depth = 0;
+  int shard_kind = 0;            // tree kind of the last sharded step (decides how a slice maps to rows)
+  int* node_depth = nullptr;     // device build: depth of every node
+  uint32_t* node_mass = nullptr; // device build: u32 mass of every node
+  float2* node_size = nullptr;   // device BVH build: boundary.size of every node
+  size_t node_aux_cap = 0;
+  char* qb_scratch = nullptr;
+  size_t qb_scratch_bytes = 0;
+  char* bb_scratch = nullptr;    // device BVH build
+  size_t bb_scratch_bytes = 0;
+  bool h_weight_stale = false;   // a device BVH build permuted the rows without touching h_weight
+  int quad_depth_hint = 0;       // depth of the last device-built quad tree (how many levels the next build sorts by)
+  // split walk (walk_split.hip): counts/offsets scratch and the term array
+  char* ws_scratch = nullptr;
+  size_t ws_scratch_bytes = 0;
+  void* ws_terms = nullptr;
+  int64_t ws_capacity = 0;       // terms
+  int ws_backoff = 0;            // steps for which the split walk is not tried (the last one needed too much memory)
+  // one-pass walk (walk_tile): the counts in ws_scratch are those of the last walk over the context's own particles
+  int64_t wt_hist_n = -1, wt_hist_begin = 0;
+  unsigned long long wt_total = 0;  // terms of that walk
+  uint32_t* wt_hist = nullptr;      // [n] per particle id: its terms in that walk
+  std::vector<T> h_pos;
+  std::vector<uint32_t> h_weight;  // current row order
+  std::vector<uint32_t> h_tmp;
+};
+
+
+}  // namespace nbody
+
+// Two consecutive direct steps (A -> B -> A position buffers) captured once as a hipGraph and replayed: a small-N step
+// is ~15 launches (hazard scan, near/far split, gated kernels), i.e. launch-bound (N = 1024: 78 us per eager step
+// against 13 us of kernels).  The graph is rebuilt when anything it baked in changes.
+namespace nbody {
+struct DirectGraph {
+  hipGraphExec_t exec = nullptr;
+  int64_t n = -1;
+  const void *pos_a = nullptr, *pos_b = nullptr, *vel = nullptr, *mass = nullptr, *ws = nullptr;
+  float delta = 0.f, clamp = 0.f, uniform = 0.f;
+  int arith = -1;
+  std::string env;  // the NBODY_DIRECT_* switches read at capture time
+  void reset() {
+    if (exec) (void)hipGraphExecDestroy(exec);
+    exec = nullptr;
+    n = -1;
+  }
+};
+inline std::string direct_env_signature() {
+  std::string sig;
+  for (const char* k : {"NBODY_DIRECT_ASM", "NBODY_DIRECT_NEARFAR", "NBODY_DIRECT_TPT", "NBODY_DIRECT_GSPLIT", "NBODY_DIRECT_NO_UNIFORM"}) {
+    const char* v = getenv(k);
+    sig += v ? v : "-";
+    sig += ';';
+  }
+  return sig;
+}
+
+}  // namespace nbody
+
+struct nbody_ctx {
+  nbody::Multi* multi = nullptr;   // non-null: this handle fronts several devices (multi.hip) and owns no device state itself
+  int64_t row_capacity = 0;        // rows the particle arrays are allocated for (>= n; a multi context pads to its block layout)
+  nbody::DirectGraph direct_graph;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  nbody_params params{};
+  nbody_counting counting{};
+  nbody_timer* timer = nullptr;
+  bool has_f32 = false, has_f64 = false;
+  nbody::State<float> sf;
+  nbody::State<double> sd;
+  void* workspace = nullptr;
+  int bvh_stops = 0;  // exact-sum restarts of the last device BVH build (diagnostic)
+  bool last_build_device = false;
+  size_t workspace_bytes = 0;
+  unsigned long long* stats_dev = nullptr;
+  uint32_t* frame_work = nullptr;  // render: per-pixel counters
+  hipStream_t copy_stream = nullptr;  // snapshot transfers, concurrent with the steps on `stream`
+  hipEvent_t snap_event = nullptr;
+  bool snap_pending = false;
+  uint64_t steps_done = 0, snap_step = 0;
+  // snapshot staging: device copy of the rows, pinned host image
+  void *snap_pos = nullptr, *snap_vel = nullptr, *snap_hpos = nullptr, *snap_hvel = nullptr;
+  uint32_t *snap_w = nullptr, *snap_ids = nullptr, *snap_hw = nullptr, *snap_hids = nullptr;
+  size_t snap_bytes2 = 0;  // bytes of one position array the staging holds
+  int64_t snap_n = 0;
+  bool snap_f64 = false;
+  // delta snapshots (delta_snapshot.hip): three key arrays in rotation (this / previous / the one before), the pieces
+  // of the stream on the device, the assembled stream in pinned memory
+  void* dl_keys[3] = {nullptr, nullptr, nullptr};
+  int dl_cur = 0;
+  uint8_t* dl_widths = nullptr;
+  uint32_t *dl_words = nullptr, *dl_offsets = nullptr;
+  void* dl_scan = nullptr;
+  size_t dl_scan_bytes = 0;
+  uint64_t *dl_payload = nullptr, *dl_total = nullptr, *dl_htotal = nullptr;
+  uint8_t* dl_host = nullptr;
+  int64_t dl_n = -1;
+  int dl_bits = 0;
+  bool dl_key_next = true, dl_pending = false;
+  size_t dl_stream_bytes = 0;
+  uint64_t dl_step = 0;
+  uint8_t* frame_rgba = nullptr;
+  uint32_t frame_px = 0;
+  unsigned long long last_stats[3] = {0, 0, 0};
+  bool want_stats = false;
+};
+
+
+namespace nbody {
+// ---- capi.hip
+int ctx_fail(nbody_ctx* c, int code, const std::string& msg);  // c == NULL: the thread's create error
+int ctx_create_single(nbody_ctx** out, int device_id);
+void ctx_destroy_single(nbody_ctx* c);
+int ctx_upload(nbody_ctx* c, bool f64, int64_t n, const void* pos, const void* vel, const uint32_t* w);
+int ctx_update_tree_shard(nbody_ctx* c, bool f64, int kind, double delta, int64_t begin, int64_t count, nbody_counting* counter);
+int ctx_export_slice(nbody_ctx* c, int64_t begin, int64_t count, void* rows, void* pos, void* vel);
+int ctx_import_rows(nbody_ctx* c, int64_t n_rows, const void* rows, const void* pos, const void* vel);
+size_t ctx_direct_ws_bytes(int64_t n_src, int64_t n_tgt);
+int ctx_ensure_workspace(nbody_ctx* c, size_t bytes);
+int ctx_direct_prep(nbody_ctx* c, hipStream_t stream, int64_t n_src, const void* pos_all, const void* mass_all, float uniform_mass,
+                    int64_t n_tgt_total, int64_t n_tgt_max, float clamp, int arith, void* ws, size_t ws_bytes);
+int ctx_direct_run(nbody_ctx* c, hipStream_t stream, int64_t n_src, const void* pos_all, const void* mass_all, float uniform_mass,
+                   int64_t tgt_begin, int64_t n_tgt, void* vel, void* pos_out, void* acc_out, float delta, float clamp, int arith,
+                   int64_t n_tgt_total, int64_t n_tgt_max, void* ws, size_t ws_bytes, nbody_timer* timer);
+// ---- multi.hip (`front` is the handle nbody_create_multi returned)
+void multi_destroy(nbody_ctx* front);
+int multi_set_params(nbody_ctx* front);
+int multi_upload(nbody_ctx* front, bool f64, int64_t n, const void* pos, const void* vel, const uint32_t* w);
+nbody_ctx* multi_peek(const nbody_ctx* front);            // the first device's context, as it is
+int multi_primary(nbody_ctx* front, nbody_ctx** out);     // ... after bringing every replica up to date
+int multi_replicate(nbody_ctx* front);                    // the first device's rows to every other replica
+int multi_update_direct(nbody_ctx* front, float delta, int n_steps, nbody_counting* counter);
+int multi_update_tree(nbody_ctx* front, bool f64, int kind, double delta, int n_steps, nbody_counting* counter);
+}  // namespace nbody
