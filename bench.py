@@ -153,8 +153,8 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"direct O(N^2) f32, N={n} bodies, seeded 2-D Plummer sphere, masses 1, "
                                    f"dt={DT}, clamp={CLAMP} (BASELINE.json configs[2])",
-                       "n_bodies": n, "targets_per_gpu": n_tgt,
-                       "exchange": "none" if world == 1 else f"{args.backend} all-gather of float2 positions per step"
+                       "n_bodies": n, "targets_per_gpu": n_tgt, "chunks_per_step": stepper.chunks,
+                       "exchange": "none" if world == 1 else f"{args.backend} in-place all-gather of float2 positions per chunk"
                                    + (" (RCCL over xGMI)" if args.backend == "nccl" else " (rehearsal)"),
                        "arith": "AUTO (FAST kernel; EXACT on hazardous positions)"},
             "roofline": {"bound": "valu_f32", "bound_class": "compute", "kernel": "nbody::direct_fast", "achieved": achieved,

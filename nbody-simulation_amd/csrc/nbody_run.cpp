@@ -2,7 +2,9 @@
 // generator: the reference's own is unseeded) stepped through the C ABI, printing the reference's once-a-second
 // block (ups / step / Counting, main.rs:149-156).  The window and the channel of the reference are out of scope; the frame
 // its render thread paints (draw, main.rs:41-72) can be written out instead of shown.
-//   nbody_run [steps=100] [bvh|quad|direct] [seed] [frame_every=0] [frame_prefix=frame] [delta_every=0]
+//   nbody_run [--gpus G] [steps=100] [bvh|quad|direct] [seed] [frame_every=0] [frame_prefix=frame] [delta_every=0]
+// --gpus G: the same world on devices 0 .. G-1 of this node behind one handle (nbody_create_multi: the step's targets are
+// sharded over them, the exchange is an RCCL all-gather inside the library); prints ms/step at the end.
 // frame_every = k > 0: every k-th step <frame_prefix>_<step>.pam (1250 x 1250 RGBA, Netpbm PAM) is written.
 // delta_every = k > 0: every k-th step the positions are taken as a delta stream and the two lines of the commented
 // experiment of main.rs:124-133 are printed ("raw: <bytes>" / "comp: <bytes>"); the streams are applied to a decoder and
@@ -64,6 +66,13 @@ int main(int argc, char** argv) {
     std::printf("len: %zu\n", p.size());
     return 0;
   }
+  int gpus = 0;
+  if (argc > 2 && !std::strcmp(argv[1], "--gpus")) {
+    gpus = std::atoi(argv[2]);
+    if (gpus < 1) { std::fprintf(stderr, "nbody_run: --gpus needs a positive count\n"); return 2; }
+    argc -= 2;
+    argv += 2;
+  }
   int steps = argc > 1 ? std::atoi(argv[1]) : 100;
   Method method = Method::Bvh;
   if (argc > 2 && !std::strcmp(argv[2], "quad")) method = Method::Quad;
@@ -75,8 +84,11 @@ int main(int argc, char** argv) {
   std::vector<uint8_t> frame, stream;
   nbody_delta_decoder* dec = delta_every > 0 ? nbody_delta_decoder_create() : nullptr;
   try {
-    World world(scene(seed), method);
+    std::vector<int> devices;
+    for (int d = 0; d < gpus; ++d) devices.push_back(d);
+    World world = gpus > 0 ? World(scene(seed), method, devices) : World(scene(seed), method);
     std::printf("len: %zu\n", world.particles.size());                // main.rs:343
+    const auto run_t0 = std::chrono::steady_clock::now();
     Counting counter{};
     auto t0 = std::chrono::steady_clock::now();
     long updates = 0, last = 0;
@@ -122,6 +134,8 @@ int main(int argc, char** argv) {
       std::printf("delta streams: receiver state differs from the device in %zu of %zu bodies\n", bad, ids.size());
       if (bad) throw std::runtime_error("delta round trip failed");
     }
+    const double run_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - run_t0).count();
+    std::printf("gpus: %d\nms/step: %.4f\n", gpus > 0 ? gpus : 1, steps > 0 ? 1e3 * run_s / steps : 0.0);
     const auto& ps = world.snapshot();
     double cx = 0, cy = 0;
     for (auto& q : ps) { cx += q.position.x; cy += q.position.y; }

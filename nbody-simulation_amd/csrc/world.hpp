@@ -30,6 +30,21 @@ class World {
   explicit World(std::vector<Particle> init, Method method = Method::Bvh, int device = 0, const nbody_params* params = nullptr)
       : particles(std::move(init)), method_(method) {
     check(nbody_create(&ctx_, device), "nbody_create");
+    upload(params);
+  }
+  // The same world on several GPUs of one node: `update` below does not change (main.rs:120 stays one call); the library
+  // shards each step's targets over `devices` and exchanges the results itself (nbody_create_multi).
+  World(std::vector<Particle> init, Method method, const std::vector<int>& devices, const nbody_params* params = nullptr)
+      : particles(std::move(init)), method_(method) {
+    check(nbody_create_multi(&ctx_, (int)devices.size(), devices.data()), "nbody_create_multi");
+    upload(params);
+  }
+  ~World() { nbody_destroy(ctx_); }
+  World(const World&) = delete;
+  World& operator=(const World&) = delete;
+
+ private:
+  void upload(const nbody_params* params) {
     if (params) check(nbody_set_params(ctx_, params), "nbody_set_params");
     std::vector<float> pos(2 * particles.size()), vel(2 * particles.size());
     std::vector<uint32_t> w(particles.size());
@@ -40,10 +55,8 @@ class World {
     }
     check(nbody_upload_f32(ctx_, (int64_t)particles.size(), pos.data(), vel.data(), w.data()), "nbody_upload_f32");
   }
-  ~World() { nbody_destroy(ctx_); }
-  World(const World&) = delete;
-  World& operator=(const World&) = delete;
 
+ public:
   // World::update, main.rs:388-425
   void update(float delta, Counting& counter) {
     int rc = method_ == Method::Direct ? nbody_update_direct_f32(ctx_, delta, 1, &counter)

@@ -25,12 +25,14 @@ _METHODS = {"bvh": _capi.TREE_BVH, "quad": _capi.TREE_QUAD, "direct": None}
 
 
 class World:
-    def __init__(self, position, velocity, weight=None, *, method="bvh", device=0, theta=THETA, clamp=0.001,
+    def __init__(self, position, velocity, weight=None, *, method="bvh", device=0, devices=None, theta=THETA, clamp=0.001,
                  leaf_size=64, order="as_written", arith="auto", quad_root=(0.0, 0.0, float(HEIGHT))):
+        """`devices=[0, 1, ...]`: the same world on several GPUs of one node behind one handle (nbody_create_multi);
+        `update` is still the one call of main.rs:120, the library shards the step and exchanges the results."""
         if method not in _METHODS:
             raise ValueError(f"method must be one of {sorted(_METHODS)}")
         self.method = method
-        self.ctx = _capi.Context(device)
+        self.ctx = _capi.MultiContext(list(devices)) if devices is not None else _capi.Context(device)
         self.ctx.set_params(theta=float(theta), clamp=float(clamp), leaf_size=int(leaf_size),
                             order={"as_written": _capi.ORDER_AS_WRITTEN, "consistent": _capi.ORDER_CONSISTENT}[order],
                             arith={"auto": _capi.ARITH_AUTO, "fast": _capi.ARITH_FAST, "exact": _capi.ARITH_EXACT}[arith],

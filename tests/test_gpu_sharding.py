@@ -37,7 +37,7 @@ def _worker(rank, world, port, n, steps, ret):
         st.step(0.1)
     torch.cuda.synchronize()
     p, v = st.local_state()
-    ret[rank] = (p, v, st.all_positions())
+    ret[rank] = (p, v, st.all_positions(), st.local_rows())
     dist.barrier()
     dist.destroy_process_group()
 
@@ -50,10 +50,9 @@ def test_two_ranks_on_one_gpu_equal_oracle(orc, nb):
     pos, vel, _ = nb.scenes.plummer(n, seed=71)
     w = (np.arange(n) % 3 + 1).astype(np.uint32)
     rp, rv, _ = orc.update_direct(pos, vel, w, delta=0.1, nsteps=steps, nthreads=8)
-    nl = n // world
     for r in range(world):
-        p, v, allp = ret[r]
-        assert np.array_equal(p, rp[r * nl:(r + 1) * nl]) and np.array_equal(v, rv[r * nl:(r + 1) * nl])
+        p, v, allp, rows = ret[r]
+        assert np.array_equal(p, rp[rows]) and np.array_equal(v, rv[rows])
         assert np.array_equal(allp, rp)
 
 
@@ -134,3 +133,59 @@ def test_sharded_tree_steps_equal_single_context(orc, nb, kind_name, dtype_name,
         p, v, _, ids = ret[r]
         assert np.array_equal(ids, rids)
         assert np.array_equal(p, rp) and np.array_equal(v, rv)
+
+
+# ------------------------------------------------------------------ RCCL between two GPUs (needs >= 2 visible devices)
+def _nccl_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    import nbody_simulation_amd as nb
+    from nbody_simulation_amd.sharding import ShardedDirectStepper, ShardedTreeStepper
+    C = nb._capi
+    n = 20011
+    pos, vel, _ = nb.scenes.plummer(n, seed=74)
+    w = (np.arange(n) % 3 + 1).astype(np.uint32)
+    st = ShardedDirectStepper(pos, vel, w, rank=rank, world=world, device=dev, arith=C.ARITH_EXACT, group=dist.group.WORLD, chunks=2)
+    for _ in range(3):
+        st.step(0.1)
+    torch.cuda.synchronize()
+    p, v = st.local_state()
+    out = {"direct": (p, v, st.all_positions(), st.local_rows())}
+    for name, kind, order in (("quad", C.TREE_QUAD, C.ORDER_CONSISTENT), ("bvh", C.TREE_BVH, C.ORDER_AS_WRITTEN)):
+        ts = ShardedTreeStepper(pos, vel, w, kind=kind, rank=rank, world=world, device_index=rank, group=dist.group.WORLD, theta=0.5,
+                                order=order)
+        for _ in range(3):
+            ts.step(0.1)
+        out[name] = ts.particles()
+        ts.close()
+    ret[rank] = out
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_two_gpus_rccl(orc, nb):
+    """The 'nccl' (= RCCL) branches of both steppers, one process per GPU: in-place chunked all-gather of the positions,
+    one packed all-gather of a tree step's slices on the context's stream.  Bit-identical to the oracle's trajectories."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU visible: RCCL between ranks runs on the driver's multi-GPU node")
+    world, n = 2, 20011
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_nccl_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    pos, vel, _ = nb.scenes.plummer(n, seed=74)
+    w = (np.arange(n) % 3 + 1).astype(np.uint32)
+    rp, rv, _ = orc.update_direct(pos, vel, w, delta=0.1, nsteps=3, nthreads=8)
+    qp, qv, _ = orc.update_quad(pos, vel, w, delta=0.1, theta=0.5, nsteps=3, nthreads=8)
+    bp, bv, _, bids, _ = orc.update_bvh(pos, vel, w, delta=0.1, theta=0.5, mode=orc.AS_WRITTEN, nsteps=3, nthreads=8)
+    for r in range(world):
+        p, v, allp, rows = ret[r]["direct"]
+        assert np.array_equal(p, rp[rows]) and np.array_equal(v, rv[rows]) and np.array_equal(allp, rp)
+        p, v, _, ids = ret[r]["quad"]
+        assert np.array_equal(ids, np.arange(n)) and np.array_equal(p, qp) and np.array_equal(v, qv)
+        p, v, _, ids = ret[r]["bvh"]
+        assert np.array_equal(ids, bids) and np.array_equal(p, bp) and np.array_equal(v, bv)

@@ -17,19 +17,22 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 class OracleBackend:
-    """CPU stand-in with the HipBackend.step signature (EXACT arithmetic semantics)."""
+    """CPU stand-in with HipBackend's prep/run signatures (EXACT arithmetic semantics)."""
 
-    def step(self, pos_all, mass_all, begin, n_local, vel_shard, out_shard, dt):
+    def prep(self, pos_all, mass_all, n):
+        pass
+
+    def run(self, pos_all, mass_all, n, begin, count, vel_block, out_block, dt):
         from oracle import oracle as orc
-        pos = pos_all.numpy()
-        w = mass_all.numpy().astype(np.uint32)
-        acc, _ = orc.direct_accel(pos, w, targets=np.arange(begin, begin + n_local))
+        pos = pos_all.numpy()[:n]
+        w = mass_all.numpy()[:n].astype(np.uint32)
+        acc, _ = orc.direct_accel(pos, w, targets=np.arange(begin, begin + count))
         acc = acc.astype(np.float32)
         d = np.float32(dt)
-        v = vel_shard.numpy() + acc * d
-        p = pos[begin:begin + n_local] + v * d
-        vel_shard.copy_(torch.from_numpy(v))
-        out_shard.copy_(torch.from_numpy(p))
+        v = vel_block.numpy() + acc * d
+        p = pos[begin:begin + count] + v * d
+        vel_block.copy_(torch.from_numpy(v))
+        out_block.copy_(torch.from_numpy(p))
 
 
 def _free_port():
@@ -40,7 +43,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n, steps, ret):
+def _worker(rank, world, port, n, steps, ret, chunks=0):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -50,40 +53,48 @@ def _worker(rank, world, port, n, steps, ret):
     pos, vel, w = nb.scenes.plummer(n, seed=61)
     w = (np.arange(n) % 3 + 1).astype(np.uint32)
     st = ShardedDirectStepper(pos, vel, w, rank=rank, world=world, device=torch.device("cpu"),
-                              backend=OracleBackend(), group=dist.group.WORLD)
+                              backend=OracleBackend(), group=dist.group.WORLD, chunks=chunks)
     for _ in range(steps):
         st.step(0.1)
     p, v = st.local_state()
-    ret[rank] = (p, v, st.all_positions())
+    ret[rank] = (p, v, st.all_positions(), st.local_rows())
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_sharded_steps_equal_single_rank(world, orc, nb):
-    n, steps = 512, 3
+@pytest.mark.parametrize("world,n,chunks", [(2, 512, 0), (4, 512, 0), (2, 700, 3), (4, 333, 2), (3, 50, 1)])
+def test_sharded_steps_equal_single_rank(world, n, chunks, orc, nb):
+    """Block layout {c*G + r}, ragged sizes (short and empty blocks) and several chunks per step included."""
+    steps = 3
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), n, steps, ret), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), n, steps, ret, chunks), nprocs=world, join=True)
     pos, vel, _ = nb.scenes.plummer(n, seed=61)
     w = (np.arange(n) % 3 + 1).astype(np.uint32)
     rp, rv, _ = orc.update_direct(pos, vel, w, delta=0.1, nsteps=steps)
-    nl = n // world
+    owned = np.zeros(n, int)
     for r in range(world):
-        p, v, allp = ret[r]
-        assert np.array_equal(p, rp[r * nl:(r + 1) * nl])
-        assert np.array_equal(v, rv[r * nl:(r + 1) * nl])
+        p, v, allp, rows = ret[r]
+        owned[rows] += 1
+        assert np.array_equal(p, rp[rows])
+        assert np.array_equal(v, rv[rows])
         assert np.array_equal(allp, rp)          # every rank holds the same gathered positions
+    assert np.all(owned == 1)                    # every body has exactly one owner
+
+
+def test_block_layout(nb):
+    from nbody_simulation_amd.sharding import block_layout
+    assert block_layout(1 << 20, 1) == (1, 1 << 20)
+    assert block_layout(1 << 20, 8) == (1, 131072)              # the headline config on 8 ranks: one chunk
+    assert block_layout(1 << 24, 8) == (8, 262144)              # config 5: eight chunks of 262 144 targets per rank
+    assert block_layout(1000, 4) == (1, 256)
+    assert block_layout(0, 2) == (1, 64)
+    for n, g, c in [(1, 1, 0), (63, 4, 4), (70001, 8, 2), (151405, 3, 0)]:
+        cc, b = block_layout(n, g, c)
+        assert b % 64 == 0 and g * cc * b >= n and (c == 0 or cc == c)
 
 
 def test_hip_backend_refuses_cpu(nb):
     from nbody_simulation_amd.sharding import HipBackend
     with pytest.raises(nb._capi.NBodyError):
-        HipBackend(torch.device("cpu"), 16, 16, 0.001, 0)
-
-
-def test_indivisible_n_is_rejected(nb):
-    from nbody_simulation_amd.sharding import ShardedDirectStepper
-    with pytest.raises(ValueError):
-        ShardedDirectStepper(np.zeros((10, 2)), np.zeros((10, 2)), np.ones(10), rank=0, world=4,
-                             device=torch.device("cpu"), backend=OracleBackend())
+        HipBackend(torch.device("cpu"), 16, 16, 16, 0.001, 0)
