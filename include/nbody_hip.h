@@ -203,7 +203,11 @@ int nbody_get_counting(const nbody_ctx* ctx, nbody_counting* out);
  *   pos_all   float2[n_sources]   all positions (gathered), read only
  *   mass_all  float [n_sources]   weights converted to f32 (u32 -> f32 as `weight as f32`, main.rs:360)
  *   uniform_mass                  > 0 asserts that every entry of mass_all equals this value (the FAST kernel
- *                                 then hoists the multiply out of the sum); 0 when masses differ or are unknown
+ *                                 then hoists the multiply out of the sum); < 0 asserts that every entry equals
+ *                                 -uniform_mass except a sparse set (at most n/64 bodies: the reference's scene has two
+ *                                 heavy bodies among 151 000 of weight 1, main.rs:282-291) — those are found on the
+ *                                 device each step and added with their own masses after the equal-mass main pass;
+ *                                 0 when masses differ freely or are unknown
  *   vel       float2[n_targets]   this shard's velocities, updated in place
  *   pos_out   float2[n_targets]   this shard's new positions (must not alias pos_all)
  *   acc_out   float2[n_targets]   or NULL

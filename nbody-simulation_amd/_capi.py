@@ -530,6 +530,22 @@ class MultiContext(Context):
         self.n = 0
 
 
+def mass_hint(weight) -> float:
+    """The `uniform_mass` argument of the direct step for these weights (include/nbody_hip.h): > 0 all equal,
+    < 0 all equal to its magnitude but for at most n/256 bodies, 0 neither."""
+    w = np.asarray(weight)
+    if w.size == 0:
+        return 0.0
+    vals, counts = np.unique(w, return_counts=True)
+    base = vals[np.argmax(counts)]
+    odd = int(w.size - counts.max())
+    if base <= 0:
+        return 0.0
+    if odd == 0:
+        return float(base)
+    return -float(base) if odd <= w.size // 256 else 0.0
+
+
 # ---- device-pointer level (raw addresses; used with torch tensors by sharding.py / bench.py)
 def direct_workspace_bytes(n_sources: int, n_targets: int) -> int:
     return int(load().nbody_direct_workspace_bytes(int(n_sources), int(n_targets)))

@@ -187,6 +187,7 @@ size_t direct_ws_bytes(int64_t n_src, int64_t n_tgt) {
 struct DirectPlan {
   int arith = 0;
   bool uni = false;
+  float sparse_base = 0.f;  // > 0: all masses equal this but a few bodies', which travel with the near list
   bool nearfar = false;
   int use_hazard = 0;
   size_t partial_bytes = 0;
@@ -203,6 +204,10 @@ int direct_plan(nbody_ctx* c, int64_t n_src, float uniform_mass, int64_t n_tgt_t
   p.arith = arith;
   p.uni = uniform_mass > 0.f && env_int("NBODY_DIRECT_NO_UNIFORM", 0) == 0;
   p.nearfar = choose_direct_config(n_src, n_tgt_total, p.uni).nearfar;
+  // uniform_mass < 0: every mass is -uniform_mass except a sparse set; the split hands those to direct_finish, so the
+  // main pass runs at the equal-mass rate.  Without the split (small problems) the per-body-mass kernel is used.
+  if (uniform_mass < 0.f && p.nearfar && env_int("NBODY_DIRECT_NO_UNIFORM", 0) == 0 && env_int("NBODY_DIRECT_NO_SPARSE", 0) == 0)
+    p.sparse_base = -uniform_mass;
   p.use_hazard = arith == NBODY_ARITH_AUTO;
   p.partial_bytes = direct_partial_bytes(n_src, n_tgt_max);
   *out = p;
@@ -225,7 +230,8 @@ int direct_prep(nbody_ctx* c, hipStream_t stream, int64_t n_src, const void* pos
     NearFarLayout L = nearfar_layout(n_src);
     const float2* pos_far = nullptr;
     const uint32_t* near_list = nullptr;
-    HIPCHK(c, launch_nearfar(stream, (const float2*)pos_all, (int)n_src, clamp, p.use_hazard, flags, nf_scratch, L, &pos_far, &near_list));
+    HIPCHK(c, launch_nearfar(stream, (const float2*)pos_all, (const float*)mass_all, p.sparse_base, (int)n_src, clamp, p.use_hazard, flags,
+                             nf_scratch, L, &pos_far, &near_list));
   } else {
     HIPCHK(c, launch_decide_simple(stream, p.use_hazard, flags));
   }
@@ -290,6 +296,7 @@ int direct_run(nbody_ctx* c, hipStream_t stream, int64_t n_src, const void* pos_
       a0.near_list = near_list;
       a0.to_partial = 1;
       a0.run_state = 0;
+      if (p.sparse_base > 0.f) a0.uniform_mass = p.sparse_base;  // the odd masses sit in the near list (state 1 reads them all)
       HIPCHK(c, launch_direct_fast(stream, a0, cfg, true));
     }
     DirectArgs a1 = a;  // state 1: one clamped pass over every source
@@ -388,6 +395,18 @@ template <class T> int upload(nbody_ctx* c, int64_t n, const T* pos, const T* ve
   }
   s.h_weight_stale = false;
   s.uniform_mass = (uniform && s.h_weight[0] > 0) ? (float)s.h_weight[0] : 0.f;
+  s.sparse_base = 0.f;
+  if (!uniform && n > 0) {  // one mass but for a few bodies?  (majority vote, then a count)
+    uint32_t cand = 0;
+    int64_t votes = 0, odd = 0;
+    for (int64_t i = 0; i < n; ++i) {
+      const uint32_t wv = s.h_weight[(size_t)i];
+      if (votes == 0) { cand = wv; votes = 1; }
+      else votes += (wv == cand) ? 1 : -1;
+    }
+    for (int64_t i = 0; i < n; ++i) odd += s.h_weight[(size_t)i] != cand;
+    if (cand > 0 && odd <= n / 256) s.sparse_base = (float)cand;
+  }
   s.tree_valid = false;
   if (sizeof(T) == 4) c->has_f32 = true; else c->has_f64 = true;
   return NBODY_OK;
@@ -1453,17 +1472,17 @@ NB_API int nbody_update_direct_f32(nbody_ctx* c, float delta, int n_steps, nbody
     const std::string sig = direct_env_signature();
     const bool stale = !g.exec || g.n != s.n || g.pos_a != st.pos || g.pos_b != s.pos_next || g.vel != st.vel ||
                        g.mass != st.mass || g.ws != c->workspace || g.delta != delta || g.clamp != c->params.clamp ||
-                       g.uniform != s.uniform_mass || g.arith != c->params.arith || g.env != sig;
+                       g.uniform != direct_mass_hint(s) || g.arith != c->params.arith || g.env != sig;
     if (stale) {
       g.reset();
       hipGraph_t graph = nullptr;
       hipError_t e = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal);
       int rc1 = NBODY_OK, rc2 = NBODY_OK;
       if (e == hipSuccess) {
-        rc1 = direct_step_dev(c, c->stream, s.n, st.pos, st.mass, s.uniform_mass, 0, s.n, st.vel, s.pos_next, nullptr, delta,
+        rc1 = direct_step_dev(c, c->stream, s.n, st.pos, st.mass, direct_mass_hint(s), 0, s.n, st.vel, s.pos_next, nullptr, delta,
                               c->params.clamp, c->params.arith, c->workspace, c->workspace_bytes, nullptr);
         if (!rc1)
-          rc2 = direct_step_dev(c, c->stream, s.n, s.pos_next, st.mass, s.uniform_mass, 0, s.n, st.vel, st.pos, nullptr, delta,
+          rc2 = direct_step_dev(c, c->stream, s.n, s.pos_next, st.mass, direct_mass_hint(s), 0, s.n, st.vel, st.pos, nullptr, delta,
                                 c->params.clamp, c->params.arith, c->workspace, c->workspace_bytes, nullptr);
         e = hipStreamEndCapture(c->stream, &graph);
       }
@@ -1474,7 +1493,7 @@ NB_API int nbody_update_direct_f32(nbody_ctx* c, float delta, int n_steps, nbody
         (void)hipGetLastError();
       } else {
         g.n = s.n; g.pos_a = st.pos; g.pos_b = s.pos_next; g.vel = st.vel; g.mass = st.mass; g.ws = c->workspace;
-        g.delta = delta; g.clamp = c->params.clamp; g.uniform = s.uniform_mass; g.arith = c->params.arith; g.env = sig;
+        g.delta = delta; g.clamp = c->params.clamp; g.uniform = direct_mass_hint(s); g.arith = c->params.arith; g.env = sig;
       }
     }
     if (g.exec) {
@@ -1484,7 +1503,7 @@ NB_API int nbody_update_direct_f32(nbody_ctx* c, float delta, int n_steps, nbody
   }
   for (; step < n_steps; ++step) {
     auto& st = s.set[s.cur];
-    rc = direct_step_dev(c, c->stream, s.n, st.pos, st.mass, s.uniform_mass, 0, s.n, st.vel, s.pos_next, nullptr, delta,
+    rc = direct_step_dev(c, c->stream, s.n, st.pos, st.mass, direct_mass_hint(s), 0, s.n, st.vel, s.pos_next, nullptr, delta,
                          c->params.clamp, c->params.arith, c->workspace, c->workspace_bytes, c->timer);
     if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1509,7 +1528,7 @@ NB_API int nbody_accel_direct_f32(nbody_ctx* c, float* acc_xy) {
   int rc = ensure_workspace(c, direct_ws_bytes(s.n, s.n));
   if (rc) return rc;
   auto& st = s.set[s.cur];
-  rc = direct_step_dev(c, c->stream, s.n, st.pos, st.mass, s.uniform_mass, 0, s.n, nullptr, nullptr, s.acc, 0.f, c->params.clamp,
+  rc = direct_step_dev(c, c->stream, s.n, st.pos, st.mass, direct_mass_hint(s), 0, s.n, nullptr, nullptr, s.acc, 0.f, c->params.clamp,
                        c->params.arith, c->workspace, c->workspace_bytes, c->timer);
   if (rc) return rc;
   if (s.n) HIPCHK(c, hipMemcpyAsync(acc_xy, s.acc, (size_t)s.n * sizeof(float2), hipMemcpyDeviceToHost, c->stream));

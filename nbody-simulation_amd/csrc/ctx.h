@@ -28,6 +28,7 @@ template <class T> struct State {
   int cur = 0;
   T2* pos_next = nullptr;  // direct step output, swapped with set[cur].pos
   float uniform_mass = 0.f;  // > 0 when every weight is the same value (checked on upload)
+  float sparse_base = 0.f;   // > 0 when every weight is this value but for at most n/256 bodies (the reference's scene)
   T2* acc = nullptr;
   // tree
   void* geom0 = nullptr;
@@ -65,6 +66,9 @@ template <class T> struct State {
   std::vector<uint32_t> h_tmp;
 };
 
+
+// The `uniform_mass` argument of the direct step for this state: > 0 all equal, < 0 all equal to its magnitude but a few, 0 neither.
+template <class T> inline float direct_mass_hint(const State<T>& s) { return s.uniform_mass > 0.f ? s.uniform_mass : -s.sparse_base; }
 
 }  // namespace nbody
 

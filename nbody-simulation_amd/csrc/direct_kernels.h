@@ -41,8 +41,9 @@ struct NearFarLayout {
   size_t keys0, keys1, idx0, idx1, is_near, scan, near_list, pos_far, cub_temp, cub_temp_bytes, total;
 };
 NearFarLayout nearfar_layout(int64_t n_src);
-hipError_t launch_nearfar(hipStream_t s, const float2* pos, int n, float clamp, int use_hazard, int* flags,
-                          char* scratch, const NearFarLayout& L, const float2** pos_far, const uint32_t** near_list);
+// heavy_base > 0: bodies whose mass differs from it join the near list (sparse-heavy scenes; `mass` is then read)
+hipError_t launch_nearfar(hipStream_t s, const float2* pos, const float* mass, float heavy_base, int n, float clamp, int use_hazard,
+                          int* flags, char* scratch, const NearFarLayout& L, const float2** pos_far, const uint32_t** near_list);
 hipError_t launch_decide_simple(hipStream_t s, int use_hazard, int* flags);
 
 hipError_t launch_direct_fast(hipStream_t s, const DirectArgs& a, const DirectConfig& c, bool noclamp);

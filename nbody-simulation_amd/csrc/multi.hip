@@ -326,14 +326,14 @@ int direct_worker(Multi& M, int d, float delta, int n_steps) {
     float2* nxt = (float2*)M.posbuf[par ^ 1][(size_t)d];
     for (int p = 0; p < G; ++p) bases[(size_t)p] = (char*)M.posbuf[par ^ 1][(size_t)p];
     if (ok) {
-      rc = ctx_direct_prep(S, S->stream, n, cur, st.mass, s.uniform_mass, total, tmax, S->params.clamp, S->params.arith, S->workspace,
+      rc = ctx_direct_prep(S, S->stream, n, cur, st.mass, direct_mass_hint(s), total, tmax, S->params.clamp, S->params.arith, S->workspace,
                            S->workspace_bytes);
       ok = rc == NBODY_OK;
     }
     for (int c = 0; c < C; ++c) {
       const int64_t tb = M.block_begin(c, d), nt = M.block_count(c, d);
       if (ok && nt > 0) {
-        rc = ctx_direct_run(S, S->stream, n, cur, st.mass, s.uniform_mass, tb, nt, st.vel + tb, nxt + tb, nullptr, delta, S->params.clamp,
+        rc = ctx_direct_run(S, S->stream, n, cur, st.mass, direct_mass_hint(s), tb, nt, st.vel + tb, nxt + tb, nullptr, delta, S->params.clamp,
                             S->params.arith, total, tmax, S->workspace, S->workspace_bytes, S->timer);
         ok = rc == NBODY_OK;
       }

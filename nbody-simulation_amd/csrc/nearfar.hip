@@ -55,8 +55,12 @@ __device__ __forceinline__ int lower_bound_u64(const uint64_t* __restrict__ a, i
 }
 
 // is_near[i] = 1 when another body shares body i's cell or one of the 8 cells around it.
+// `heavy_base` > 0: a body whose mass differs from it is listed as near too — the main pass then runs with the one mass
+// hoisted out of the sum, and direct_finish adds the few odd bodies with their own masses (the reference's scene: two
+// heavy bodies among 151 000 of weight 1, main.rs:282-291).
 __global__ __launch_bounds__(256) void nf_mark(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ idx,
-                                               int n, uint32_t* __restrict__ is_near) {
+                                               int n, const float* __restrict__ mass, float heavy_base,
+                                               uint32_t* __restrict__ is_near) {
   int r = blockIdx.x * 256 + threadIdx.x;
   if (r >= n) return;
   const uint64_t k = keys[r];
@@ -76,7 +80,9 @@ __global__ __launch_bounds__(256) void nf_mark(const uint64_t* __restrict__ keys
       near |= (p < n && keys[p] <= lo + 2);
     }
   }
-  is_near[idx[r]] = near ? 1u : 0u;
+  const uint32_t body = idx[r];
+  if (heavy_base > 0.f) near |= mass[body] != heavy_base;
+  is_near[body] = near ? 1u : 0u;
 }
 
 __global__ __launch_bounds__(256) void nf_compact(const float2* __restrict__ pos, const uint32_t* __restrict__ is_near,
@@ -134,8 +140,8 @@ NearFarLayout nearfar_layout(int64_t n_src) {
 }
 
 // Enqueues the split.  On return flags[kFlagState] is (will be) valid on the stream.
-hipError_t launch_nearfar(hipStream_t s, const float2* pos, int n, float clamp, int use_hazard, int* flags,
-                          char* scratch, const NearFarLayout& L, const float2** pos_far, const uint32_t** near_list) {
+hipError_t launch_nearfar(hipStream_t s, const float2* pos, const float* mass, float heavy_base, int n, float clamp, int use_hazard,
+                          int* flags, char* scratch, const NearFarLayout& L, const float2** pos_far, const uint32_t** near_list) {
   uint64_t* k0 = (uint64_t*)(scratch + L.keys0);
   uint64_t* k1 = (uint64_t*)(scratch + L.keys1);
   uint32_t* i0 = (uint32_t*)(scratch + L.idx0);
@@ -167,7 +173,7 @@ hipError_t launch_nearfar(hipStream_t s, const float2* pos, int n, float clamp, 
   size_t tb = L.cub_temp_bytes;
   e = hipcub::DeviceRadixSort::SortPairs(scratch + L.cub_temp, tb, dk, dv, n, 0, 64, s);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(nf_mark, dim3(blocks), dim3(256), 0, s, dk.Current(), dv.Current(), n, is_near);
+  hipLaunchKernelGGL(nf_mark, dim3(blocks), dim3(256), 0, s, dk.Current(), dv.Current(), n, mass, heavy_base, is_near);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
   tb = L.cub_temp_bytes;

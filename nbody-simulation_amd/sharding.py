@@ -77,7 +77,7 @@ class ShardedDirectStepper:
         self.n_local = sum(cnt for _, cnt in self.blocks)
         device = device if device is not None else torch.device("cuda", 0)
         self.device = device
-        uniform = float(weight[0]) if n > 0 and weight[0] > 0 and bool(np.all(weight == weight[0])) else 0.0
+        uniform = _capi.mass_hint(weight)    # > 0 equal masses, < 0 equal but for a few (added after the main pass), 0 neither
 
         def padded(a, rows):
             out = np.zeros((rows,) + a.shape[1:], a.dtype)

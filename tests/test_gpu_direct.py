@@ -359,3 +359,56 @@ def test_config5_shard_slice_of_16M(nb, orc):
     v_exp = vel[begin:begin + cnt] + a * dt
     assert np.array_equal(tv.cpu().numpy(), v_exp)
     assert np.array_equal(out.cpu().numpy(), pos[begin:begin + cnt] + v_exp * dt)
+
+
+# ------------------------------------------------------------------ a few odd masses among equal ones (the reference's scene)
+def test_mass_hint():
+    from nbody_simulation_amd._capi import mass_hint
+    assert mass_hint(np.ones(1000, np.uint32)) == 1.0
+    assert mass_hint(np.full(10, 7, np.uint32)) == 7.0
+    w = np.ones(151409, np.uint32)
+    w[0], w[1] = 75_000_000, 750_000
+    assert mass_hint(w) == -1.0                                  # World::new: two heavy bodies first (main.rs:282-291)
+    assert mass_hint((np.arange(1000) % 3 + 1).astype(np.uint32)) == 0.0
+    w = np.ones(1024, np.uint32); w[:5] = 9
+    assert mass_hint(w) == 0.0                                   # more than n/256 odd bodies
+    assert mass_hint(np.zeros(0, np.uint32)) == 0.0
+
+
+def test_sparse_heavy_masses_ride_with_the_near_list(nb, orc, force_nearfar):
+    """uniform_mass < 0: every mass is |uniform_mass| but for a few bodies; those are found on the device, leave the
+    equal-mass main pass (their slot holds a far-away point) and are added by direct_finish with their own masses."""
+    n = 40000
+    pos, vel, _ = nb.scenes.plummer(n, seed=86)
+    w = np.full(n, 3, np.uint32)
+    heavy = [0, 1, 777, 20000, n - 1]
+    w[heavy] = [75_000_000, 750_000, 1, 4_000_000_000, 2]        # heavier, lighter, beyond 2^24 (rounded by `as f32`)
+    pos[100] = pos[200] + F32(0.004)                             # a genuinely near pair besides
+    pos[777] = pos[778] + F32(0.002)                             # an odd-mass body that is ALSO near
+    acc, (hazard, fallback, n_near, state) = _dev_accel(nb, pos, w, uniform=-3.0)
+    assert (hazard, fallback, state) == (0, 0, 0)
+    assert n_near == len(heavy) + 2 + 1                          # the odd masses, the pair, 777's partner
+    ref64, norm, cpu32 = _refs(orc, pos, w)
+    check_fast(acc, ref64, norm, cpu32)
+    a0, st0 = _dev_accel(nb, pos, w, uniform=0.0)                # per-body masses: the same sum within the tolerance
+    assert st0[2] == 4                                           # just the two close pairs
+    check_fast(a0, ref64, norm, cpu32)
+
+
+def test_reference_scene_takes_the_sparse_path(nb, orc, monkeypatch):
+    """The whole scene of World::new (151 k bodies, two heavy): the context finds the sparse structure on upload; the
+    step equals the per-body-mass one within the tolerance, on sampled targets against the oracle."""
+    C = nb._capi
+    pos, vel, w = nb.scenes.galaxy()
+    n = pos.shape[0]
+    tg = np.concatenate([[0, 1], np.arange(2, n, 37)])
+    ref64, norm, _ = _refs(orc, pos, w, targets=tg)
+    accs = {}
+    for no_sparse in ("0", "1"):
+        monkeypatch.setenv("NBODY_DIRECT_NO_SPARSE", no_sparse)
+        with C.Context(0) as c:
+            c.upload(pos, vel, w)
+            accs[no_sparse] = c.accel_direct()
+    check_fast(accs["0"][tg], ref64, norm, label=" galaxy sparse")
+    check_fast(accs["1"][tg], ref64, norm, label=" galaxy per-body")
+    assert not np.array_equal(accs["0"], accs["1"])              # i.e. another kernel really ran
