@@ -47,4 +47,9 @@ hipError_t bvh_build_finish(hipStream_t s, const uint32_t* weight, int n, int le
                             uint32_t* order_out, void* geom0, void* geom1, void* link, int* depth_out, uint32_t* mass_out,
                             float2* size_out);
 
+// What the host would conclude from the flags after bvh_build_finish, written on the stream for kernels enqueued ahead
+// of that conclusion: verdict[0] = node count if the build is complete and usable (no fallback, no long node left at
+// `level_end`, every node numbered, count within the buffers), else 0; verdict[1] = the same as a 0/1 word.
+hipError_t bvh_build_verdict(hipStream_t s, int level_end, char* scratch, const BvhBuildLayout& L, int* verdict);
+
 }  // namespace nbody

@@ -1501,4 +1501,21 @@ hipError_t bvh_build_finish(hipStream_t s, const uint32_t* weight, int n, int le
   return hipMemcpyAsync(order_out, a.ID, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToDevice, s);
 }
 
+namespace {
+__global__ void bvh_verdict_kernel(const int* __restrict__ flags, const int* __restrict__ bigcount, int level_end, int node_cap,
+                                   int* __restrict__ verdict) {
+  const int m = flags[kBvhNodeCount];
+  const bool ok = flags[kBvhFallback] == 0 && flags[kBvhBadIndex] == 0 && m > 0 && m <= node_cap &&
+                  (level_end <= 0 || bigcount[level_end] == 0);
+  verdict[0] = ok ? m : 0;
+  verdict[1] = ok ? 1 : 0;
+}
+}  // namespace
+
+hipError_t bvh_build_verdict(hipStream_t s, int level_end, char* scratch, const BvhBuildLayout& L, int* verdict) {
+  hipLaunchKernelGGL(bvh_verdict_kernel, dim3(1), dim3(1), 0, s, (const int*)(scratch + L.flags), (const int*)(scratch + L.bigcount),
+                     level_end, L.node_cap, verdict);
+  return hipGetLastError();
+}
+
 }  // namespace nbody

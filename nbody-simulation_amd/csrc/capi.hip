@@ -117,7 +117,7 @@ template <class T> void free_state(State<T>& s) {
   free_dev(s.pos_next); free_dev(s.acc); free_dev(s.geom0); free_dev(s.geom1); free_dev(s.link); free_dev(s.order_dev);
   free_dev(s.node_depth); free_dev(s.node_mass); free_dev(s.node_size); free_dev(s.qb_scratch); free_dev(s.bb_scratch); free_dev(s.ws_scratch); free_dev(s.ws_terms); free_dev(s.wt_hist);
   s.node_aux_cap = 0; s.qb_scratch_bytes = 0; s.bb_scratch_bytes = 0; s.h_weight_stale = false;
-  s.ws_scratch_bytes = 0; s.ws_capacity = 0; s.ws_backoff = 0; s.quad_depth_hint = 0; s.wt_hist_n = -1;
+  s.ws_scratch_bytes = 0; s.ws_capacity = 0; s.ws_backoff = 0; s.quad_depth_hint = 0; s.wt_hist_n = -1; s.bvh_levels_hint = 0; s.ahead_total_due = false;
   s.tree_host_stale = false; s.n_nodes = 0;
   s.node_cap = 0; s.n = 0; s.tree_valid = false; s.tree.clear();
   s.h_pos.clear(); s.h_weight.clear();
@@ -656,6 +656,54 @@ template <class T> int download_tree(nbody_ctx* c, State<T>& s) {
   return NBODY_OK;
 }
 
+// ---- phase timing by events (see PhaseEvents in ctx.h)
+// `prev`: the step enqueued just before this one, with nothing in between — its end event doubles as this step's start
+// (every recorded event is a marker in the queue, ~6 us of idle stream: two back to back would be the largest gap of a step).
+int phase_begin(nbody_ctx* c, PhaseEvents* out, const PhaseEvents* prev = nullptr) {
+  PhaseEvents p;
+  for (int k = prev ? 1 : 0; k < 4; ++k) {
+    if (!c->ph_free.empty()) {
+      p.e[k] = c->ph_free.back();
+      c->ph_free.pop_back();
+    } else {
+      HIPCHK(c, hipEventCreate(&p.e[k]));
+    }
+  }
+  if (prev) {
+    p.e[0] = prev->e[3];
+    p.borrowed = true;
+  } else {
+    HIPCHK(c, hipEventRecord(p.e[0], c->stream));
+  }
+  *out = p;
+  return NBODY_OK;
+}
+int phase_mark(nbody_ctx* c, const PhaseEvents& p, int k) {
+  HIPCHK(c, hipEventRecord(p.e[k], c->stream));
+  if (k == 3) c->ph_pending.push_back(p);
+  return NBODY_OK;
+}
+// Reads every recorded step's phases into the context's (and the caller's) Counting.  Waits for them.
+int phase_drain(nbody_ctx* c) {
+  for (auto& p : c->ph_pending) {
+    HIPCHK(c, hipEventSynchronize(p.e[3]));
+    float ms[3] = {0.f, 0.f, 0.f};
+    for (int k = 0; k < 3; ++k) HIPCHK(c, hipEventElapsedTime(&ms[k], p.e[k], p.e[k + 1]));
+    c->counting.build_bvh += 1e-3 * ms[0];
+    c->counting.sum_gravity += 1e-3 * ms[1];
+    c->counting.post_calculations += 1e-3 * ms[2];
+    if (c->ph_counter) {
+      c->ph_counter->build_bvh += 1e-3 * ms[0];
+      c->ph_counter->sum_gravity += 1e-3 * ms[1];
+      c->ph_counter->post_calculations += 1e-3 * ms[2];
+    }
+  }
+  for (auto& p : c->ph_pending)
+    for (int k = p.borrowed ? 1 : 0; k < 4; ++k) c->ph_free.push_back(p.e[k]);
+  c->ph_pending.clear();
+  return NBODY_OK;
+}
+
 // Phase 1 of update (main.rs:398-401): snapshot + build + upward pass.  After it, for the BVH, set[cur] holds the
 // permuted particles and set[1-cur].pos the pre-build snapshot (`cloned`); for the quad tree set[1-cur].pos/.mass
 // hold the leaf-ordered copies the leaves own.
@@ -880,32 +928,216 @@ int tree_walk_phase(nbody_ctx* c, State<T>& s, int kind, const void* tgt_pos, in
   return NBODY_OK;
 }
 
+// A whole f32 BVH step enqueued AHEAD of the host's knowledge of it.  The plain sequence asks the device three
+// questions per step (is the build complete?  did the walk's estimate wrap?  how many terms were there?) and the old
+// step driver added a wait at every phase boundary: five round trips on a 1.2 ms step.  Here the stream gets, in one go,
+//     build (blind: the levels the last tree had, plus one) -> verdict of the build, ON THE DEVICE -> row gather ->
+//     the walk's preparation (estimate scan, wrap check, budget) -> a 0.5 KB copy of {verdict, flags, level counters,
+//     walk info} to pinned memory + an event -> the walk kernel, reading the node count from device memory and
+//     returning at once if the verdict or the preparation said no
+// and the host waits for that EVENT only — it fires when the long kernel starts, so the integration and the whole next
+// step's build are enqueued while the walk runs and the stream never drains between steps.  Everything the host
+// decides on is known before the walk; the rows a step starts from stay intact until it has decided (the gather writes
+// the other set, the integration is enqueued after the decision), so a step whose speculation fails is simply done
+// again by the plain sequence.  The walk's exact term count (next estimate's scale) is read one step late.
+// Returns NBODY_OK (step done), 1 (not applicable / speculation failed: take the plain sequence), or an error.
+constexpr int kSpecWords = 2 + 128 + 8 + 8;  // verdict | flags + level counters (512 B) | info before the walk | info after it
+
+template <class T> int step_ahead_collect(nbody_ctx* c, State<T>& s) {  // the previous ahead-step's term count, if one is due
+  if (!s.ahead_total_due) return NBODY_OK;
+  s.ahead_total_due = false;
+  const int* post = c->spec_host + 2 + 128 + 8;
+  unsigned long long total = 0;
+  std::memcpy(&total, &post[6], 8);
+  s.wt_total = total;
+  if ((double)total > (double)s.n * (double)s.n / 16.0) s.ws_backoff = 64;  // nearly the direct sum: the fused walk for a while
+  return NBODY_OK;
+}
+
+template <class T> int bvh_step_ahead(nbody_ctx* c, State<T>& s, T delta, PhaseEvents* chain) {
+  if constexpr (!std::is_same<T, float>::value) {
+    return 1;
+  } else {
+    const int n = (int)s.n;
+    const int leaf = c->params.leaf_size;
+    const int mode = env_int("NBODY_WALK_SPLIT", 1);
+    if (n < 4096 || leaf < 16 || mode != 1 || c->want_stats || s.ws_backoff != 0) return 1;
+    if (!s.wt_hist || s.wt_hist_n != n || s.wt_hist_begin != 0) return 1;  // no walk of these targets to estimate from yet
+    if (env_int("NBODY_STEP_AHEAD", 1) == 0 || env_int("NBODY_BVH_BUILD_HOST", 0) != 0 || env_int("NBODY_WALK_PER_THREAD", 0) != 0 ||
+        env_int("NBODY_WALK_TILE_COUNT", 0) != 0)
+      return 1;
+    const BvhBuildLayout L = bvh_build_layout(n, leaf);
+    const WalkSplitLayout WL = walk_split_layout(n);
+    if (s.bb_scratch_bytes < L.total || s.ws_scratch_bytes < WL.total || s.node_cap < (size_t)L.node_cap || s.node_aux_cap < (size_t)L.node_cap)
+      return 1;  // the plain sequence sizes the buffers the first time
+    static_assert(kBvhFlagWords + kBvhLevels <= 128, "flags and level counters travel as one 512-byte block");
+    if (L.bigcount - L.flags + kBvhLevels * sizeof(int) > 128 * sizeof(int)) return 1;
+    if (!c->spec_dev) {
+      HIPCHK(c, hipMalloc((void**)&c->spec_dev, 2 * sizeof(int)));
+      HIPCHK(c, hipHostMalloc((void**)&c->spec_host, kSpecWords * sizeof(int), hipHostMallocDefault));
+      HIPCHK(c, hipEventCreateWithFlags(&c->spec_event, hipEventDisableTiming));
+    }
+    PhaseEvents ph;
+    int rc = phase_begin(c, &ph, chain->e[3] ? chain : nullptr);
+    *chain = PhaseEvents{};
+    if (rc) return rc;
+    auto& in = s.set[s.cur];
+    auto& out = s.set[1 - s.cur];
+    // ---- build: as many long-node levels as the last tree had, plus one (a balanced tree's, plus two, the first time)
+    const int first_levels = bvh_build_first_levels(n);
+    int lv_end = first_levels > 0 ? first_levels + 2 : 0;
+    if (lv_end > 0 && s.bvh_levels_hint > 0 && s.bvh_levels_hint + 1 < lv_end) lv_end = s.bvh_levels_hint + 1;
+    if (lv_end > 0) lv_end = std::max(1, env_int("NBODY_BVH_BLIND_LEVELS", lv_end));  // tests: too few levels, the verdict fails
+    if (lv_end > kBvhKeyDepth + 1) lv_end = kBvhKeyDepth + 1;
+    HIPCHK(c, bvh_build_begin(c->stream, in.pos, n, s.bb_scratch, L));
+    if (lv_end > 0) HIPCHK(c, bvh_build_levels(c->stream, n, leaf, 0, lv_end, s.bb_scratch, L));
+    HIPCHK(c, bvh_build_finish(c->stream, in.weight, n, leaf, 0, s.bb_scratch, L, s.order_dev, s.geom0, s.geom1, s.link, s.node_depth,
+                               s.node_mass, s.node_size));
+    HIPCHK(c, bvh_build_verdict(c->stream, lv_end, s.bb_scratch, L, c->spec_dev));
+    GatherArgs<T> g{};
+    g.perm = s.order_dev;
+    g.n = n;
+    g.pos_in = in.pos; g.pos_out = out.pos;
+    g.weight_in = in.weight;
+    g.mass_out = out.mass;
+    g.vel_in = in.vel; g.vel_out = out.vel;
+    g.weight_out = out.weight;
+    g.ids_in = in.ids; g.ids_out = out.ids;
+    HIPCHK(c, launch_gather<T>(c->stream, g));
+    rc = phase_mark(c, ph, 1);
+    if (rc) return rc;
+    // ---- walk (rows as after the build: `out` is the permuted set, `in` the snapshot)
+    WalkArgs<T> w{};
+    w.geom0 = s.geom0; w.geom1 = s.geom1; w.link = s.link;
+    w.n_nodes = 0;
+    w.n_nodes_dev = c->spec_dev;
+    w.big_leaves = 1;
+    w.fast = c->params.arith == NBODY_ARITH_FAST;
+    w.theta = (T)c->params.theta;
+    w.clamp = (T)c->params.clamp;
+    w.acc = s.acc;
+    w.leaf_pos = out.pos;
+    w.leaf_mass = out.mass;
+    const bool as_written = c->params.order == NBODY_ORDER_AS_WRITTEN;
+    w.tgt_pos = as_written ? in.pos : out.pos;
+    w.n_tgt = n;
+    const uint32_t* tgt_ids = as_written ? in.ids : out.ids;
+    int shift = 0;
+    while ((s.wt_total >> shift) >= (1ull << 31)) ++shift;
+    if (env_int("NBODY_WALK_TILE_POISON", 0) != 0)  // test hook: a history whose scan wraps must be noticed
+      HIPCHK(c, hipMemsetAsync(s.wt_hist, 0xFF, (size_t)s.n * 4, c->stream));
+    int64_t waves = 0;
+    HIPCHK(c, launch_tree_walk_tile_prep<T>(c->stream, w, s.ws_scratch, WL, tgt_ids, s.wt_hist, 1, shift, &waves));
+    int* walk_info = (int*)(s.ws_scratch + WL.info);
+    int* h = c->spec_host;
+    HIPCHK(c, hipMemcpyAsync(h, c->spec_dev, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(h + 2, s.bb_scratch + L.flags, 128 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(h + 2 + 128, walk_info, 8 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipEventRecord(c->spec_event, c->stream));
+    {
+      TimerScope ts(c->timer, c->stream);
+      HIPCHK(c, launch_tree_walk_tile_main<T>(c->stream, w, s.ws_scratch, WL, tgt_ids, s.wt_hist, waves));
+    }
+    HIPCHK(c, hipMemcpyAsync(h + 2 + 128 + 8, walk_info, 8 * sizeof(int), hipMemcpyDeviceToHost, c->stream));  // read one step late
+    rc = phase_mark(c, ph, 2);
+    if (rc) return rc;
+    // ---- the step's one wait: for the event in front of the walk kernel
+    HIPCHK(c, hipEventSynchronize(c->spec_event));
+    rc = step_ahead_collect<T>(c, s);  // (the previous step's copies are older than this event)
+    if (rc) return rc;
+    const int* flags = h + 2;
+    const int* bigcount = flags + (L.bigcount - L.flags) / sizeof(int);
+    const int* info = h + 2 + 128;
+    if (env_int("NBODY_TRACE", 0) != 0) {
+      std::fprintf(stderr, "[nbody] step ahead: build verdict %d (%d nodes, depth %d, fallback %d, %d blind levels)\n", h[1], flags[kBvhNodeCount],
+                   flags[kBvhMaxDepth], flags[kBvhFallback], lv_end);
+      std::fprintf(stderr, "[nbody] tile walk (step ahead): estimate from the last walk (shift %d, total %d), %d per wave, overflow %d\n", shift,
+                   info[0], info[3], info[1]);
+    }
+    if (h[1] == 0) {  // the build needs more levels or the host builder: nothing was integrated, `in` is intact
+      s.wt_hist_n = -1;  // (the walk returned at once and left zeros in the history)
+      s.bvh_levels_hint = 0;
+      (void)phase_mark(c, ph, 3);
+      return 1;
+    }
+    // the build stands: what bvh_build_device records
+    int used = 0;
+    while (used < kBvhLevels - 1 && bigcount[used] != 0) ++used;
+    s.bvh_levels_hint = used;
+    s.cur = 1 - s.cur;
+    s.h_weight_stale = true;
+    s.n_nodes = flags[kBvhNodeCount];
+    s.tree_kind = NBODY_TREE_BVH;
+    s.tree_max_depth = flags[kBvhMaxDepth];
+    s.tree_host_stale = true;
+    s.tree_valid = true;
+    c->bvh_stops = flags[kBvhStops];
+    c->last_build_device = true;
+    if (info[1] != 0) {  // the estimate's scan wrapped (the walk kernel returned at once): walk again the plain way
+      rc = tree_walk_phase<T>(c, s, NBODY_TREE_BVH, nullptr, 0, s.acc);
+      if (rc) return rc;
+    } else {
+      s.ahead_total_due = true;
+    }
+    HIPCHK(c, launch_integrate<T>(c->stream, s.set[s.cur].pos, s.set[s.cur].vel, s.acc, s.n, delta));
+    rc = phase_mark(c, ph, 3);
+    if (!rc) *chain = ph;  // the next step starts where this one ends
+    return rc;
+  }
+}
+
 template <class T> int update_tree(nbody_ctx* c, int kind, T delta, int n_steps, nbody_counting* counter) {
   if (!c) return NBODY_ERR_INVALID;
   if (!has_state<T>(c)) return fail(c, NBODY_ERR_INVALID, "update_tree: no particles of this precision uploaded");
   if (n_steps < 0) return fail(c, NBODY_ERR_INVALID, "update_tree: n_steps < 0");
   HIPCHK(c, hipSetDevice(c->device));
   State<T>& s = state_of<T>(c);
+  c->ph_counter = counter;
+  auto done = [&](int rc) {
+    int rc2 = phase_drain(c);  // (waits for the last step: the call is synchronous)
+    if (!rc2 && s.ahead_total_due) {
+      hipError_t e = hipStreamSynchronize(c->stream);
+      rc2 = e == hipSuccess ? step_ahead_collect<T>(c, s) : fail_hip(c, e, "hipStreamSynchronize");
+    }
+    c->ph_counter = nullptr;
+    return rc ? rc : rc2;
+  };
+  PhaseEvents chain;  // the step before, when the next one follows it directly on the stream
   for (int step = 0; step < n_steps; ++step) {
-    double t0 = now_s();
-    int rc = tree_build_phase<T>(c, s, kind);
-    if (rc) return rc;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    double t1 = now_s();
+    if (c->ph_pending.size() >= 64) {
+      int rc = phase_drain(c);
+      if (rc) return done(rc);
+      chain = PhaseEvents{};
+    }
+    if (kind == NBODY_TREE_BVH) {
+      int rc = bvh_step_ahead<T>(c, s, delta, &chain);
+      if (rc < 0) return done(rc);
+      if (rc == NBODY_OK) {
+        ++c->steps_done;
+        continue;
+      }
+    }
+    // the plain sequence: no host wait between the phases but those a phase needs for itself
+    chain = PhaseEvents{};
+    PhaseEvents ph;
+    int rc = phase_begin(c, &ph);
+    if (rc) return done(rc);
+    rc = tree_build_phase<T>(c, s, kind);
+    if (rc) return done(rc);
+    rc = phase_mark(c, ph, 1);
+    if (rc) return done(rc);
     rc = tree_walk_phase<T>(c, s, kind, nullptr, 0, s.acc);
-    if (rc) return rc;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    double t2 = now_s();
-    HIPCHK(c, launch_integrate<T>(c->stream, s.set[s.cur].pos, s.set[s.cur].vel, s.acc, s.n, delta));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    double t3 = now_s();
-    c->counting.build_bvh += t1 - t0;
-    c->counting.sum_gravity += t2 - t1;
-    c->counting.post_calculations += t3 - t2;
-    if (counter) { counter->build_bvh += t1 - t0; counter->sum_gravity += t2 - t1; counter->post_calculations += t3 - t2; }
+    if (rc) return done(rc);
+    rc = phase_mark(c, ph, 2);
+    if (rc) return done(rc);
+    hipError_t e = launch_integrate<T>(c->stream, s.set[s.cur].pos, s.set[s.cur].vel, s.acc, s.n, delta);
+    if (e != hipSuccess) return done(fail_hip(c, e, "launch_integrate"));
+    rc = phase_mark(c, ph, 3);
+    if (rc) return done(rc);
     ++c->steps_done;
   }
-  return NBODY_OK;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return done(NBODY_OK);
 }
 
 // One tree step of a rank that owns the slice [begin, begin+count) of the tree-ordered targets: the tree is built over
@@ -916,24 +1148,32 @@ template <class T> int update_tree_shard(nbody_ctx* c, int kind, T delta, int64_
   State<T>& s = state_of<T>(c);
   if (begin < 0 || count < 0 || begin + count > s.n) return fail(c, NBODY_ERR_INVALID, "update_tree_shard: slice out of range");
   HIPCHK(c, hipSetDevice(c->device));
-  double t0 = now_s();
-  int rc = tree_build_phase<T>(c, s, kind);
-  if (rc) return rc;
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  double t1 = now_s();
+  c->ph_counter = counter;
+  auto done = [&](int rc) {
+    int rc2 = phase_drain(c);
+    c->ph_counter = nullptr;
+    return rc ? rc : rc2;
+  };
+  PhaseEvents ph;
+  int rc = phase_begin(c, &ph);
+  if (rc) return done(rc);
+  rc = tree_build_phase<T>(c, s, kind);
+  if (rc) return done(rc);
+  rc = phase_mark(c, ph, 1);
+  if (rc) return done(rc);
   rc = tree_walk_phase<T>(c, s, kind, nullptr, 0, s.acc, begin, count);
-  if (rc) return rc;
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  double t2 = now_s();
+  if (rc) return done(rc);
+  rc = phase_mark(c, ph, 2);
+  if (rc) return done(rc);
   const uint32_t* rows = kind == NBODY_TREE_QUAD ? s.order_dev + begin : nullptr;
-  HIPCHK(c, launch_integrate_rows<T>(c->stream, s.set[s.cur].pos, s.set[s.cur].vel, s.acc, rows, begin, count, delta));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  double t3 = now_s();
-  c->counting.build_bvh += t1 - t0; c->counting.sum_gravity += t2 - t1; c->counting.post_calculations += t3 - t2;
-  if (counter) { counter->build_bvh += t1 - t0; counter->sum_gravity += t2 - t1; counter->post_calculations += t3 - t2; }
+  hipError_t e = launch_integrate_rows<T>(c->stream, s.set[s.cur].pos, s.set[s.cur].vel, s.acc, rows, begin, count, delta);
+  if (e != hipSuccess) return done(fail_hip(c, e, "launch_integrate_rows"));
+  rc = phase_mark(c, ph, 3);
+  if (rc) return done(rc);
   s.shard_kind = kind;
   ++c->steps_done;
-  return NBODY_OK;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return done(NBODY_OK);
 }
 template <class T>
 int export_slice(nbody_ctx* c, int64_t begin, int64_t count, void* rows_dev, void* pos_dev, void* vel_dev) {
@@ -1113,6 +1353,13 @@ void nbody::ctx_destroy_single(nbody_ctx* c) {
   free_dev(c->stats_dev);
   free_dev(c->frame_work);
   free_dev(c->frame_rgba);
+  free_dev(c->spec_dev);
+  if (c->spec_host) (void)hipHostFree(c->spec_host);
+  if (c->spec_event) (void)hipEventDestroy(c->spec_event);
+  for (auto& p : c->ph_pending)
+    for (int k = p.borrowed ? 1 : 0; k < 4; ++k)
+      if (p.e[k]) (void)hipEventDestroy(p.e[k]);
+  for (auto e : c->ph_free) (void)hipEventDestroy(e);
   if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
   free_snapshot(c);
   free_delta(c);

@@ -51,6 +51,8 @@ template <class T> struct State {
   size_t bb_scratch_bytes = 0;
   bool h_weight_stale = false;   // a device BVH build permuted the rows without touching h_weight
   int quad_depth_hint = 0;       // depth of the last device-built quad tree (how many levels the next build sorts by)
+  int bvh_levels_hint = 0;       // long-node levels the last device-built BVH had (how many the next step enqueues blind)
+  bool ahead_total_due = false;  // the last ahead-step's exact term count has not been read back yet
   // split walk (walk_split.hip): counts/offsets scratch and the term array
   char* ws_scratch = nullptr;
   size_t ws_scratch_bytes = 0;
@@ -101,6 +103,16 @@ inline std::string direct_env_signature() {
 
 }  // namespace nbody
 
+namespace nbody {
+// The three phases of a tree step (Counting, main.rs:74-79) timed by four events on the step's stream: the stream idles
+// while the host works inside a phase (a host-side build), so device-timeline intervals cover host time too, and no
+// phase boundary needs a host synchronisation.
+struct PhaseEvents {
+  hipEvent_t e[4] = {nullptr, nullptr, nullptr, nullptr};
+  bool borrowed = false;  // e[0] is the previous step's e[3]
+};
+}  // namespace nbody
+
 struct nbody_ctx {
   nbody::Multi* multi = nullptr;   // non-null: this handle fronts several devices (multi.hip) and owns no device state itself
   int64_t row_capacity = 0;        // rows the particle arrays are allocated for (>= n; a multi context pads to its block layout)
@@ -149,6 +161,13 @@ struct nbody_ctx {
   uint32_t frame_px = 0;
   unsigned long long last_stats[3] = {0, 0, 0};
   bool want_stats = false;
+  std::vector<nbody::PhaseEvents> ph_pending;           // recorded phase events
+  std::vector<hipEvent_t> ph_free;                       // reusable events
+  nbody_counting* ph_counter = nullptr;                // the caller's counter of the call in progress
+  // a BVH step enqueued whole, ahead of the host's knowledge of its build (capi.hip, bvh_step_ahead)
+  int* spec_dev = nullptr;    // [2] verdict of the build: node count or 0, ok
+  int* spec_host = nullptr;   // pinned: verdict [2] | build flags + level counters [128] | walk info before [8] and after [8] the walk
+  hipEvent_t spec_event = nullptr;
 };
 
 

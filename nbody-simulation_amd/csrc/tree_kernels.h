@@ -31,6 +31,15 @@ template <class T> struct WalkArgs {
   unsigned long long* stats;  // optional [3]: node visits, accepted nodes, leaf pairs
   int fast;                   // FAST pair arithmetic (one reciprocal) instead of the as-written IEEE divides
   int big_leaves;             // leaves hold tens of particles (BVH) rather than a handful (quad)
+  const int* n_nodes_dev;     // optional (walk_tile only): the node count is read here instead — the walk was enqueued
+                              // before the host saw the build's verdict; 0 there = the build failed, walk nothing
+};
+
+// Device-side condition of a kernel enqueued ahead of the host's knowledge: it runs iff *nonzero != 0 (when given) and
+// *zero == 0 (when given).
+struct Gate {
+  const int* nonzero = nullptr;
+  const int* zero = nullptr;
 };
 
 template <class T> struct GatherArgs {
@@ -45,7 +54,7 @@ template <class T> struct GatherArgs {
 
 template <class T> hipError_t launch_tree_walk(hipStream_t s, const WalkArgs<T>& a, bool wave_uniform);
 template <class T> hipError_t launch_gather(hipStream_t s, const GatherArgs<T>& a);
-template <class T> hipError_t launch_integrate(hipStream_t s, void* pos, void* vel, const void* acc, int64_t n, T delta);
+template <class T> hipError_t launch_integrate(hipStream_t s, void* pos, void* vel, const void* acc, int64_t n, T delta, Gate gate = Gate{});
 
 template <class T>
 hipError_t launch_integrate_rows(hipStream_t s, void* pos, void* vel, const void* acc, const uint32_t* rows, int64_t row0, int64_t n, T delta);

@@ -392,7 +392,8 @@ __global__ __launch_bounds__(256) void gather_particles(const GatherArgs<T> a) {
   using T2 = typename V2<T>::type;
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= a.n) return;
-  const int64_t s = (int64_t)a.perm[i];
+  int64_t s = (int64_t)a.perm[i];
+  if (s >= a.n) s = i;  // a build that failed leaves no permutation behind; the rows it produces are never used
   if (a.pos_out) reinterpret_cast<T2*>(a.pos_out)[i] = reinterpret_cast<const T2*>(a.pos_in)[s];
   if (a.vel_out) reinterpret_cast<T2*>(a.vel_out)[i] = reinterpret_cast<const T2*>(a.vel_in)[s];
   if (a.weight_out) a.weight_out[i] = a.weight_in[s];
@@ -402,8 +403,9 @@ __global__ __launch_bounds__(256) void gather_particles(const GatherArgs<T> a) {
 
 // main.rs:419-423: v += a*dt ; x += v*dt, multiply then add, in place.
 template <class T>
-__global__ __launch_bounds__(256) void integrate_inplace(void* pos, void* vel, const void* acc, int64_t n, T delta) {
+__global__ __launch_bounds__(256) void integrate_inplace(void* pos, void* vel, const void* acc, int64_t n, T delta, const Gate gate) {
   using T2 = typename V2<T>::type;
+  if ((gate.nonzero && *gate.nonzero == 0) || (gate.zero && *gate.zero != 0)) return;
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   T2 v = reinterpret_cast<T2*>(vel)[i];
@@ -520,9 +522,9 @@ template <class T> hipError_t launch_gather(hipStream_t s, const GatherArgs<T>& 
   hipLaunchKernelGGL((gather_particles<T>), dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0, s, a);
   return hipGetLastError();
 }
-template <class T> hipError_t launch_integrate(hipStream_t s, void* pos, void* vel, const void* acc, int64_t n, T delta) {
+template <class T> hipError_t launch_integrate(hipStream_t s, void* pos, void* vel, const void* acc, int64_t n, T delta, Gate gate) {
   if (n <= 0) return hipSuccess;
-  hipLaunchKernelGGL((integrate_inplace<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, pos, vel, acc, n, delta);
+  hipLaunchKernelGGL((integrate_inplace<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, pos, vel, acc, n, delta, gate);
   return hipGetLastError();
 }
 
@@ -530,7 +532,7 @@ template hipError_t launch_tree_walk<float>(hipStream_t, const WalkArgs<float>&,
 template hipError_t launch_tree_walk<double>(hipStream_t, const WalkArgs<double>&, bool);
 template hipError_t launch_gather<float>(hipStream_t, const GatherArgs<float>&);
 template hipError_t launch_gather<double>(hipStream_t, const GatherArgs<double>&);
-template hipError_t launch_integrate<float>(hipStream_t, void*, void*, const void*, int64_t, float);
-template hipError_t launch_integrate<double>(hipStream_t, void*, void*, const void*, int64_t, double);
+template hipError_t launch_integrate<float>(hipStream_t, void*, void*, const void*, int64_t, float, Gate);
+template hipError_t launch_integrate<double>(hipStream_t, void*, void*, const void*, int64_t, double, Gate);
 
 }  // namespace nbody

@@ -31,4 +31,13 @@ template <class T>
 hipError_t launch_tree_walk_tile(hipStream_t s, const WalkArgs<T>& a, char* scratch, const WalkSplitLayout& L, const uint32_t* tgt_ids,
                                  uint32_t* hist, int estimate, int shift);
 
+// The same in two halves (preparation: estimate scan, wrap check, budget — info[0..3] final; then the walk kernel), for
+// a caller that enqueues a copy of info and an event in between.
+template <class T>
+hipError_t launch_tree_walk_tile_prep(hipStream_t s, const WalkArgs<T>& a, char* scratch, const WalkSplitLayout& L, const uint32_t* tgt_ids,
+                                      uint32_t* hist, int estimate, int shift, int64_t* grid_waves);
+template <class T>
+hipError_t launch_tree_walk_tile_main(hipStream_t s, const WalkArgs<T>& a, char* scratch, const WalkSplitLayout& L, const uint32_t* tgt_ids,
+                                      uint32_t* hist, int64_t grid_waves);
+
 }  // namespace nbody

@@ -387,7 +387,7 @@ __global__ __launch_bounds__(256) void walk_tile(const WalkArgs<T> a, const uint
   const T2* __restrict__ lpos = reinterpret_cast<const T2*>(a.leaf_pos);
   const T* __restrict__ lmass = a.leaf_mass;
   const T theta = a.theta, clamp = a.clamp;
-  const int n_nodes = a.n_nodes;
+  const int n_nodes = a.n_nodes_dev ? __builtin_amdgcn_readfirstlane(*a.n_nodes_dev) : a.n_nodes;
   int resume = live ? 0 : n_nodes;
   uint32_t n_terms = 0;
   T ax = 0, ay = 0;  // Vec2::zero(), main.rs:409
@@ -591,10 +591,14 @@ hipError_t launch_tree_walk_split(hipStream_t s, const WalkArgs<float>& a, char*
 }
 
 
+// The walk's preparation (the estimate's scan, its wrap check, the waves' budget: info[0..3] are final afterwards) and
+// the walk proper, separately: a caller that wants to see info[1] before the long kernel has run enqueues a copy and an
+// event between the two.  *grid_waves carries the wave count from the one to the other.
 template <class T>
-hipError_t launch_tree_walk_tile(hipStream_t s, const WalkArgs<T>& a, char* scratch, const WalkSplitLayout& L, const uint32_t* tgt_ids,
-                                 uint32_t* hist, int estimate, int shift) {
+hipError_t launch_tree_walk_tile_prep(hipStream_t s, const WalkArgs<T>& a, char* scratch, const WalkSplitLayout& L, const uint32_t* tgt_ids,
+                                      uint32_t* hist, int estimate, int shift, int64_t* grid_waves) {
   const bool have_history = estimate != 0;  // 1: from hist; 2: none at all (every wave takes 64 targets)
+  *grid_waves = 0;
   if (a.n_tgt <= 0) return hipSuccess;
   uint32_t* cnt = (uint32_t*)(scratch + L.cnt);
   uint32_t* off = (uint32_t*)(scratch + L.off);
@@ -630,9 +634,19 @@ hipError_t launch_tree_walk_tile(hipStream_t s, const WalkArgs<T>& a, char* scra
   const int64_t twaves = extra + a.n_tgt / 64 + 4;  // upper bound of g(t) + 1 (budget >= ceil(total / extra))
   walk_tile_total<<<dim3(1), dim3(1), 0, s>>>(have_history ? nullptr : cnt, off, a.n_tgt, tgt_ids, estimate == 1 ? hist : nullptr, shift, extra,
                                               twaves, info);
+  *grid_waves = twaves;
+  return hipGetLastError();
+}
+
+template <class T>
+hipError_t launch_tree_walk_tile_main(hipStream_t s, const WalkArgs<T>& a, char* scratch, const WalkSplitLayout& L, const uint32_t* tgt_ids,
+                                      uint32_t* hist, int64_t grid_waves) {
+  if (a.n_tgt <= 0 || grid_waves <= 0) return hipSuccess;
+  const uint32_t* off = (const uint32_t*)(scratch + L.off);
+  int* info = (int*)(scratch + L.info);
   unsigned long long* total_out = (unsigned long long*)(info + 6);
   const int tt = sizeof(T) == 8 ? tile_targets_f64() : tile_targets();
-  const dim3 grid((unsigned)((twaves + 3) / 4));
+  const dim3 grid((unsigned)((grid_waves + 3) / 4));
 #define NB_TILE(F, R) walk_tile<T, F, R><<<grid, dim3(256), 0, s>>>(a, off, info, tgt_ids, hist, total_out)
   if (a.fast) { if (tt == 16) NB_TILE(true, 16); else if (tt == 4) NB_TILE(true, 4); else NB_TILE(true, 8); }
   else { if (tt == 16) NB_TILE(false, 16); else if (tt == 4) NB_TILE(false, 4); else NB_TILE(false, 8); }
@@ -640,7 +654,20 @@ hipError_t launch_tree_walk_tile(hipStream_t s, const WalkArgs<T>& a, char* scra
   return hipGetLastError();
 }
 
+template <class T>
+hipError_t launch_tree_walk_tile(hipStream_t s, const WalkArgs<T>& a, char* scratch, const WalkSplitLayout& L, const uint32_t* tgt_ids,
+                                 uint32_t* hist, int estimate, int shift) {
+  int64_t waves = 0;
+  hipError_t e = launch_tree_walk_tile_prep<T>(s, a, scratch, L, tgt_ids, hist, estimate, shift, &waves);
+  if (e != hipSuccess) return e;
+  return launch_tree_walk_tile_main<T>(s, a, scratch, L, tgt_ids, hist, waves);
+}
+
 template hipError_t launch_tree_walk_tile<float>(hipStream_t, const WalkArgs<float>&, char*, const WalkSplitLayout&, const uint32_t*, uint32_t*, int, int);
 template hipError_t launch_tree_walk_tile<double>(hipStream_t, const WalkArgs<double>&, char*, const WalkSplitLayout&, const uint32_t*, uint32_t*, int, int);
+template hipError_t launch_tree_walk_tile_prep<float>(hipStream_t, const WalkArgs<float>&, char*, const WalkSplitLayout&, const uint32_t*, uint32_t*, int, int, int64_t*);
+template hipError_t launch_tree_walk_tile_prep<double>(hipStream_t, const WalkArgs<double>&, char*, const WalkSplitLayout&, const uint32_t*, uint32_t*, int, int, int64_t*);
+template hipError_t launch_tree_walk_tile_main<float>(hipStream_t, const WalkArgs<float>&, char*, const WalkSplitLayout&, const uint32_t*, uint32_t*, int64_t);
+template hipError_t launch_tree_walk_tile_main<double>(hipStream_t, const WalkArgs<double>&, char*, const WalkSplitLayout&, const uint32_t*, uint32_t*, int64_t);
 
 }  // namespace nbody

@@ -557,3 +557,61 @@ def test_one_pass_walk_notices_a_history_whose_scan_wraps(nb, monkeypatch, capfd
         assert "estimate from the last walk" in err
     for a, b in zip(*res):
         assert np.array_equal(a, b)
+
+
+# ------------------------------------------------------------------ the BVH step enqueued ahead of the host (one wait per step)
+@pytest.mark.parametrize("order_name", ["as_written", "consistent"])
+def test_step_ahead_equals_the_plain_sequence(nb, orc, monkeypatch, capfd, order_name):
+    """From the second step of a call on, a BVH step is enqueued whole — build, device-side verdict, gather, walk reading
+    the node count from device memory, gated integration — with one host wait at its end (capi.hip, bvh_step_ahead).
+    Same kernels on the same data: bit-identical to the phase-by-phase sequence and to the oracle."""
+    C = nb._capi
+    order = C.ORDER_AS_WRITTEN if order_name == "as_written" else C.ORDER_CONSISTENT
+    pos, vel, w = nb.scenes.galaxy()
+    pos, vel, w = pos[::2].copy(), vel[::2].copy(), w[::2].copy()
+    res = {}
+    for ahead in ("1", "0"):
+        monkeypatch.setenv("NBODY_STEP_AHEAD", ahead)
+        monkeypatch.setenv("NBODY_TRACE", "1")
+        with C.Context(0) as c:
+            c.set_params(order=order)
+            c.upload(pos, vel, w)
+            cnt = C.Counting()
+            c.update_tree(C.TREE_BVH, 0.1, 6, cnt)
+            c.update_tree(C.TREE_BVH, 0.1, 1, cnt)                  # a later call starts ahead at once (the history is there)
+            res[ahead] = c.download()
+            assert cnt.build_bvh > 0 and cnt.sum_gravity > 0 and cnt.post_calculations > 0
+            assert c.last_build_on_device() and c.tree_info().n_nodes > 0
+            t = c.tree_export()                                    # the tree of the last (ahead) step is exportable
+            assert t["order"].shape[0] == pos.shape[0]
+        err = capfd.readouterr().err
+        assert (err.count("step ahead: build verdict 1") == 6) == (ahead == "1"), err[-800:]
+    assert all(np.array_equal(a, b) for a, b in zip(res["1"], res["0"]))
+    mode = orc.AS_WRITTEN if order_name == "as_written" else orc.CONSISTENT
+    rp, rv, _, rids, _ = orc.update_bvh(pos, vel, w, delta=0.1, theta=50.0, mode=mode, nsteps=7, nthreads=16)
+    assert np.array_equal(res["1"][3], rids) and np.array_equal(res["1"][0], rp) and np.array_equal(res["1"][1], rv)
+
+
+@pytest.mark.parametrize("hook", ["NBODY_BVH_BLIND_LEVELS", "NBODY_WALK_TILE_POISON"])
+def test_step_ahead_recovers_when_its_speculation_fails(nb, monkeypatch, capfd, hook):
+    """Too few blind build levels (the device verdict says 'long nodes left') and a history whose scan wraps (the walk
+    flags itself) both leave the step's input rows untouched — the gather writes the other set, the integration is
+    gated — and the plain sequence does the step again.  Same trajectory as without the hooks."""
+    C = nb._capi
+    pos, vel, w = nb.scenes.galaxy()
+    pos, vel, w = pos[::2].copy(), vel[::2].copy(), w[::2].copy()
+    res = []
+    for on in (False, True):
+        if on:
+            monkeypatch.setenv(hook, "1")
+        monkeypatch.setenv("NBODY_TRACE", "1")
+        with C.Context(0) as c:
+            c.upload(pos, vel, w)
+            c.update_tree(C.TREE_BVH, 0.1, 5)
+            res.append(c.download())
+        err = capfd.readouterr().err
+        if on and hook == "NBODY_BVH_BLIND_LEVELS":
+            assert "step ahead: build verdict 0" in err and "step ahead: build verdict 1" not in err
+        if on and hook == "NBODY_WALK_TILE_POISON":
+            assert "overflow 1" in err and "estimate none" in err
+    assert all(np.array_equal(a, b) for a, b in zip(*res))
