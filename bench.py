@@ -6,11 +6,16 @@ N = 1 048 576 bodies (BASELINE.json configs[2]) on 1/2/4/8 MI355X.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus 8 --steps 5 --warmup 1
 
-One process per GPU.  The N bodies are fixed (strong scaling): rank r owns targets [r*N/G, (r+1)*N/G), keeps a
-replicated copy of all positions, runs nbody_direct_step_dev on its shard and all-gathers the new positions
-(RCCL over xGMI) once per step.  A step = force on every body from every body + semi-implicit Euler
-(reference: World::update, src/main.rs:388-425, with the direct sum of SURVEY a9 as the force phase).
-Prints ONE JSON line on rank 0.
+One process per GPU.  The N bodies are fixed (strong scaling): rank r owns the target blocks {c*G + r} (sharding.py),
+keeps a replicated copy of all positions, runs nbody_direct_prep_dev / nbody_direct_run_dev on its blocks and
+all-gathers the new positions in place (RCCL over xGMI) once per chunk.  A step = force on every body from every
+body + semi-implicit Euler (reference: World::update, src/main.rs:388-425, with the direct sum of SURVEY a9 as the
+force phase).  Prints ONE JSON line on rank 0.
+
+At N = 1 the line also carries `cpu_baseline` (the oracle on the host cores, a bounded sample) and `legs`: the other
+single-GPU configurations of BASELINE.json, each with its own roofline — config 2 (65 536 direct), per-body masses and
+the reference's own scene (direct), config 4 (4 194 304 bodies, quad tree, theta 0.5, f64; the reference's arithmetic and
+the opt-in FAST one).  `--leg NAME` runs one leg alone (what the rocprofv3 passes under profiles/ were taken on).
 """
 import argparse
 import json
@@ -25,10 +30,46 @@ sys.path.insert(0, ROOT)
 
 N_BODIES = 1 << 20          # BASELINE.json configs[2]
 FLOPS_PER_PAIR = 14         # SURVEY §8d / DESIGN.md: algorithmic flops of one force-law evaluation
+# what the timed instantiation (equal masses, far sources: direct_fast<1,true,true,true>) executes per pair:
+# v_pk_add 2, v_mul 1, v_fmac 2, v_add 1, v_fmaak 2 (the 2^-90 bias rides in its addend), v_rcp 1, v_pk_fma 4 = 13; against the
+# 14 algorithmic ones the mass multiply is hoisted out of the sum and the clamp is dropped for far sources (-2), the
+# bias add is extra (+1)
+FLOPS_EXECUTED_PER_PAIR = 13
 PEAK_F32_TFLOPS = 157.3     # MI355X_MICROARCH.md: peak FP32 vector (= FP32 matrix) rate
+PEAK_F64_TFLOPS = 78.6      # FP64 vector: half the FP32 vector rate (256 CU x 2.4 GHz x 128 flop/clk/CU; AMD's MI355X figure)
 DT = 0.1                    # STEP_SIZE, main.rs:34
 CLAMP = 0.001               # main.rs:247-248
 SEED = 0x5EED0003
+PAIR_FLOPS_AS_WRITTEN = 14  # main.rs:236-252 in GPU-minimal counting, a division as one flop
+NODE_TEST_FLOPS = 12        # contains (4 compares) + dist2 (2 sub, 2 mul, 1 add) + d2*theta*theta (2 mul) + 1 compare
+
+
+def _profile(name):
+    """A committed rocprofv3 summary under profiles/ (HBM bytes per launch from PMC counters), or None."""
+    path = os.path.join(ROOT, "profiles", name)
+    try:
+        with open(path) as f:
+            return json.load(f), "profiles/" + name
+    except Exception:
+        return None, None
+
+
+def _traffic(roof, profile_name, algorithmic_bytes):
+    """roofline.traffic is not measurable from inside this process (PMC counters need rocprofv3): it is read from the
+    committed summary of the same command and says so."""
+    prof, src = _profile(profile_name)
+    roof["algorithmic_bytes_per_launch"] = algorithmic_bytes
+    if prof and prof.get("hbm_bytes_per_launch") is not None:
+        roof["traffic"] = prof["hbm_bytes_per_launch"]
+        roof["traffic_source"] = src + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, per launch; not measured in this run)"
+        if algorithmic_bytes:
+            roof["traffic_over_algorithmic"] = prof["hbm_bytes_per_launch"] / algorithmic_bytes
+        if prof.get("traffic_note"):
+            roof["traffic_note"] = prof["traffic_note"]
+    else:
+        roof["traffic"] = None
+        roof["traffic_source"] = None
+    return roof
 
 
 def cpu_baseline(pos, w, n_sample_targets):
@@ -65,6 +106,113 @@ def cpu_baseline(pos, w, n_sample_targets):
             "ms_per_step_extrapolated": 1e3 * float(n) * n / (pairs / dt)}
 
 
+# ---------------------------------------------------------------------------------------------------- legs
+def _direct_leg(nb, name, workload, pos, vel, w, steps, profile_name, executed=None):
+    """A direct-sum leg through the context path (nbody_update_direct_f32), timed like the headline."""
+    C = nb._capi
+    n = pos.shape[0]
+    timer = C.Timer()
+    with C.Context(0) as ctx:
+        ctx.upload(pos, vel, w)
+        ctx.set_timer(timer)                   # (with a timer attached small steps are not graph-replayed: eager launches)
+        ctx.update_direct(DT, 1)
+        timer.read(reset=True)
+        t0 = time.perf_counter()
+        ctx.update_direct(DT, steps)
+        dt = time.perf_counter() - t0
+        kms, kl = timer.read(reset=True)
+        ctx.set_timer(None)
+    pairs = float(n) * n
+    ach = FLOPS_PER_PAIR * pairs / (kms * 1e-3) / 1e12 if kms > 0 else 0.0
+    roof = {"bound": "valu_f32", "bound_class": "compute", "kernel": "nbody::direct_fast", "achieved": ach, "peak": PEAK_F32_TFLOPS,
+            "unit": "TFLOP/s", "frac": ach / PEAK_F32_TFLOPS, "flops_per_pair": FLOPS_PER_PAIR, "pairs_per_launch": pairs,
+            "kernel_ms": kms, "launches_timed": kl}
+    if executed:
+        roof["flops_executed_per_pair"] = executed
+        roof["frac_executed"] = roof["frac"] * executed / FLOPS_PER_PAIR
+    _traffic(roof, profile_name, 36 * n)
+    return {"leg": name, "workload": workload, "metric": "pair-interactions/s", "value": pairs * steps / dt, "ms_per_step": 1e3 * dt / steps,
+            "steps": steps, "dtype": "f32", "roofline": roof}
+
+
+def _tree_leg(nb, name, workload, pos, vel, w, kind, theta, steps, profile_name):
+    """A Barnes-Hut leg: the step with the reference's arithmetic (bit-identical to the oracle) and with the opt-in FAST
+    pair function; roofline of the walk kernel priced in flops (it is VALU-bound: two IEEE divisions per pair)."""
+    C = nb._capi
+    f64 = pos.dtype == np.float64
+    n = pos.shape[0]
+    out = {"leg": name, "workload": workload, "dtype": "f64" if f64 else "f32", "steps": steps}
+    with C.Context(0) as ctx:
+        ctx.set_params(theta=theta, order=C.ORDER_CONSISTENT)
+        ctx.upload(pos, vel, w)
+        ctx.walk_stats(True)                   # one untimed walk with the counters on (3 atomics per target)
+        ctx.accel_tree(kind)
+        visits, accepted, leaf_pairs = ctx.walk_stats(False)
+        ctx.upload(pos, vel, w)
+        for label, arith in (("exact", C.ARITH_AUTO), ("fast", C.ARITH_FAST)):
+            ctx.set_params(arith=arith)
+            ctx.upload(pos, vel, w)
+            timer = C.Timer()
+            ctx.update_tree(kind, DT, 1)
+            ctx.set_timer(timer)
+            cnt = C.Counting()
+            t0 = time.perf_counter()
+            ctx.update_tree(kind, DT, steps, cnt)
+            dt = time.perf_counter() - t0
+            kms, kl = timer.read(reset=True)
+            ctx.set_timer(None)
+            flops = PAIR_FLOPS_AS_WRITTEN * float(leaf_pairs + accepted) + NODE_TEST_FLOPS * float(visits)
+            ach = flops / (kms * 1e-3) / 1e12 if kms > 0 else 0.0
+            peak = PEAK_F64_TFLOPS if f64 else PEAK_F32_TFLOPS
+            roof = {"bound": "valu_f64" if f64 else "valu_f32", "bound_class": "compute",
+                    "kernel": "nbody::tree_walk_small" if kind == C.TREE_QUAD else "nbody::walk_tile", "achieved": ach, "peak": peak,
+                    "unit": "TFLOP/s", "frac": ach / peak, "kernel_ms": kms, "launches_timed": kl,
+                    "pair_evaluations_per_launch": float(leaf_pairs + accepted), "node_tests_per_launch": float(visits),
+                    "flops_per_pair": PAIR_FLOPS_AS_WRITTEN, "flops_per_node_test": NODE_TEST_FLOPS,
+                    "note": "a division counts as one flop; the as-written pair function does two correctly rounded divisions "
+                            "(~30 VALU instructions each in f64), which is what holds the fraction down"}
+            # node records and leaf particles reach a wave by scalar loads, shared by its 64 targets: per-target counts / 64 is
+            # the lower bound (every lane on the same path); plus the targets read and the accelerations written
+            node_b, pair_b = (144, 24) if f64 else (80, 12)
+            _traffic(roof, profile_name, int(visits * node_b / 64 + leaf_pairs * pair_b / 64 + n * (32 if f64 else 16)))
+            roof["algorithmic_bytes_note"] = "lower bound: wave-uniform scalar loads, per-target node and leaf bytes divided by 64"
+            out[label] = {"ms_per_step": 1e3 * dt / steps, "bodies_per_s": n * steps / dt, "build_ms": 1e3 * cnt.build_bvh / steps,
+                          "walk_phase_ms": 1e3 * cnt.sum_gravity / steps, "integrate_ms": 1e3 * cnt.post_calculations / steps,
+                          "interactions_per_s": (leaf_pairs + accepted) / (kms * 1e-3) if kms > 0 else None, "roofline": roof,
+                          "parity": "bit-identical to the oracle" if label == "exact" else "tolerance of the direct kernel (2e-5)"}
+    out["metric"] = "ms/step"
+    out["value"] = out["exact"]["ms_per_step"]
+    out["default_arithmetic"] = "exact (the reference's operations; FAST is opt-in, NBODY_ARITH_FAST)"
+    out["walk"] = {"node_visits_per_target": visits / n, "accepted_per_target": accepted / n, "leaf_pairs_per_target": leaf_pairs / n}
+    return out
+
+
+LEGS = ("config2", "per_body_masses", "reference_scene_direct", "config4")
+
+
+def run_leg(nb, name):
+    C = nb._capi
+    if name == "config2":
+        pos, vel, w = nb.scenes.plummer(65536, seed=0x5EED0002)
+        return _direct_leg(nb, name, "BASELINE.json configs[1]: 65 536 bodies direct O(N^2) f32, Plummer, masses 1", pos, vel, w, 200,
+                           "r02_leg_config2_pmc.json", executed=14)   # below 2^33 pairs the clamped single pass runs (direct_fast<1,true,false,true>)
+    if name == "per_body_masses":
+        pos, vel, _ = nb.scenes.plummer(N_BODIES, seed=SEED)
+        w = (np.arange(N_BODIES) % 5 + 1).astype(np.uint32)
+        return _direct_leg(nb, name, "1 048 576 bodies direct f32, Plummer, per-body masses 1..5 (direct_fast<1,false,true,true>)", pos, vel, w, 3,
+                           "r02_leg_per_body_masses_pmc.json", executed=14)
+    if name == "reference_scene_direct":
+        pos, vel, w = nb.scenes.galaxy()
+        return _direct_leg(nb, name, f"the reference's own scene (World::new, main.rs:276-346, seeded): {pos.shape[0]} bodies, masses 1 but for "
+                                     "75 000 000 and 750 000 — the two ride with the near list, the main pass runs at the equal-mass rate",
+                           pos, vel, w, 50, "r02_leg_reference_scene_direct_pmc.json", executed=FLOPS_EXECUTED_PER_PAIR)
+    if name == "config4":
+        pos, vel, w = nb.scenes.plummer(1 << 22, seed=0x5EED0004, dtype=np.float64)
+        return _tree_leg(nb, name, "BASELINE.json configs[3]: 4 194 304 bodies Barnes-Hut theta 0.5, linearised quad tree, f64", pos, vel, w,
+                         C.TREE_QUAD, 0.5, 5, "r02_leg_config4_pmc.json")
+    raise SystemExit(f"bench.py: unknown leg {name!r} (one of {LEGS})")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -72,6 +220,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--bodies", dest="n", type=int, default=N_BODIES, help="total bodies (default: the BASELINE config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-legs", action="store_true", help="skip the non-headline single-GPU configurations")
+    ap.add_argument("--leg", default=None, help=f"run ONE leg alone and print it (for profiling): {', '.join(LEGS)}")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
                                                       "several ranks on one GPU)")
     ap.add_argument("--cpu-sample-targets", type=int, default=131072)
@@ -93,6 +243,9 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; the HIP path has no CPU fallback", file=sys.stderr)
         sys.exit(3)
+    if args.leg:
+        print(json.dumps(run_leg(nb, args.leg)), flush=True)
+        return
     dev_index = local_rank % torch.cuda.device_count()   # one rank per GPU; the modulo only matters in a rehearsal
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
@@ -136,16 +289,22 @@ def main():
         pairs_per_step = float(n) * float(n)
         value = pairs_per_step * args.steps / elapsed
         n_tgt = stepper.n_local
-        flops_per_launch = FLOPS_PER_PAIR * float(n) * float(n_tgt)
+        n_launch = max(1, kern_launches // max(1, args.steps))      # launches of the dominant kernel per step (= chunks)
+        flops_per_launch = FLOPS_PER_PAIR * float(n) * float(n_tgt) / n_launch
         achieved = flops_per_launch / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
-        traffic = None
-        prof = os.path.join(ROOT, "profiles", "r01_direct_pmc.json")
-        if os.path.exists(prof) and world == 1 and n == N_BODIES:
-            try:
-                with open(prof) as f:
-                    traffic = json.load(f).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        roof = {"bound": "valu_f32", "bound_class": "compute", "kernel": "nbody::direct_fast<1,true,true,true>", "achieved": achieved,
+                "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_TFLOPS,
+                "flops_per_pair": FLOPS_PER_PAIR, "flops_executed_per_pair": FLOPS_EXECUTED_PER_PAIR,
+                "frac_executed": achieved / PEAK_F32_TFLOPS * FLOPS_EXECUTED_PER_PAIR / FLOPS_PER_PAIR,
+                "frac_note": "frac prices the 14 ALGORITHMIC flops of a pair; the timed instantiation executes 13 (mass multiply hoisted "
+                             "for equal masses, clamp dropped for far sources, one bias add extra): frac_executed = frac * 13/14",
+                "pairs_per_launch": float(n) * n_tgt / n_launch, "kernel_ms": kern_ms, "launches_timed": kern_launches,
+                "note": "no MFMA on this path (no dense contraction); peak = f32 vector peak"}
+        if world == 1 and n == N_BODIES:
+            _traffic(roof, "r02_direct_pmc.json", 36 * n)
+        else:
+            roof["traffic"] = None
+            roof["traffic_source"] = None
         out = {
             "metric": "pair-interactions/sec + ms/step at N=1M direct O(N^2) (force + integration step)",
             "value": value, "unit": "pair-interactions/s", "n_gpus": world, "steps": args.steps,
@@ -157,14 +316,20 @@ def main():
                        "exchange": "none" if world == 1 else f"{args.backend} in-place all-gather of float2 positions per chunk"
                                    + (" (RCCL over xGMI)" if args.backend == "nccl" else " (rehearsal)"),
                        "arith": "AUTO (FAST kernel; EXACT on hazardous positions)"},
-            "roofline": {"bound": "valu_f32", "bound_class": "compute", "kernel": "nbody::direct_fast", "achieved": achieved,
-                         "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_TFLOPS,
-                         "traffic": traffic, "flops_per_pair": FLOPS_PER_PAIR, "pairs_per_launch": float(n) * n_tgt,
-                         "kernel_ms": kern_ms, "launches_timed": kern_launches,
-                         "note": "no MFMA on this path (no dense contraction); peak = f32 vector peak"},
+            "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pos, w, args.cpu_sample_targets)
+        if world == 1 and not args.no_legs and n == N_BODIES:
+            del stepper
+            torch.cuda.empty_cache()
+            legs = []
+            for name in LEGS:
+                try:
+                    legs.append(run_leg(nb, name))
+                except Exception as e:  # a leg must not cost the headline line
+                    legs.append({"leg": name, "error": repr(e)})
+            out["legs"] = legs
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -1,0 +1,18 @@
+#!/bin/bash
+# rocprofv3 passes of bench.py's headline and legs (run on the GPU box from the repo root):
+#   tools/profile_legs.sh <leg: headline|config2|per_body_masses|reference_scene_direct|config4> <kernel regex> <out json>
+# writes gpurun_out/prof_r02/<leg>/{stats,pmc1,pmc2,pmc3} and the summary json; the --stats csv is copied beside it.
+set -o pipefail
+leg=$1; rx=$2; out=$3
+root=$PWD
+d=$root/gpurun_out/prof_r02/$leg
+mkdir -p $d
+cd /tmp && export TMPDIR=/tmp && cd $root
+if [ "$leg" = headline ]; then cmd="bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-legs"; else cmd="bench.py --leg $leg"; fi
+rocprofv3 --kernel-trace --stats --output-format csv -d $d/stats -o p -- python3 $cmd > $d/stats.log 2>&1 || { tail -5 $d/stats.log; exit 1; }
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $d/pmc1 -o p -- python3 $cmd > $d/pmc1.log 2>&1 || { tail -5 $d/pmc1.log; exit 1; }
+rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $d/pmc2 -o p -- python3 $cmd > $d/pmc2.log 2>&1 || { tail -5 $d/pmc2.log; exit 1; }
+rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_INSTS_SMEM --kernel-trace --output-format csv -d $d/pmc3 -o p -- python3 $cmd > $d/pmc3.log 2>&1 || { tail -5 $d/pmc3.log; exit 1; }
+python3 tools/pmc_summary.py $d "$rx" $out "$leg: python3 $cmd"
+cp $(find $d/stats -name "*kernel_stats.csv" | head -1) ${out%_pmc.json}_kernel_stats.csv
+grep '^{' $d/stats.log | tail -1 > ${out%_pmc.json}_bench.json
