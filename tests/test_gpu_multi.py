@@ -235,3 +235,31 @@ def test_rccl_between_distinct_devices(nb):
             ctx.update_direct(0.1, 1)
         ref = s.download()
         assert _same_rows(ref, m.download()) and _same_rows(ref, mp_.download())
+
+
+def test_config5_as_stated_rehearsed_on_one_gpu(nb, orc):
+    """BASELINE config 5 AS STATED — 16 777 216 bodies, direct O(N^2) f32, sharded over 8 ranks, positions exchanged every
+    step — with the 8 ranks on the one GPU of the test box (peer-copy exchange; the RCCL exchange needs 8 physical devices
+    and runs in the driver's scaling bench).  One whole step: 2.8e14 pair interactions, 8 x 8 blocks of 262 144 targets
+    (the chunk count the size picks by itself), every block's new positions copied to the 7 other replicas, then the lazy
+    velocity gather of the download.  Checked on 4 096 sampled targets against the oracle (frozen tolerance), the
+    integration bit for bit given the new velocities, and ids untouched."""
+    C = nb._capi
+    n = 1 << 24
+    pos, vel, w = nb.scenes.plummer(n, seed=0x5EED0005)
+    vel = np.zeros_like(vel)                       # from rest: v1 = fl(a * dt), so the step exposes the accelerations
+    with _multi(nb, [0] * 8, pos, vel, w, C.EXCHANGE_PEER) as m:
+        assert m.multi_info() == (8, C.EXCHANGE_PEER, 8, 262144)
+        cnt = C.Counting()
+        m.update_direct(0.1, 1, cnt)
+        p, v, w2, ids = m.download()
+    print(f"[config 5 on one GPU] one step of 16.7M bodies on 8 ranks sharing the device: {cnt.sum_gravity:.1f} s")
+    assert np.array_equal(ids, np.arange(n, dtype=np.uint32)) and np.array_equal(w2, w)
+    assert np.array_equal(p, (pos + v * F32(0.1)).astype(F32))
+    tg = np.arange(1234, n, 4096)                  # 4 096 targets spread over every rank's blocks
+    ref64, norm = orc.direct_accel(pos, w, targets=tg, accum="f64", nthreads=16)
+    err = np.abs(v[tg].astype(np.float64) / 0.1 - ref64).sum(axis=1)
+    slack = 4 * np.finfo(F32).eps * np.abs(ref64).sum(axis=1)
+    rel = (err - slack) / norm
+    print(f"[config 5 on one GPU] e_gpu on {len(tg)} sampled targets: median {np.median(err / norm):.2e} max {(err / norm).max():.2e}")
+    assert np.all(rel <= ACC_RTOL), float(rel.max())
