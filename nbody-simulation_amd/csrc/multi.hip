@@ -258,16 +258,19 @@ struct Multi {
     return NBODY_OK;
   }
   // After device d enqueued its last piece: `stream` (on device d) continues once everything it is owed has landed.
+  // Every rank passes through the same barriers whatever happens to it (a rank that left early would strand the others),
+  // and all of them return the same verdict.
   int gather_finish(int d, hipStream_t stream) {
-    MHIP(d, hipEventRecord(ev_done[(size_t)d], comm_stream[(size_t)d]));
+    hipError_t e = hipEventRecord(ev_done[(size_t)d], comm_stream[(size_t)d]);
     if (exchange == NBODY_EXCHANGE_RCCL) {  // the collective on my stream completes when my receive buffer is whole
-      MHIP(d, hipStreamWaitEvent(stream, ev_done[(size_t)d], 0));
-      return NBODY_OK;
+      if (e == hipSuccess) e = hipStreamWaitEvent(stream, ev_done[(size_t)d], 0);
+      return e == hipSuccess ? NBODY_OK : hip_fail(d, e, "gather_finish");
     }
-    barrier.arrive(true);  // every device has recorded its event
-    for (int p = 0; p < G; ++p) MHIP(d, hipStreamWaitEvent(stream, ev_done[(size_t)p], 0));
-    barrier.arrive(true);  // nobody re-records an event a peer has yet to wait on
-    return NBODY_OK;
+    bool all = barrier.arrive(e == hipSuccess);  // every device has recorded its event
+    for (int p = 0; p < G && all && e == hipSuccess; ++p) e = hipStreamWaitEvent(stream, ev_done[(size_t)p], 0);
+    all = barrier.arrive(e == hipSuccess) && all;  // nobody re-records an event a peer has yet to wait on
+    if (e != hipSuccess) return hip_fail(d, e, "gather_finish");
+    return all ? NBODY_OK : NBODY_ERR_HIP;
   }
 };
 

@@ -90,7 +90,7 @@ class ShardedDirectStepper:
         self.vel = padded(vel, cap)                                # only this rank's blocks are kept up to date
         n_max = max([cnt for _, cnt in self.blocks] + [0])
         self.backend = backend if backend is not None else HipBackend(device, n, self.n_local, n_max, clamp, arith, timer, uniform)
-        self._staged = None
+        self._inplace = True
 
     def _gather_chunk(self, c):
         """In-place all-gather of chunk c of pos_next (rank r's piece = block c*world + r).  Returns a work handle or None."""
@@ -111,7 +111,12 @@ class ShardedDirectStepper:
         # RCCL: sendbuff = recvbuff + rank * count is NCCL's in-place all-gather.  async_op: the collective runs on the
         # process group's own stream, ordered after what the current stream holds now (this chunk's kernels); the next
         # chunk's kernels, enqueued next on the current stream, overlap it.
-        return dist.all_gather_into_tensor(region.view(-1), mine.view(-1), group=self.group, async_op=True)
+        if self._inplace:
+            try:
+                return dist.all_gather_into_tensor(region.view(-1), mine.view(-1), group=self.group, async_op=True)
+            except (RuntimeError, ValueError):   # a torch build that refuses aliased buffers: send from a copy instead
+                self._inplace = False
+        return dist.all_gather_into_tensor(region.view(-1), mine.clone().view(-1), group=self.group, async_op=True)
 
     def step(self, dt):
         """One World::update: force + integrate for this rank's blocks, each chunk's exchange behind its kernels."""
@@ -176,6 +181,7 @@ class ShardedTreeStepper:
         self.sec = self.off_vel + a256(rows * es)                  # one rank's section: rows u32 | positions | velocities
         self.buf = torch.zeros(self.sec * world, dtype=torch.uint8, device=dev)
         self.stream = torch.cuda.ExternalStream(self.ctx.stream, device=dev)
+        self._inplace = True
 
     def _count(self, r):
         return max(0, min(self.slice, self.n - r * self.slice))
@@ -196,7 +202,13 @@ class ShardedTreeStepper:
                 dist.all_gather_into_tensor(host, section.cpu(), group=self.group)
                 self.buf.copy_(host)
             else:                                                  # in place: sendbuff = recvbuff + rank * count
-                dist.all_gather_into_tensor(self.buf, section, group=self.group)
+                try:
+                    dist.all_gather_into_tensor(self.buf, section if self._inplace else section.clone(), group=self.group)
+                except (RuntimeError, ValueError):                 # a torch build that refuses aliased buffers
+                    if not self._inplace:
+                        raise
+                    self._inplace = False
+                    dist.all_gather_into_tensor(self.buf, section.clone(), group=self.group)
         for r in range(self.world):
             cnt = self._count(r)
             if r == self.rank or cnt == 0:
