@@ -156,7 +156,7 @@ __device__ __forceinline__ void exact_pair(float xi, float yi, float xj, float y
   float sum = __builtin_fabsf(dx) + __builtin_fabsf(dy);  // :238
   if (!__builtin_isnormal(sum)) return;                   // :241-243
   float distance = dx * dx + dy * dy;                     // :245
-  if (distance < clamp) distance = clamp;                 // :247-249
+  distance = __builtin_fmaxf(distance, clamp);            // :247-249 (one v_max_f32; `distance` is never NaN after the is_normal test)
   float den = sum * distance;
   ax = ax + (dx * mj) / den;                              // :252
   ay = ay + (dy * mj) / den;

@@ -32,7 +32,9 @@ __device__ __forceinline__ void pair_as_written(T px, T py, T qx, T qy, T force,
   T sum = __builtin_fabs(dx) + __builtin_fabs(dy);       // :238
   if (!is_normal_t(sum)) return;                         // :241-243
   T distance = dx * dx + dy * dy;                        // :245
-  if (distance < clamp) distance = clamp;                // :247-249
+  // :247-249 as one max (half the cost of compare + select): `distance` is never NaN here (a normal `sum` means finite
+  // dx, dy), and for a NaN clamp both forms keep `distance`
+  distance = __builtin_fmax(distance, clamp);
   T den = sum * distance;
   ax = ax + (dx * force) / den;                          // :252
   ay = ay + (dy * force) / den;
@@ -45,7 +47,7 @@ __device__ __forceinline__ void pair_as_written<float>(float px, float py, float
   float sum = __builtin_fabsf(dx) + __builtin_fabsf(dy);
   if (!__builtin_isnormal(sum)) return;
   float distance = dx * dx + dy * dy;
-  if (distance < clamp) distance = clamp;
+  distance = __builtin_fmaxf(distance, clamp);
   float den = sum * distance;
   ax = ax + (dx * force) / den;
   ay = ay + (dy * force) / den;
@@ -268,7 +270,7 @@ template <class T> __device__ __forceinline__ typename V2<T>::type pair_term_t(T
   const T sum = __builtin_fabs(dx) + __builtin_fabs(dy);
   if (!is_normal_t(sum)) return T2{(T)-0.0, (T)-0.0};
   T distance = dx * dx + dy * dy;
-  if (distance < clamp) distance = clamp;
+  distance = sizeof(T) == 8 ? (T)__builtin_fmax((double)distance, (double)clamp) : (T)__builtin_fmaxf((float)distance, (float)clamp);
   const T den = sum * distance;
   return T2{(dx * force) / den, (dy * force) / den};
 }

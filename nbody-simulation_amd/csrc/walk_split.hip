@@ -48,9 +48,23 @@ __device__ __forceinline__ float2 pair_term(float px, float py, float qx, float 
   const float sum = __builtin_fabsf(dx) + __builtin_fabsf(dy);     // :238
   if (!__builtin_isnormal(sum)) return make_float2(-0.0f, -0.0f);  // :241-243: no addition at all == adding -0.0
   float distance = dx * dx + dy * dy;                              // :245
-  if (distance < clamp) distance = clamp;                          // :247-249
+  // :247-249 `if distance < 0.001 { distance = 0.001 }` as one v_max_f32 (half the cost of compare + select): `distance`
+  // is never NaN here (a normal `sum` means finite dx, dy), and for a NaN clamp both forms keep `distance`
+  distance = __builtin_fmaxf(distance, clamp);
   const float den = sum * distance;
   return make_float2((dx * force) / den, (dy * force) / den);      // :252
+}
+// The same with a per-lane `valid` folded into the skip: a lane past the leaf's end yields -0.0 like a skipped pair, under
+// the one exec mask (a select afterwards costs two v_cndmask per round).
+__device__ __forceinline__ float2 pair_term_if(bool valid, float px, float py, float qx, float qy, float force, float clamp) {
+  const float dx = qx - px;
+  const float dy = qy - py;
+  const float sum = __builtin_fabsf(dx) + __builtin_fabsf(dy);
+  if (!(valid && __builtin_isnormal(sum))) return make_float2(-0.0f, -0.0f);
+  float distance = dx * dx + dy * dy;
+  distance = __builtin_fmaxf(distance, clamp);
+  const float den = sum * distance;
+  return make_float2((dx * force) / den, (dy * force) / den);
 }
 
 // nbody_arith FAST (opt-in, tolerance instead of bit parity): one reciprocal instead of two IEEE divisions; a zero difference
@@ -86,9 +100,19 @@ __device__ __forceinline__ double2 pair_term(double px, double py, double qx, do
   const double sum = __builtin_fabs(dx) + __builtin_fabs(dy);      // :238
   if (!__builtin_isnormal(sum)) return make_double2(-0.0, -0.0);   // :241-243
   double distance = dx * dx + dy * dy;                             // :245
-  if (distance < clamp) distance = clamp;                          // :247-249
+  distance = __builtin_fmax(distance, clamp);                      // :247-249 (see the f32 version)
   const double den = sum * distance;
   return make_double2((dx * force) / den, (dy * force) / den);     // :252
+}
+__device__ __forceinline__ double2 pair_term_if(bool valid, double px, double py, double qx, double qy, double force, double clamp) {
+  const double dx = qx - px;
+  const double dy = qy - py;
+  const double sum = __builtin_fabs(dx) + __builtin_fabs(dy);
+  if (!(valid && __builtin_isnormal(sum))) return make_double2(-0.0, -0.0);
+  double distance = dx * dx + dy * dy;
+  distance = __builtin_fmax(distance, clamp);
+  const double den = sum * distance;
+  return make_double2((dx * force) / den, (dy * force) / den);
 }
 __device__ __forceinline__ double2 pair_term_fast(double px, double py, double qx, double qy, double force, double clamp) {
   const double dx = qx - px, dy = qy - py;
@@ -431,17 +455,26 @@ __global__ __launch_bounds__(256) void walk_tile(const WalkArgs<T> a, const uint
             continue;
           }
           unsigned long long todo = mask;
+          const bool valid = mine < l.z;
+          // the acting targets take the rows in lane order, TT per batch: a target's row is its rank among the acting lanes
+          const int rank = act ? (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u)) : -1;
+          int batch0 = 0;
           while (todo) {
-            int slot = 0, myslot = -1;
+            int slot = 0;
             while (todo && slot < TT) {  // lane = particle: one acting target per round, its terms into row `slot`
               const int tl = __builtin_ctzll(todo);
               todo &= todo - 1;
               const T tx = lane_t(p.x, tl), ty = lane_t(p.y, tl);
-              const T2 term = term_of<FAST>(tx, ty, q.x, q.y, m, clamp);
-              tile[slot * kStride + lane] = mine < l.z ? term : neg_zero2<T>();  // past the leaf: the identity of addition
-              if (lane == tl) myslot = slot;
+              if constexpr (FAST) {
+                const T2 term = term_of<FAST>(tx, ty, q.x, q.y, m, clamp);
+                tile[slot * kStride + lane] = valid ? term : neg_zero2<T>();  // past the leaf: the identity of addition
+              } else {
+                tile[slot * kStride + lane] = pair_term_if(valid, tx, ty, q.x, q.y, m, clamp);
+              }
               ++slot;
             }
+            const int myslot = (rank >= batch0 && rank < batch0 + slot) ? rank - batch0 : -1;
+            batch0 += slot;
             wave_lds_handoff();
             if (myslot >= 0) {  // lane = target: its row, in slice order
               const T2* __restrict__ r = tile + myslot * kStride;

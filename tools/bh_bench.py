@@ -1,6 +1,8 @@
 """Barnes-Hut step timings (secondary path; the headline bench is bench.py).  Prints one JSON line per case:
-phase seconds as the reference's Counting names them, walk statistics, algorithmic bytes of the walk and the
-CPU oracle's timing of the same step on the host cores."""
+phase seconds as the reference's Counting names them, walk statistics, the walk priced in flops against the VALU peak
+(the walks are VALU-bound on the reference's two IEEE divisions per pair — profiles/r02_leg_config4_pmc.json,
+r01_walk_tile_pmc.json; round 1 priced bytes against HBM, which over-counts by the wave-sharing factor: node and leaf
+data reach a wave by scalar loads shared by its 64 targets) and the CPU oracle's timing of the same step on the host cores."""
 import json
 import os
 import sys
@@ -36,14 +38,20 @@ def case(name, pos, vel, w, kind, theta, steps=3, cpu=True, cpu_steps=1):
         visits, accepted, leaf_pairs = ctx.walk_stats(False)
         info = ctx.tree_info()
     n = pos.shape[0]
-    alg_bytes = visits * node_bytes + leaf_pairs * pair_bytes + n * (2 * (8 if f64 else 4)) * 2
+    # lower bound of the walk's bytes: per-target node and leaf bytes / 64 (wave-uniform scalar loads) + targets in, accelerations out
+    alg_bytes = (visits * node_bytes + leaf_pairs * pair_bytes) / 64 + n * (2 * (8 if f64 else 4)) * 2
+    flops = 14.0 * (accepted + leaf_pairs) + 12.0 * visits        # as bench.py: pair evaluation 14 (a division = 1), node test 12
+    peak = 78.6 if f64 else 157.3
     out = {"case": name, "n": n, "dtype": "f64" if f64 else "f32", "tree": "bvh" if kind == C.TREE_BVH else "quad",
            "theta": theta, "nodes": info.n_nodes, "max_depth": info.max_depth, "steps": steps,
            "ms_per_step": 1e3 * wall / steps, "build_ms": 1e3 * cnt.build_bvh / steps,
            "walk_phase_ms": 1e3 * cnt.sum_gravity / steps, "integrate_ms": 1e3 * cnt.post_calculations / steps,
            "walk_kernel_ms": walk_ms, "node_visits_per_target": visits / n, "leaf_pairs_per_target": leaf_pairs / n,
-           "accepted_per_target": accepted / n, "walk_algorithmic_GB": alg_bytes / 1e9,
-           "walk_algorithmic_GBps": alg_bytes / 1e9 / (walk_ms * 1e-3) if walk_ms > 0 else None,
+           "accepted_per_target": accepted / n, "walk_bound": "valu_f64" if f64 else "valu_f32",
+           "walk_TFLOPs": flops / (walk_ms * 1e-3) / 1e12 if walk_ms > 0 else None,
+           "walk_frac_of_vector_peak": flops / (walk_ms * 1e-3) / 1e12 / peak if walk_ms > 0 else None,
+           "walk_bytes_lower_bound_GB": alg_bytes / 1e9,
+           "walk_bytes_lower_bound_GBps": alg_bytes / 1e9 / (walk_ms * 1e-3) if walk_ms > 0 else None,
            "interactions_per_s": (accepted + leaf_pairs) / (walk_ms * 1e-3) if walk_ms > 0 else None}
     if cpu:
         cores = min(len(os.sched_getaffinity(0)), 64)
