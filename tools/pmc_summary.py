@@ -2,12 +2,15 @@
 kernel (regex), kernel time from the --stats pass, HBM bytes per launch with the gfx950 correction the guide prescribes
 (MI355X_MICROARCH.md, HBM: FETCH_SIZE counts 128-B requests at 64 B for wide coalesced reads -> x2; WRITE_SIZE exact; both
 in KB).
-    python tools/pmc_summary.py <dir with stats/ pmc1/ pmc2/ pmc3/> <kernel regex> <out.json> [note]
+    python tools/pmc_summary.py <dir with stats/ pmc1/ pmc2/ pmc3/> <kernel regex> <out.json> [note] [skip]
+`skip`: leave out the first `skip` launches of the kernel in every pass (a first launch that does other work, e.g. a walk
+without history).
 """
 import csv, glob, json, os, re, sys
 
 root, rx, out = sys.argv[1], re.compile(sys.argv[2]), sys.argv[3]
 note = sys.argv[4] if len(sys.argv) > 4 else ""
+skip = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 res = {"kernel_regex": sys.argv[2], "note": note, "source": "rocprofv3 (ROCm 7.2), MI355X; passes: --kernel-trace --stats | --pmc FETCH_SIZE | "
        "--pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum | --pmc GRBM_GUI_ACTIVE SQ_*; every --pmc pass with --kernel-trace only"}
 
@@ -20,10 +23,13 @@ def rows(pattern):
 
 # kernel time from the trace (no counters attached)
 durs, name = [], None
-for r in rows("stats/**/*kernel_trace.csv"):
+for r in sorted(rows("stats/**/*kernel_trace.csv"), key=lambda r: int(r["Start_Timestamp"])):
     if rx.search(r["Kernel_Name"]):
         durs.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
         name = r["Kernel_Name"]
+durs = durs[skip:]
+if skip:
+    res["launches_skipped"] = skip
 if durs:
     res["kernel"] = name[:200]
     res["launches"] = len(durs)
@@ -33,10 +39,13 @@ if durs:
 counters = {}
 for p in ("pmc1", "pmc2", "pmc3"):
     acc = {}
-    for r in rows(p + "/**/*counter_collection.csv"):
+    for r in sorted(rows(p + "/**/*counter_collection.csv"), key=lambda r: int(r["Dispatch_Id"])):
         if rx.search(r["Kernel_Name"]):
             acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
     for k, v in acc.items():
+        v = v[skip:]
+        if not v:
+            continue
         counters[k] = sum(v) / len(v)
         counters[k + "_launches"] = len(v)
 res["counters_per_launch"] = counters
