@@ -36,6 +36,41 @@ def test_no_cpu_fallback(nb):
     assert "no CPU path" in str(e.value)
 
 
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="only meaningful without a GPU")
+def test_multi_context_has_no_cpu_fallback_either(nb):
+    """nbody_create_multi: no device -> NBODY_ERR_NO_DEVICE (the first single-device context it makes says so); bad
+    arguments are refused before any device is touched."""
+    C = nb._capi
+    for exchange in (None, C.EXCHANGE_RCCL, C.EXCHANGE_PEER):
+        with pytest.raises(C.NBodyError) as e:
+            C.MultiContext([0], exchange)
+        assert e.value.code == C.ERR_NO_DEVICE and "no CPU path" in str(e.value)
+    for bad in ([], list(range(65))):
+        with pytest.raises(C.NBodyError) as e:
+            C.MultiContext(bad, C.EXCHANGE_PEER)
+        assert e.value.code == C.ERR_INVALID
+    with pytest.raises(C.NBodyError) as e:
+        C.MultiContext([0, 0], C.EXCHANGE_RCCL)          # one rank per physical device under RCCL
+    assert e.value.code == C.ERR_INVALID and "one rank per physical device" in str(e.value)
+    with pytest.raises(C.NBodyError) as e:
+        C.MultiContext([0], 7)
+    assert e.value.code == C.ERR_INVALID
+    with pytest.raises(C.NBodyError) as e:
+        C.MultiContext([0], C.EXCHANGE_PEER, chunks=99)
+    assert e.value.code == C.ERR_INVALID
+
+
+def test_mass_hint_of_the_direct_step(nb):
+    from nbody_simulation_amd._capi import mass_hint
+    assert mass_hint(np.ones(1000, np.uint32)) == 1.0
+    w = np.ones(151409, np.uint32)
+    w[0], w[1] = 75_000_000, 750_000
+    assert mass_hint(w) == -1.0                                  # World::new: two heavy bodies (main.rs:282-291)
+    assert mass_hint((np.arange(1000) % 3 + 1).astype(np.uint32)) == 0.0
+    assert mass_hint(np.zeros(8, np.uint32)) == 0.0              # a zero base mass is no hint
+    assert mass_hint(np.zeros(0, np.uint32)) == 0.0
+
+
 def test_workspace_size_is_monotone_and_small(nb):
     C = nb._capi
     a = C.direct_workspace_bytes(1 << 20, 1 << 20)
