@@ -113,6 +113,7 @@ _SIGS = {
     "nbody_render_rgba": (C.c_int, [_vp, C.c_uint32, C.c_uint32, _vp]),
     "nbody_render_rgba_dev": (C.c_int, [_vp, C.c_int64, C.c_int, _vp, _vp, _vp, C.c_uint32, C.c_uint32, _vp, _vp]),
     "nbody_selftest_exact_sum": (C.c_int, [_vp, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int64)]),
+    "nbody_selftest_exact_sum_f64": (C.c_int, [_vp, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "nbody_selftest_exact_sum_chunked": (C.c_int, [_vp, C.c_int64, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int64)]),
     "nbody_bvh_build_restarts": (C.c_int, [_vp]),
     "nbody_last_build_on_device": (C.c_int, [_vp]),
@@ -221,6 +222,15 @@ def selftest_exact_sum(x, tile=4096, seq_run=64):
     check(None, load().nbody_selftest_exact_sum(_ptr(x) if x.size else None, x.size, int(tile), int(seq_run),
                                                 C.byref(out), C.byref(st)))
     return np.float32(out.value), st.value
+
+
+def selftest_exact_sum_f64(x, tile=4096, seq_run=16):
+    """CPU emulation of the f64 device build's exact sequential-sum scan -> (sum as np.float64, restarts)."""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    out, st = C.c_double(0), _i64(0)
+    check(None, load().nbody_selftest_exact_sum_f64(_ptr(x) if x.size else None, x.size, int(tile), int(seq_run),
+                                                    C.byref(out), C.byref(st)))
+    return np.float64(out.value), st.value
 
 
 def selftest_exact_sum_chunked(x, chunk=2048):

@@ -19,10 +19,12 @@
 #include "common.h"
 #include "direct_kernels.h"
 #include "bvh_build.h"
+#include "bvh_build64.h"
 #include "delta_codec.h"
 #include "delta_decoder.hpp"
 #include "delta_snapshot.h"
 #include "exact_sum.h"
+#include "exact_sum64.h"
 #include "quad_build.h"
 #include "render.h"
 #include "tree_build.hpp"
@@ -466,16 +468,84 @@ template <class T> int ensure_node_aux(nbody_ctx* c, State<T>& s, size_t m) {
     size_t cap = m + m / 4 + 64;
     HIPCHK(c, hipMalloc((void**)&s.node_depth, cap * sizeof(int)));
     HIPCHK(c, hipMalloc((void**)&s.node_mass, cap * sizeof(uint32_t)));
-    HIPCHK(c, hipMalloc((void**)&s.node_size, cap * sizeof(float2)));
+    HIPCHK(c, hipMalloc((void**)&s.node_size, cap * sizeof(typename State<T>::T2)));
     s.node_aux_cap = cap;
   }
   return NBODY_OK;
 }
 
 // BVH built on the device (bvh_build.hip, f32 only).  Returns NBODY_OK, an error, or 1 when the device build declines.
+// The same for f64 rows (bvh_build64.hip): every level enqueued blind, one question at the end.
+int bvh_build_device64(nbody_ctx* c, State<double>& s) {
+  const int n = (int)s.n;
+  const int leaf = c->params.leaf_size;
+  const Bvh64Layout L = bvh64_layout(n, leaf);
+  if (s.bb_scratch_bytes < L.total) {
+    free_dev(s.bb_scratch);
+    s.bb_scratch_bytes = 0;
+    HIPCHK(c, hipMalloc((void**)&s.bb_scratch, L.total));
+    s.bb_scratch_bytes = L.total;
+  }
+  int rc = ensure_node_buffers<double>(c, s, (size_t)L.node_cap);
+  if (rc) return rc;
+  rc = ensure_node_aux<double>(c, s, (size_t)L.node_cap);
+  if (rc) return rc;
+  auto& in = s.set[s.cur];
+  auto& out = s.set[1 - s.cur];
+  HIPCHK(c, bvh64_begin(c->stream, in.pos, n, s.bb_scratch, L));
+  // the levels a balanced tree has, plus a margin (the mean split is not the median: real trees run a few levels deeper);
+  // a tree that is deeper still goes on four levels at a time
+  int lv_end = std::min(bvh64_first_levels(n, leaf) + 4, kB64Levels);
+  lv_end = std::max(1, std::min(env_int("NBODY_BVH_BLIND_LEVELS", lv_end), kB64Levels));  // tests force the long way
+  int hostf[kB64FlagWords + kB64Levels + 2];
+  auto finish_and_ask = [&]() -> int {
+    HIPCHK(c, bvh64_finish(c->stream, in.weight, n, lv_end, s.bb_scratch, L, s.order_dev, s.geom0, s.geom1, s.link, s.node_depth, s.node_mass,
+                           s.node_size));
+    HIPCHK(c, hipMemcpyAsync(hostf, s.bb_scratch + L.flags, kB64FlagWords * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(hostf + kB64FlagWords, s.bb_scratch + L.opencount, (kB64Levels + 2) * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return NBODY_OK;
+  };
+  HIPCHK(c, bvh64_levels(c->stream, n, leaf, 0, lv_end, s.bb_scratch, L));
+  rc = finish_and_ask();
+  if (rc) return rc;
+  while (hostf[kB64Fallback] == 0 && hostf[kB64FlagWords + lv_end] != 0) {  // open nodes were left behind
+    if (lv_end >= kB64Levels) return 1;  // deeper than the device follows (coincident points): the host builder reports it
+    const int lv = lv_end;
+    lv_end = std::min(lv_end + 4, kB64Levels);
+    HIPCHK(c, bvh64_levels(c->stream, n, leaf, lv, lv_end, s.bb_scratch, L));
+    rc = finish_and_ask();
+    if (rc) return rc;
+  }
+  if (env_int("NBODY_TRACE", 0) != 0)
+    std::fprintf(stderr, "[nbody] device bvh build (f64): %d nodes, depth %d, %d levels enqueued, %d scan restarts, fallback %d\n",
+                 hostf[kB64NodeCount], hostf[kB64MaxDepth], lv_end, hostf[kB64Stops], hostf[kB64Fallback]);
+  const int m = hostf[kB64NodeCount];
+  if (hostf[kB64Fallback] != 0 || m <= 0 || m > L.node_cap) return 1;
+  GatherArgs<double> g{};  // rows into tree order, as the in-place partition leaves `self.particles` (bvh_tree.rs:73-77)
+  g.perm = s.order_dev;
+  g.n = n;
+  g.pos_in = in.pos; g.pos_out = out.pos;
+  g.weight_in = in.weight;
+  g.mass_out = out.mass;
+  g.vel_in = in.vel; g.vel_out = out.vel;
+  g.weight_out = out.weight;
+  g.ids_in = in.ids; g.ids_out = out.ids;
+  HIPCHK(c, launch_gather<double>(c->stream, g));
+  s.cur = 1 - s.cur;
+  s.h_weight_stale = true;
+  s.n_nodes = m;
+  s.tree_kind = NBODY_TREE_BVH;
+  s.tree_max_depth = hostf[kB64MaxDepth];
+  s.tree_host_stale = true;
+  s.tree_valid = true;
+  c->bvh_stops = hostf[kB64Stops];
+  return NBODY_OK;
+}
+
 template <class T> int bvh_build_device(nbody_ctx* c, State<T>& s) {
   if constexpr (!std::is_same<T, float>::value) {
-    return 1;
+    return env_int("NBODY_BVH64_BUILD_HOST", 0) != 0 ? 1 : bvh_build_device64(c, s);
   } else {
     const int n = (int)s.n;
     const int leaf = c->params.leaf_size;
@@ -633,8 +703,8 @@ template <class T> int download_tree(nbody_ctx* c, State<T>& s) {
   HIPCHK(c, hipStreamSynchronize(c->stream));
   t.size_x.resize(m); t.size_y.resize(m);
   if (s.tree_kind == NBODY_TREE_BVH) {  // boundary.size as the build computed it (max - min)
-    std::vector<float2> sz(m);
-    HIPCHK(c, hipMemcpy(sz.data(), s.node_size, m * sizeof(float2), hipMemcpyDeviceToHost));
+    std::vector<typename State<T>::T2> sz(m);
+    HIPCHK(c, hipMemcpy(sz.data(), s.node_size, m * sizeof(typename State<T>::T2), hipMemcpyDeviceToHost));
     for (size_t i = 0; i < m; ++i) { t.size_x[i] = (T)sz[i].x; t.size_y[i] = (T)sz[i].y; }
     s.tree_host_stale = false;
     return NBODY_OK;
@@ -1948,6 +2018,11 @@ NB_API int nbody_selftest_exact_sum_chunked(const float* x, int64_t n, int chunk
   if ((!x && n > 0) || n < 0 || chunk < 1 || !out_sum) return NBODY_ERR_INVALID;
   // segments of 8 addends per thread, as bvh_chunk_runs cuts a chunk
   *out_sum = xsum::emulate_fold_chunked2(x, n, chunk, chunk >= 8 ? 8 : 1, out_runs_used);
+  return NBODY_OK;
+}
+NB_API int nbody_selftest_exact_sum_f64(const double* x, int64_t n, int tile, int seq_run, double* out_sum, int64_t* out_restarts) {
+  if ((!x && n > 0) || n < 0 || tile < 1 || seq_run < 1 || !out_sum) return NBODY_ERR_INVALID;
+  *out_sum = xsum64::emulate_fold(x, n, tile, seq_run, out_restarts);
   return NBODY_OK;
 }
 NB_API int nbody_bvh_build_restarts(const nbody_ctx* ctx) {

@@ -43,7 +43,7 @@ template <class T> struct State {
   int shard_kind = 0;            // tree kind of the last sharded step (decides how a slice maps to rows)
   int* node_depth = nullptr;     // device build: depth of every node
   uint32_t* node_mass = nullptr; // device build: u32 mass of every node
-  float2* node_size = nullptr;   // device BVH build: boundary.size of every node
+  T2* node_size = nullptr;       // device BVH build: boundary.size of every node
   size_t node_aux_cap = 0;
   char* qb_scratch = nullptr;
   size_t qb_scratch_bytes = 0;

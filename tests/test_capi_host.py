@@ -213,6 +213,65 @@ def test_exact_sum_scan_random_bit_patterns(nb):
         assert _bits(got) == _bits(want) or (np.isnan(got) and np.isnan(want)), (it, x, got, want)
 
 
+def _seq_sum_f64(x):
+    x = np.asarray(x, np.float64)
+    if x.size == 0:
+        return np.float64(0)
+    with np.errstate(all="ignore"):
+        return np.cumsum(x, dtype=np.float64)[-1]
+
+
+def _bits64(v):
+    return np.asarray(v, np.float64).view(np.uint64)
+
+
+@pytest.mark.parametrize("tile,seq_run", [(4096, 16), (1024, 16), (4, 1), (7, 3)])
+def test_exact_sum_scan_f64_reproduces_the_sequential_chain(nb, tile, seq_run):
+    """The f64 twin (csrc/exact_sum64.h) that the device build of f64 BVHs runs: 53-bit significands, 64-bit increments."""
+    C = nb._capi
+    rng = np.random.default_rng(199)
+    cases = {}
+    for n in (0, 1, 2, 63, 64, 65, 1000, 200003):
+        cases[f"uniform{n}"] = rng.random(n) * 1e5
+        cases[f"negative{n}"] = -rng.random(n) * 1e5
+        cases[f"centred{n}"] = rng.standard_normal(n) * 3e4
+        cases[f"f32grid{n}"] = (rng.random(n) * 1e5).astype(np.float32).astype(np.float64)    # few mantissa bits: ties
+        cases[f"halves_pm{n}"] = rng.integers(-1000, 1000, n) * 0.5
+        cases[f"wide{n}"] = 10.0 ** rng.uniform(-100, 100, n) * rng.choice([-1.0, 1.0], n)
+        cases[f"pow2{n}"] = 2.0 ** rng.integers(-60, 60, n)
+        cases[f"tiny_ulps{n}"] = 1.0 + rng.integers(-3, 4, n) * 2.0 ** -53                  # ties at every add
+    x = rng.random(5000) * 1e5
+    x[::97] = 1e-310
+    cases["subnormals"] = x
+    for name, bad in (("inf", np.inf), ("nan", np.nan), ("big", 1.7e308)):
+        x = rng.random(5000) * 1e5
+        x[2500] = bad
+        x[2501] = bad
+        cases[name] = x
+    for name, x in cases.items():
+        x = np.asarray(x, np.float64)
+        got, _ = C.selftest_exact_sum_f64(x, tile, seq_run)
+        want = _seq_sum_f64(x)
+        assert _bits64(got) == _bits64(want) or (np.isnan(got) and np.isnan(want)), (name, got, want)
+
+
+def test_exact_sum_scan_f64_random_bit_patterns(nb):
+    C = nb._capi
+    rng = np.random.default_rng(5)
+    for it in range(3000):
+        n = int(rng.integers(1, 48))
+        b = rng.integers(0, 2**64, n, dtype=np.uint64)
+        mode = it % 3
+        if mode == 1:   # exponents clustered so that chains stay inside a few binades
+            b = (b & np.uint64(0x800FFFFFFFFFFFFF)) | (rng.integers(1000, 1050, n).astype(np.uint64) << np.uint64(52))
+        elif mode == 2:  # few mantissa bits: many exact ties
+            b &= np.uint64(0xFFFFFF0000000000)
+        x = b.view(np.float64)
+        got, _ = C.selftest_exact_sum_f64(x, 4 if it % 2 else 64, 1 + it % 3)
+        want = _seq_sum_f64(x)
+        assert _bits64(got) == _bits64(want) or (np.isnan(got) and np.isnan(want)), (it, x, got, want)
+
+
 def test_exact_sum_scan_restarts_are_rare_on_scene_data(nb):
     """Same-signed coordinates leave a binade about once per doubling of the sum: the scan restarts O(log) times."""
     C = nb._capi

@@ -615,3 +615,88 @@ def test_step_ahead_recovers_when_its_speculation_fails(nb, monkeypatch, capfd, 
         if on and hook == "NBODY_WALK_TILE_POISON":
             assert "overflow 1" in err and "estimate none" in err
     assert all(np.array_equal(a, b) for a, b in zip(*res))
+
+
+# ------------------------------------------------------------------ the f64 BVH built on the device (bvh_build64.hip)
+def _bvh64_scenes(nb):
+    rng = np.random.default_rng(31)
+    out = {}
+    for name, (pos, w) in _bvh_scenes(nb).items():
+        out[name] = (pos.astype(np.float64), w)                       # f32-representable coordinates: ties at every add
+    p, _, w = nb.scenes.plummer(200003, seed=91, dtype=np.float64)    # full 53-bit mantissas
+    out["plummer64"] = (p, w)
+    out["wide64"] = (10.0 ** rng.uniform(-8, 8, (30000, 2)), np.ones(30000, np.uint32))
+    out["deep64"] = (10.0 ** rng.uniform(-100, 100, (3000, 2)), np.ones(3000, np.uint32))   # one point peeled off per level
+    out["centred64"] = (rng.standard_normal((40000, 2)) * 1e4, (np.arange(40000) % 7 + 1).astype(np.uint32))
+    out["tiny_n"] = (rng.random((5, 2)) * 100.0, np.ones(5, np.uint32))
+    out["one"] = (np.array([[3.0, 4.0]]), np.array([9], np.uint32))
+    return out
+
+
+@pytest.mark.parametrize("leaf", [64, 8, 1, 200, 5000])
+def test_device_bvh64_build_equals_oracle_tree(nb, orc, leaf):
+    """f64 rows: the level-by-level device build (exact f64 sequential sums by the parity-map scan with 64-bit increments,
+    rank-list partition, pre-order numbering from subtree sizes) gives the oracle's tree, node for node and bit for bit."""
+    C = nb._capi
+    with C.Context(0) as ctx:
+        for name, (pos, w) in _bvh64_scenes(nb).items():
+            if leaf < 8 and pos.shape[0] > 50000:
+                continue
+            prm = C.default_params()
+            prm.leaf_size = leaf
+            if C.host_tree(C.TREE_BVH, pos, w, prm)["overflow"]:
+                continue   # the reference itself recurses without end here: covered by the degenerate-input tests
+            ctx.set_params(theta=50.0, leaf_size=leaf)
+            ctx.upload(pos, np.zeros_like(pos), w)
+            ctx.accel_tree(C.TREE_BVH, pos[:4])
+            # a tree deeper than the 62 levels the device follows goes to the host builder (same tree either way)
+            assert ctx.last_build_on_device() == (ctx.tree_info().max_depth <= 62), (name, ctx.tree_info().max_depth)
+            if name == "deep64" and leaf <= 64:
+                assert ctx.tree_info().max_depth > 62
+            t = ctx.tree_export()
+            o = orc.BVH(pos, w, leaf_size=leaf).flat()
+            for k in ("mass", "is_leaf", "first", "count", "skip"):
+                assert np.array_equal(t[k], getattr(o, k)), (name, k)
+            assert np.array_equal(t["geom"], o.geom, equal_nan=True), name
+            assert np.array_equal(t["order"], o.ids), name
+            p, _, w2, ids = ctx.download()
+            assert np.array_equal(ids, o.ids) and np.array_equal(p, o.pos_perm) and np.array_equal(w2, w[o.ids]), name
+
+
+def test_device_and_host_bvh64_builds_agree_over_steps(nb, monkeypatch, capfd):
+    """10 full f64 steps with the device build against 10 with the host build: same rows; too few blind levels (the
+    build then goes on four levels at a time) changes nothing either."""
+    C = nb._capi
+    pos, vel, w = nb.scenes.plummer(60000, seed=92, dtype=np.float64)
+    res = []
+    for host, blind in (("0", None), ("1", None), ("0", "3")):
+        monkeypatch.setenv("NBODY_BVH64_BUILD_HOST", host)
+        if blind:
+            monkeypatch.setenv("NBODY_BVH_BLIND_LEVELS", blind)
+        with C.Context(0) as c:
+            c.set_params(theta=0.7)
+            c.upload(pos, vel, w)
+            c.update_tree(C.TREE_BVH, 0.1, 10)
+            assert c.last_build_on_device() == (host == "0")
+            res.append(c.download())
+    for other in res[1:]:
+        assert all(np.array_equal(a, b) for a, b in zip(res[0], other))
+
+
+def test_device_bvh64_build_declines_what_it_cannot_express(nb, orc):
+    """NaN positions (the fold's minps / maxps are order-dependent there) and more coincident points than a leaf holds
+    (the reference recurses without end) go to the host builder, which handles the one and reports the other."""
+    C = nb._capi
+    pos, vel, w = nb.scenes.plummer(5000, seed=93, dtype=np.float64)
+    with C.Context(0) as c:
+        p = pos.copy()
+        p[77, 0] = np.nan
+        c.upload(p, vel, w)
+        c.accel_tree(C.TREE_BVH, pos[:4])
+        assert not c.last_build_on_device()
+        p = pos.copy()
+        p[100:300] = p[100]                                            # 200 coincident points > leaf_size 64
+        c.upload(p, vel, w)
+        with pytest.raises(C.NBodyError) as e:
+            c.accel_tree(C.TREE_BVH, pos[:4])
+        assert e.value.code == C.ERR_DEGENERATE
