@@ -108,10 +108,16 @@ __global__ __launch_bounds__(256) void b64_init(Ptrs a, const double2* __restric
 }
 
 // ---- per level -------------------------------------------------------------------------------------------------------
+constexpr int kSmallNode = 256;  // nodes up to this long are folded by one thread per coordinate, in order (b64_fold_small)
+
 // One coordinate of the fold of bvh_tree.rs:58-61 over a node: min, max and the sum exactly as the sequential chain rounds it.
+// A scan round covers TILE = NT * EPT consecutive addends: they are fetched coalesced (the rows are double2: a thread reading
+// its own 16 consecutive rows straight from memory touches 16 cache lines for 128 useful bytes) into LDS, padded by one
+// word per 16 so that the threads' consecutive reads spread over the banks.
 template <int NT, int kFoldEPT>
 __global__ __launch_bounds__(NT) void b64_fold(Ptrs a, int level) {
   constexpr int NW = NT / 64, TILE = NT * kFoldEPT;
+  __shared__ double stage[TILE + TILE / 16];
   __shared__ xsum64::Step wtot[NW];
   __shared__ unsigned long long sh_S;
   __shared__ int sh_bad;
@@ -121,41 +127,41 @@ __global__ __launch_bounds__(NT) void b64_fold(Ptrs a, int level) {
   for (int q = blockIdx.x; q < nopen; q += gridDim.x) {
     const int node = a.openq[(size_t)(level & 1) * a.open_cap + q];
     const int b = a.nbegin[node], len = a.nlen[node];
+    if (len <= kSmallNode) continue;  // (uniform) b64_fold_small's
     const double* __restrict__ X = reinterpret_cast<const double*>(a.P + b) + comp;  // element i at X[2 i]
-    // min (from f64::MAX) and max (from 0.0: bvh_tree.rs:59): order-free without NaNs
-    double mn = kMaxD, mx = 0.0;
-    for (int i = tid; i < len; i += NT) {
-      const double v = X[2 * (size_t)i];
-      mn = sse_min(mn, v);
-      mx = sse_max(mx, v);
-    }
-    for (int d = 32; d >= 1; d >>= 1) {
-      mn = sse_min(mn, __shfl_xor(mn, d, 64));
-      mx = sse_max(mx, __shfl_xor(mx, d, 64));
-    }
-    if (lane == 0) { red[0][wave] = mn; red[1][wave] = mx; }
-    __syncthreads();
-    mn = red[0][0]; mx = red[1][0];
-    for (int w = 1; w < NW; ++w) { mn = sse_min(mn, red[0][w]); mx = sse_max(mx, red[1][w]); }
-    // the chain
-    double s = 0.0;  // uniform across the group
+    double mn = kMaxD, mx = 0.0;  // min from f64::MAX, max from 0.0 (bvh_tree.rs:59): order-free without NaNs
+    double s = 0.0;               // the chain; uniform across the group
     int pos = 0, stops = 0;
     while (pos < len) {
       xsum64::Chain c;
       if (!xsum64::chain_open(s, c)) {  // not inside a binade (zero, subnormal, a power of two, non-finite): real adds
         int cnt = pos == 0 ? kSeqStart : kSeqRun;
         cnt = len - pos < cnt ? len - pos : cnt;
-        for (int k = 0; k < cnt; ++k) s = s + X[2 * (size_t)(pos + k)];  // every thread the same adds: no hand-over
+        for (int k = 0; k < cnt; ++k) {  // every thread the same adds: no hand-over
+          const double v = X[2 * (size_t)(pos + k)];
+          s = s + v;
+          mn = sse_min(mn, v);
+          mx = sse_max(mx, v);
+        }
         pos += cnt;
         continue;
       }
       const int cnt = len - pos < TILE ? len - pos : TILE;
-      const int base = pos + tid * kFoldEPT, end = pos + cnt;
+      const int end = pos + cnt;
+      for (int e = tid; e < cnt; e += NT) stage[e + (e >> 4)] = X[2 * (size_t)(pos + e)];
+      if (tid == 0) sh_bad = INT_MAX;
+      __syncthreads();
+      const int base = tid * kFoldEPT;  // tile-relative
       xsum64::Step f[kFoldEPT];
       xsum64::Step F = xsum64::identity();
 #pragma unroll
       for (int j = 0; j < kFoldEPT; ++j) {
-        f[j] = base + j < end ? xsum64::step_of(X[2 * (size_t)(base + j)], c.sign, c.E) : xsum64::identity();
+        if (base + j < cnt) {
+          const double v = stage[base + j + ((base + j) >> 4)];
+          f[j] = xsum64::step_of(v, c.sign, c.E);
+        } else {
+          f[j] = xsum64::identity();
+        }
         F = xsum64::compose(F, f[j]);
       }
       xsum64::Step inc = F;  // inclusive scan of the threads' maps, in thread order
@@ -164,7 +170,6 @@ __global__ __launch_bounds__(NT) void b64_fold(Ptrs a, int level) {
         if (lane >= d) inc = xsum64::compose(o, inc);
       }
       if (lane == 63) wtot[wave] = inc;
-      if (tid == 0) sh_bad = INT_MAX;
       __syncthreads();
       xsum64::Step excl = xsum64::identity();
       for (int w = 0; w < wave; ++w) excl = xsum64::compose(excl, wtot[w]);
@@ -176,7 +181,7 @@ __global__ __launch_bounds__(NT) void b64_fold(Ptrs a, int level) {
       uint64_t S_at_bad = 0;
 #pragma unroll
       for (int j = 0; j < kFoldEPT; ++j) {
-        if (base + j < end && bad == INT_MAX) {
+        if (base + j < cnt && bad == INT_MAX) {
           const uint64_t after = xsum64::apply(S, f[j]);
           if (!xsum64::in_binade(after)) { bad = base + j; S_at_bad = S; }
           else S = after;
@@ -184,9 +189,15 @@ __global__ __launch_bounds__(NT) void b64_fold(Ptrs a, int level) {
       }
       if (bad != INT_MAX) atomicMin(&sh_bad, bad);
       __syncthreads();
-      const int first_bad = sh_bad;  // the earliest one is right: everything before it stayed inside the binade
+      const int first_bad = sh_bad;  // tile-relative; the earliest one is right: everything before it stayed inside the binade
+      const int used = first_bad == INT_MAX ? cnt : first_bad;
+      for (int e = tid; e < used; e += NT) {  // min / max of what the chain has taken
+        const double v = stage[e + (e >> 4)];
+        mn = sse_min(mn, v);
+        mx = sse_max(mx, v);
+      }
       if (first_bad == INT_MAX) {
-        if (base <= end - 1 && end - 1 < base + kFoldEPT) sh_S = S;  // the owner of the tile's last addend
+        if (base <= cnt - 1 && cnt - 1 < base + kFoldEPT) sh_S = S;  // the owner of the tile's last addend
         __syncthreads();
         s = xsum64::chain_value(c, sh_S);
         pos = end;
@@ -195,20 +206,53 @@ __global__ __launch_bounds__(NT) void b64_fold(Ptrs a, int level) {
         __syncthreads();
         s = xsum64::chain_value(c, sh_S);
         ++stops;
-        pos = first_bad;
-        int run = len - pos < kSeqRun ? len - pos : kSeqRun;
-        for (int k = 0; k < run; ++k) s = s + X[2 * (size_t)(pos + k)];
+        pos += first_bad;
+        const int run = cnt - first_bad < kSeqRun ? cnt - first_bad : kSeqRun;  // real adds, as far as the tile holds them
+        for (int k = 0; k < run; ++k) {
+          const double v = stage[first_bad + k + ((first_bad + k) >> 4)];
+          s = s + v;
+          if (tid == 0) { mn = sse_min(mn, v); mx = sse_max(mx, v); }
+        }
         pos += run;
       }
-      __syncthreads();  // sh_S, sh_bad and wtot are reused by the next round
+      __syncthreads();  // stage, sh_S, sh_bad and wtot are reused by the next round
     }
+    // the sequential parts were added to every thread's mn / mx alike or to thread 0's only: either way the reduction is right
+    for (int d = 32; d >= 1; d >>= 1) {
+      mn = sse_min(mn, __shfl_xor(mn, d, 64));
+      mx = sse_max(mx, __shfl_xor(mx, d, 64));
+    }
+    if (lane == 0) { red[0][wave] = mn; red[1][wave] = mx; }
+    __syncthreads();
     if (tid == 0) {
+      for (int w = 1; w < NW; ++w) { mn = sse_min(mn, red[0][w]); mx = sse_max(mx, red[1][w]); }
       if (comp == 0) { a.nsum[node].x = s; a.nmin[node].x = mn; a.nmax[node].x = mx; }
       else { a.nsum[node].y = s; a.nmin[node].y = mn; a.nmax[node].y = mx; }
       if (stops) atomicAdd(&a.flags[kB64Stops], stops);
     }
     __syncthreads();
   }
+}
+
+// Short nodes: the chain as written, one thread per node and coordinate.
+__global__ __launch_bounds__(256) void b64_fold_small(Ptrs a, int level) {
+  const int nopen = a.opencount[level] < a.open_cap ? a.opencount[level] : a.open_cap;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int q = t >> 1, comp = t & 1;
+  if (q >= nopen) return;
+  const int node = a.openq[(size_t)(level & 1) * a.open_cap + q];
+  const int b = a.nbegin[node], len = a.nlen[node];
+  if (len > kSmallNode) return;
+  const double* __restrict__ X = reinterpret_cast<const double*>(a.P + b) + comp;
+  double mn = kMaxD, mx = 0.0, s = 0.0;
+  for (int i = 0; i < len; ++i) {
+    const double v = X[2 * (size_t)i];
+    s = s + v;
+    mn = sse_min(mn, v);
+    mx = sse_max(mx, v);
+  }
+  if (comp == 0) { a.nsum[node].x = s; a.nmin[node].x = mn; a.nmax[node].x = mx; }
+  else { a.nsum[node].y = s; a.nmin[node].y = mn; a.nmax[node].y = mx; }
 }
 
 // mean (bvh_tree.rs:67), the node's chunks into the level's table, counters to zero.  One wave per open node.
@@ -233,6 +277,26 @@ __global__ __launch_bounds__(64) void b64_plan(Ptrs a, int level) {
       a.ch_node[c0 + c] = node;
       a.ch_index[c0 + c] = c;
     }
+  }
+}
+
+// The same with one THREAD per open node: below the top levels a node has a chunk or two, and a wave per node idles 63 lanes.
+__global__ __launch_bounds__(256) void b64_plan_t(Ptrs a, int level) {
+  const int nopen = a.opencount[level] < a.open_cap ? a.opencount[level] : a.open_cap;
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= nopen) return;
+  const int node = a.openq[(size_t)(level & 1) * a.open_cap + q];
+  const int len = a.nlen[node];
+  const int nch = (len + kChunk - 1) / kChunk;
+  const int c0 = atomicAdd(&a.chunkcount[level], nch);
+  const double2 s = a.nsum[node];
+  a.nmean[node] = make_double2(s.x / (double)len, s.y / (double)len);
+  a.ncx[node] = 0; a.ncy[node] = 0;
+  a.nchunk0[node] = c0;
+  if (c0 + nch > a.chunk_cap) a.flags[kB64Fallback] = 1;
+  for (int c = 0; c < nch && c0 + c < a.chunk_cap; ++c) {
+    a.ch_node[c0 + c] = node;
+    a.ch_index[c0 + c] = c;
   }
 }
 
@@ -317,13 +381,49 @@ __global__ __launch_bounds__(256) void b64_mis(Ptrs a, int level) {
   }
 }
 
-// Prefix of the chunks' misplaced counts; the two children (bvh_tree.rs:78-88).  One wave per open node.
+// The two children of a node whose chunks' misplaced counts add up to runl / runr (bvh_tree.rs:78-88).
+__device__ __forceinline__ void make_children64(const Ptrs& a, int level, int node, int leaf_size, int runl, int runr) {
+  const int len = a.nlen[node], b = a.nbegin[node];
+  bool on_x;
+  int split;
+  axis_of(a, node, on_x, split);
+  a.naxis[node] = on_x ? 1 : 0;
+  a.nsplit[node] = split;
+  a.nk[node] = runl;  // == runr: as many misplaced on the left as on the right
+  if (runl != runr) a.flags[kB64Fallback] = 1;
+  const int first = atomicAdd(&a.flags[kB64NodeCount], 2);
+  if (first + 2 > a.node_cap) {
+    a.flags[kB64Fallback] = 1;
+    a.nchild[node] = -1;
+    return;
+  }
+  a.nchild[node] = first;
+  const int depth = a.ndepth[node] + 1;
+  atomicMax(&a.flags[kB64MaxDepth], depth);
+  for (int side = 0; side < 2; ++side) {  // left = the "greater" side, built first
+    const int id = first + side;
+    const int cl = side == 0 ? split : len - split;
+    a.nbegin[id] = side == 0 ? b : b + split;
+    a.nlen[id] = cl;
+    a.ndepth[id] = depth;
+    a.nchild[id] = -1;
+    const bool leaf = !(cl > leaf_size);
+    a.nleaf[id] = leaf ? 1 : 0;
+    if (!leaf) {
+      const int slot = atomicAdd(&a.opencount[level + 1], 1);
+      if (slot < a.open_cap) a.openq[(size_t)((level + 1) & 1) * a.open_cap + slot] = id;
+      else a.flags[kB64Fallback] = 1;
+    }
+  }
+}
+
+// Prefix of the chunks' misplaced counts, then the children.  One wave per open node (the top levels: thousands of chunks) ...
 __global__ __launch_bounds__(64) void b64_children(Ptrs a, int level, int leaf_size) {
   const int nopen = a.opencount[level] < a.open_cap ? a.opencount[level] : a.open_cap;
   const int lane = threadIdx.x;
   for (int q = blockIdx.x; q < nopen; q += gridDim.x) {
     const int node = a.openq[(size_t)(level & 1) * a.open_cap + q];
-    const int len = a.nlen[node], b = a.nbegin[node];
+    const int len = a.nlen[node];
     const int nch = (len + kChunk - 1) / kChunk, c0 = a.nchunk0[node];
     int runl = 0, runr = 0;
     for (int cb = 0; cb < nch; cb += 64) {  // exclusive prefix over the node's chunks, 64 at a time
@@ -339,40 +439,25 @@ __global__ __launch_bounds__(64) void b64_children(Ptrs a, int level, int leaf_s
       runl += __shfl(il, 63, 64);
       runr += __shfl(ir, 63, 64);
     }
-    if (lane == 0) {
-      bool on_x;
-      int split;
-      axis_of(a, node, on_x, split);
-      a.naxis[node] = on_x ? 1 : 0;
-      a.nsplit[node] = split;
-      a.nk[node] = runl;  // == runr: as many misplaced on the left as on the right
-      if (runl != runr) a.flags[kB64Fallback] = 1;
-      const int first = atomicAdd(&a.flags[kB64NodeCount], 2);
-      if (first + 2 > a.node_cap) {
-        a.flags[kB64Fallback] = 1;
-        a.nchild[node] = -1;
-      } else {
-        a.nchild[node] = first;
-        const int depth = a.ndepth[node] + 1;
-        atomicMax(&a.flags[kB64MaxDepth], depth);
-        for (int side = 0; side < 2; ++side) {  // left = the "greater" side, built first
-          const int id = first + side;
-          const int cl = side == 0 ? split : len - split;
-          a.nbegin[id] = side == 0 ? b : b + split;
-          a.nlen[id] = cl;
-          a.ndepth[id] = depth;
-          a.nchild[id] = -1;
-          const bool leaf = !(cl > leaf_size);
-          a.nleaf[id] = leaf ? 1 : 0;
-          if (!leaf) {
-            const int slot = atomicAdd(&a.opencount[level + 1], 1);
-            if (slot < a.open_cap) a.openq[(size_t)((level + 1) & 1) * a.open_cap + slot] = id;
-            else a.flags[kB64Fallback] = 1;
-          }
-        }
-      }
-    }
+    if (lane == 0) make_children64(a, level, node, leaf_size, runl, runr);
   }
+}
+// ... or one thread per open node (everywhere else: a chunk or two each).
+__global__ __launch_bounds__(256) void b64_children_t(Ptrs a, int level, int leaf_size) {
+  const int nopen = a.opencount[level] < a.open_cap ? a.opencount[level] : a.open_cap;
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= nopen) return;
+  const int node = a.openq[(size_t)(level & 1) * a.open_cap + q];
+  const int len = a.nlen[node];
+  const int nch = (len + kChunk - 1) / kChunk, c0 = a.nchunk0[node];
+  int runl = 0, runr = 0;
+  for (int c = 0; c < nch && c0 + c < a.chunk_cap; ++c) {
+    a.ch_loff[c0 + c] = runl;
+    a.ch_roff[c0 + c] = runr;
+    runl += a.ch_l[c0 + c];
+    runr += a.ch_r[c0 + c];
+  }
+  make_children64(a, level, node, leaf_size, runl, runr);
 }
 
 // the k-th misplaced point from the left / from the right of every node, in position order
@@ -573,13 +658,19 @@ hipError_t bvh64_levels(hipStream_t s, int n, int leaf_size, int level_begin, in
     const int64_t width = level < 30 ? (int64_t)1 << level : (int64_t)1 << 30;  // a level never has more open nodes than this
     const int64_t go = std::min<int64_t>(L.open_cap, width);
     const int64_t gc = std::min<int64_t>(L.chunk_cap, (int64_t)n / kChunk + width + 1);
-    // a scan round covers 16 addends per thread: 512 threads (8192 addends) for the few long chains of the top levels, 256 below
-    if (width <= 32) b64_fold<512, 16><<<dim3((unsigned)go, 2), dim3(512), 0, s>>>(a, level);
-    else b64_fold<256, 16><<<dim3((unsigned)go, 2), dim3(256), 0, s>>>(a, level);
-    b64_plan<<<dim3((unsigned)go), dim3(64), 0, s>>>(a, level);
+    // the fold: a scan round covers 16 addends per thread — 512 threads (8192 addends) for the few long chains of the top
+    // levels, 256 below; nodes of <= 256 points are added in order, a thread per node and coordinate
+    const int64_t gbig = std::min<int64_t>(go, (int64_t)n / kSmallNode + 1);  // blocks stride over the queue: this many is plenty
+    if (width <= 32) b64_fold<512, 16><<<dim3((unsigned)gbig, 2), dim3(512), 0, s>>>(a, level);
+    else b64_fold<256, 16><<<dim3((unsigned)gbig, 2), dim3(256), 0, s>>>(a, level);
+    b64_fold_small<<<dim3((unsigned)((2 * go + 255) / 256)), dim3(256), 0, s>>>(a, level);
+    const bool by_wave = width <= 64;  // a wave per open node while nodes are few and long, a thread per node after
+    if (by_wave) b64_plan<<<dim3((unsigned)go), dim3(64), 0, s>>>(a, level);
+    else b64_plan_t<<<dim3((unsigned)((go + 255) / 256)), dim3(256), 0, s>>>(a, level);
     b64_count<<<dim3((unsigned)gc), dim3(256), 0, s>>>(a, level);
     b64_mis<<<dim3((unsigned)gc), dim3(256), 0, s>>>(a, level);
-    b64_children<<<dim3((unsigned)go), dim3(64), 0, s>>>(a, level, leaf_size);
+    if (by_wave) b64_children<<<dim3((unsigned)go), dim3(64), 0, s>>>(a, level, leaf_size);
+    else b64_children_t<<<dim3((unsigned)((go + 255) / 256)), dim3(256), 0, s>>>(a, level, leaf_size);
     b64_ranks<<<dim3((unsigned)gc), dim3(256), 0, s>>>(a, level);
     b64_swap<<<dim3((unsigned)gc), dim3(256), 0, s>>>(a, level);
   }
