@@ -62,9 +62,12 @@ class HipBackend:
 
 class ShardedDirectStepper:
     def __init__(self, pos, vel, weight, *, rank=0, world=1, device=None, clamp=0.001, arith=_capi.ARITH_AUTO,
-                 timer=None, group=None, backend=None, chunks=0):
+                 timer=None, group=None, backend=None, chunks=0, exchange_always=False):
+        """exchange_always: issue the collectives even with one rank (a one-rank all-gather is a no-op that still goes
+        through RCCL: how the exchange code is exercised on a one-GPU box)."""
         import torch
         self.torch = torch
+        self.exchange_always = exchange_always
         pos = np.ascontiguousarray(pos, np.float32).reshape(-1, 2)
         vel = np.ascontiguousarray(vel, np.float32).reshape(-1, 2)
         weight = np.ascontiguousarray(weight, np.uint32)
@@ -126,7 +129,7 @@ class ShardedDirectStepper:
             if count > 0:
                 self.backend.run(self.pos_all, self.mass_all, self.n, begin, count, self.vel[begin:begin + count],
                                  self.pos_next[begin:begin + count], dt)
-            if self.world > 1:
+            if self.world > 1 or self.exchange_always:
                 w = self._gather_chunk(c)
                 if w is not None:
                     pending.append(w)
@@ -158,9 +161,11 @@ class ShardedTreeStepper:
     the context's own stream (torch sees it as an ExternalStream), so there is no device-wide synchronisation.
     Results are bit-identical to the single-context step: a target's walk does not depend on who performs it."""
 
-    def __init__(self, pos, vel, weight, *, kind=_capi.TREE_QUAD, rank=0, world=1, device_index=0, group=None, **params):
+    def __init__(self, pos, vel, weight, *, kind=_capi.TREE_QUAD, rank=0, world=1, device_index=0, group=None,
+                 exchange_always=False, **params):
         import torch
         self.torch = torch
+        self.exchange_always = exchange_always
         self.kind, self.rank, self.world, self.group = kind, rank, world, group
         self.ctx = _capi.Context(device_index)
         if params:
@@ -188,7 +193,7 @@ class ShardedTreeStepper:
 
     def step(self, dt, counter=None):
         self.ctx.update_tree_shard(self.kind, dt, self.begin, self.n_local, counter)
-        if self.world == 1:
+        if self.world == 1 and not self.exchange_always:
             return
         import torch.distributed as dist
         base = self.buf.data_ptr()

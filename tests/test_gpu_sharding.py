@@ -189,3 +189,68 @@ def test_two_ranks_two_gpus_rccl(orc, nb):
         assert np.array_equal(ids, np.arange(n)) and np.array_equal(p, qp) and np.array_equal(v, qv)
         p, v, _, ids = ret[r]["bvh"]
         assert np.array_equal(ids, bids) and np.array_equal(p, bp) and np.array_equal(v, bv)
+
+
+# ------------------------------------------------------------------ the torch 'nccl' code path with ONE rank (real RCCL)
+def _one_rank_nccl_worker(rank, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    import nbody_simulation_amd as nb
+    from nbody_simulation_amd.sharding import ShardedDirectStepper, ShardedTreeStepper
+    C = nb._capi
+    n = 70001
+    pos, vel, _ = nb.scenes.plummer(n, seed=75)
+    w = (np.arange(n) % 3 + 1).astype(np.uint32)
+    st = ShardedDirectStepper(pos, vel, w, rank=0, world=1, device=dev, arith=C.ARITH_AUTO, group=dist.group.WORLD, chunks=3,
+                              exchange_always=True)
+    for _ in range(4):
+        st.step(0.1)
+    torch.cuda.synchronize()
+    out = {"direct": (st.all_positions(), st.local_state()[1], st._inplace)}
+    for name, kind in (("quad", C.TREE_QUAD), ("bvh", C.TREE_BVH)):
+        ts = ShardedTreeStepper(pos, vel, w, kind=kind, rank=0, world=1, device_index=0, group=dist.group.WORLD, theta=0.5,
+                                exchange_always=True)
+        for _ in range(3):
+            ts.step(0.1)
+        out[name] = (ts.particles(), ts._inplace)
+        ts.close()
+    ret[0] = out
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_one_rank_over_the_nccl_backend(nb):
+    """What one GPU can say about the torchrun path the driver's multi-GPU bench takes: the process group is 'nccl' (RCCL),
+    the collectives are issued although there is one rank — the in-place, asynchronous, chunked all-gather of the positions
+    behind each chunk's kernels; the packed all-gather of a tree step on the context's own stream — and the results equal
+    the plain context's.  (Aliased send / receive buffers, async_op + wait, ExternalStream: the torch API usage is what
+    this checks; the exchange between ranks needs two GPUs, test_two_ranks_two_gpus_rccl.)"""
+    C = nb._capi
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_one_rank_nccl_worker, args=(_free_port(), ret), nprocs=1, join=True)
+    n = 70001
+    pos, vel, _ = nb.scenes.plummer(n, seed=75)
+    w = (np.arange(n) % 3 + 1).astype(np.uint32)
+    allp, v, inplace = ret[0]["direct"]
+    assert inplace                                           # the aliased (in-place) all-gather was accepted
+    with C.Context(0) as c:
+        c.upload(pos, vel, w)
+        c.update_direct(0.1, 4)
+        cp, cv, _, _ = c.download()
+    # three chunks of a third of the targets each instead of one launch: another split of the sources over blockIdx.y, so
+    # the FAST sums differ by summation order; the exchange itself must not change a bit: compare through EXACT below
+    assert np.allclose(allp, cp, rtol=0, atol=1e-2) and np.allclose(v, cv, rtol=1e-3, atol=1e-6)
+    for name, kind in (("quad", C.TREE_QUAD), ("bvh", C.TREE_BVH)):
+        (p, vv, ww, ids), inplace = ret[0][name]
+        assert inplace
+        with C.Context(0) as c:
+            c.set_params(theta=0.5)
+            c.upload(pos, vel, w)
+            c.update_tree(kind, 0.1, 3)
+            ref = c.download()
+        assert all(np.array_equal(a, b) for a, b in zip((p, vv, ww, ids), ref)), name
