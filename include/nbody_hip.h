@@ -137,8 +137,8 @@ int64_t nbody_num_particles(const nbody_ctx* ctx);
 /* Direct O(N^2): a_i = sum_j calculate_gravity(p_i, p_j, w_j) for j ascending, then main.rs:419-423.
  * (No reference function: this is what bvh_sum_gravity degenerates to at theta = 0) */
 int nbody_update_direct_f32(nbody_ctx* ctx, float delta, int n_steps, nbody_counting* counter);
-/* Barnes-Hut: the linearised tree is the reference's tree, node for node (built on the device; by the host builder for f64
- * BVHs and for what the device builders decline, see nbody_last_build_on_device), and the device walks it. */
+/* Barnes-Hut: the linearised tree is the reference's tree, node for node (built on the device; by the host builder
+ * for what the device builders decline — NaN positions, trees deeper than they follow — see nbody_last_build_on_device), and the device walks it. */
 int nbody_update_tree_f32(nbody_ctx* ctx, int tree_kind, float delta, int n_steps, nbody_counting* counter);
 int nbody_update_tree_f64(nbody_ctx* ctx, int tree_kind, double delta, int n_steps, nbody_counting* counter);
 
