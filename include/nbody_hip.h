@@ -141,6 +141,15 @@ int nbody_update_direct_f32(nbody_ctx* ctx, float delta, int n_steps, nbody_coun
  * for what the device builders decline — NaN positions, trees deeper than they follow — see nbody_last_build_on_device), and the device walks it. */
 int nbody_update_tree_f32(nbody_ctx* ctx, int tree_kind, float delta, int n_steps, nbody_counting* counter);
 int nbody_update_tree_f64(nbody_ctx* ctx, int tree_kind, double delta, int n_steps, nbody_counting* counter);
+/* The reference's loop makes one `update` per iteration and then hands a snapshot to its renderer (main.rs:118-139); a
+ * synchronous call per step leaves the GPU idle from the end of one call to the first launch of the next.  The asynchronous
+ * form returns as soon as the steps are enqueued — for the f32 BVH: as soon as the host has made its one decision per
+ * step, while the walk still runs — so consecutive calls (and nbody_snapshot_begin / nbody_delta_begin between them) run
+ * back to back on the device.  The rows are complete for every later call that reads them (each orders itself after
+ * the steps); the phase seconds of nbody_get_counting are complete after nbody_wait, which also reports a failure of
+ * the device.  On a context made by nbody_create_multi the call is simply synchronous. */
+int nbody_update_tree_async_f32(nbody_ctx* ctx, int tree_kind, float delta, int n_steps);
+int nbody_wait(nbody_ctx* ctx);
 
 /* ---- sharded Barnes-Hut steps (one process per GPU) ------------------------------------------------
  * Every rank uploads ALL particles and builds the same tree; a rank walks and integrates only its slice

@@ -69,6 +69,8 @@ _SIGS = {
     "nbody_update_direct_f32": (C.c_int, [_vp, _f32, _i32, C.POINTER(Counting)]),
     "nbody_update_tree_f32": (C.c_int, [_vp, _i32, _f32, _i32, C.POINTER(Counting)]),
     "nbody_update_tree_f64": (C.c_int, [_vp, _i32, _f64, _i32, C.POINTER(Counting)]),
+    "nbody_update_tree_async_f32": (C.c_int, [_vp, _i32, _f32, _i32]),
+    "nbody_wait": (C.c_int, [_vp]),
     "nbody_update_tree_shard_f32": (C.c_int, [_vp, _i32, _f32, _i64, _i64, C.POINTER(Counting)]),
     "nbody_update_tree_shard_f64": (C.c_int, [_vp, _i32, _f64, _i64, _i64, C.POINTER(Counting)]),
     "nbody_export_slice_dev": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _vp]),
@@ -414,6 +416,13 @@ class Context:
         f = self.lib.nbody_update_tree_f64 if self.dtype == np.float64 else self.lib.nbody_update_tree_f32
         check(self.h, f(self.h, int(kind), float(delta), int(n_steps),
                         C.byref(counter) if counter is not None else None))
+
+    def update_tree_async(self, kind, delta, n_steps=1):
+        """f32 only: returns once the steps are enqueued; `wait()` (or any call that reads the rows) completes them."""
+        check(self.h, self.lib.nbody_update_tree_async_f32(self.h, int(kind), float(delta), int(n_steps)))
+
+    def wait(self):
+        check(self.h, self.lib.nbody_wait(self.h))
 
     def update_tree_shard(self, kind, delta, begin, count, counter: Counting | None = None):
         f = self.lib.nbody_update_tree_shard_f64 if self.dtype == np.float64 else self.lib.nbody_update_tree_shard_f32

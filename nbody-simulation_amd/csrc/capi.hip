@@ -1156,7 +1156,9 @@ template <class T> int bvh_step_ahead(nbody_ctx* c, State<T>& s, T delta, PhaseE
   }
 }
 
-template <class T> int update_tree(nbody_ctx* c, int kind, T delta, int n_steps, nbody_counting* counter) {
+// `async`: return once everything is enqueued (for a step ahead: once the host's one decision per step is made) instead of
+// waiting for the last step; nbody_wait (or any call that reads the rows) completes it.
+template <class T> int update_tree(nbody_ctx* c, int kind, T delta, int n_steps, nbody_counting* counter, bool async = false) {
   if (!c) return NBODY_ERR_INVALID;
   if (!has_state<T>(c)) return fail(c, NBODY_ERR_INVALID, "update_tree: no particles of this precision uploaded");
   if (n_steps < 0) return fail(c, NBODY_ERR_INVALID, "update_tree: n_steps < 0");
@@ -1205,6 +1207,10 @@ template <class T> int update_tree(nbody_ctx* c, int kind, T delta, int n_steps,
     rc = phase_mark(c, ph, 3);
     if (rc) return done(rc);
     ++c->steps_done;
+  }
+  if (async) {  // the phase events and the last walk's term count are collected by nbody_wait or the next synchronous call
+    c->ph_counter = nullptr;
+    return NBODY_OK;
   }
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return done(NBODY_OK);
@@ -1860,6 +1866,20 @@ NB_API int nbody_update_tree_f32(nbody_ctx* c, int kind, float delta, int n_step
 NB_API int nbody_update_tree_f64(nbody_ctx* c, int kind, double delta, int n_steps, nbody_counting* counter) {
   if (c && c->multi) return nbody::multi_update_tree(c, true, kind, delta, n_steps, counter);
   return update_tree<double>(c, kind, delta, n_steps, counter);
+}
+// Asynchronous form of nbody_update_tree_f32 and its completion.
+NB_API int nbody_update_tree_async_f32(nbody_ctx* c, int kind, float delta, int n_steps) {
+  if (c && c->multi) return nbody::multi_update_tree(c, false, kind, (double)delta, n_steps, nullptr);  // (synchronous there)
+  return update_tree<float>(c, kind, delta, n_steps, nullptr, true);
+}
+NB_API int nbody_wait(nbody_ctx* c) {
+  if (!c) return NBODY_ERR_INVALID;
+  if (c->multi) return NBODY_OK;  // every call on a multi-device context is synchronous
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  int rc = phase_drain(c);
+  if (!rc && c->has_f32) rc = step_ahead_collect<float>(c, c->sf);
+  return rc;
 }
 static int not_on_multi(nbody_ctx* c, const char* what) {
   return fail(c, NBODY_ERR_INVALID, std::string(what) + ": a context made by nbody_create_multi shards its steps itself");

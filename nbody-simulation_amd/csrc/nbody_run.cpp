@@ -2,9 +2,10 @@
 // generator: the reference's own is unseeded) stepped through the C ABI, printing the reference's once-a-second
 // block (ups / step / Counting, main.rs:149-156).  The window and the channel of the reference are out of scope; the frame
 // its render thread paints (draw, main.rs:41-72) can be written out instead of shown.
-//   nbody_run [--gpus G] [steps=100] [bvh|quad|direct] [seed] [frame_every=0] [frame_prefix=frame] [delta_every=0]
+//   nbody_run [--gpus G] [--async] [steps=100] [bvh|quad|direct] [seed] [frame_every=0] [frame_prefix=frame] [delta_every=0]
 // --gpus G: the same world on devices 0 .. G-1 of this node behind one handle (nbody_create_multi: the step's targets are
 // sharded over them, the exchange is an RCCL all-gather inside the library); prints ms/step at the end.
+// --async: every step is `update_async` (returns once enqueued), the Counting is fetched with `wait` when it is printed.
 // frame_every = k > 0: every k-th step <frame_prefix>_<step>.pam (1250 x 1250 RGBA, Netpbm PAM) is written.
 // delta_every = k > 0: every k-th step the positions are taken as a delta stream and the two lines of the commented
 // experiment of main.rs:124-133 are printed ("raw: <bytes>" / "comp: <bytes>"); the streams are applied to a decoder and
@@ -73,6 +74,12 @@ int main(int argc, char** argv) {
     argc -= 2;
     argv += 2;
   }
+  bool async = false;
+  if (argc > 1 && !std::strcmp(argv[1], "--async")) {
+    async = true;
+    argc -= 1;
+    argv += 1;
+  }
   int steps = argc > 1 ? std::atoi(argv[1]) : 100;
   Method method = Method::Bvh;
   if (argc > 2 && !std::strcmp(argv[2], "quad")) method = Method::Quad;
@@ -93,7 +100,8 @@ int main(int argc, char** argv) {
     auto t0 = std::chrono::steady_clock::now();
     long updates = 0, last = 0;
     for (int s = 0; s < steps; ++s) {
-      world.update(0.1f, counter);                                    // main.rs:120 (STEP_SIZE)
+      if (async) world.update_async(0.1f);
+      else world.update(0.1f, counter);                               // main.rs:120 (STEP_SIZE)
       ++updates;
       if (frame_every > 0 && updates % frame_every == 0) {
         world.draw(frame);
@@ -113,6 +121,7 @@ int main(int argc, char** argv) {
       }
       auto now = std::chrono::steady_clock::now();
       if (std::chrono::duration<double>(now - t0).count() >= 1.0 || s + 1 == steps) {
+        if (async) world.wait(counter);
         std::printf("ups: %ld\nstep: %ld\nCounting { build_bvh: %.6f, sum_gravity: %.6f, post_calculations: %.6f }\n",
                     updates - last, updates, counter.build_bvh, counter.sum_gravity, counter.post_calculations);
         last = updates;

@@ -66,6 +66,21 @@ class World {
     stale_ = true;
   }
 
+  // The same step without waiting for it (nbody_update_tree_async_f32): the loop of main.rs:118-139 — update, then hand a
+  // snapshot over if the channel has room — keeps the device busy from one iteration to the next.  `wait` folds the phase
+  // times into `counter`.  (The direct path's steps are hundreds of milliseconds: it stays synchronous.)
+  void update_async(float delta) {
+    if (method_ == Method::Direct) { Counting c{}; update(delta, c); return; }
+    check(nbody_update_tree_async_f32(ctx_, method_ == Method::Bvh ? NBODY_TREE_BVH : NBODY_TREE_QUAD, delta, 1), "update_async");
+    stale_ = true;
+  }
+  void wait(Counting& counter) {
+    check(nbody_wait(ctx_), "nbody_wait");
+    Counting total{};
+    check(nbody_get_counting(ctx_, &total), "nbody_get_counting");
+    counter = total;
+  }
+
   // Brings `particles` up to date with the device (the reference's hand-off clone, main.rs:138).
   const std::vector<Particle>& snapshot() {
     if (stale_) {

@@ -49,6 +49,19 @@ class World:
         else:
             self.ctx.update_tree(_METHODS[self.method], delta, n_steps, counter)
 
+    def update_async(self, delta: float, n_steps: int = 1):
+        """The same step(s) without waiting for them (f32 tree methods; nbody_update_tree_async_f32): the reference's loop
+        — update, then hand a snapshot over if the channel has room, main.rs:118-139 — keeps the device busy from one
+        iteration to the next.  `wait()` completes them and returns the cumulative Counting."""
+        if self.method == "direct" or self.ctx.dtype != np.float32:
+            self.update(delta, None, n_steps)
+        else:
+            self.ctx.update_tree_async(_METHODS[self.method], delta, n_steps)
+
+    def wait(self) -> Counting:
+        self.ctx.wait()
+        return self.ctx.counting()
+
     def particles(self):
         """-> (position[n,2], velocity[n,2], weight[n], ids[n]); rows are in the order the reference's
         `self.particles` would be in (permuted by every BVH build); ids give each row's original index."""

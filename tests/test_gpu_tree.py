@@ -700,3 +700,33 @@ def test_device_bvh64_build_declines_what_it_cannot_express(nb, orc):
         with pytest.raises(C.NBodyError) as e:
             c.accel_tree(C.TREE_BVH, pos[:4])
         assert e.value.code == C.ERR_DEGENERATE
+
+
+def test_async_updates_equal_synchronous_ones(nb, orc):
+    """nbody_update_tree_async_f32 returns once a step is enqueued; calls that read the rows order themselves after it.  One
+    update per call, as the reference's loop makes them (main.rs:118-139), with a snapshot hand-off in between: same rows
+    as the synchronous calls, same Counting shape, and nbody_wait reports the phases."""
+    C = nb._capi
+    pos, vel, w = nb.scenes.galaxy()
+    pos, vel, w = pos[::2].copy(), vel[::2].copy(), w[::2].copy()
+    with C.Context(0) as a, C.Context(0) as b:
+        for c in (a, b):
+            c.upload(pos, vel, w)
+        snaps = []
+        for k in range(12):
+            a.update_tree(C.TREE_BVH, 0.1, 1)
+            b.update_tree_async(C.TREE_BVH, 0.1, 1)
+            if k == 6:
+                b.snapshot_begin()                       # ordered after the enqueued step, overlaps the next ones
+        snaps = b.snapshot_end()
+        assert snaps[4] == 7
+        b.wait()
+        cb = b.counting()
+        assert cb.build_bvh > 0 and cb.sum_gravity > 0 and cb.post_calculations > 0
+        assert all(np.array_equal(x, y) for x, y in zip(a.download(), b.download()))
+        b.update_tree_async(C.TREE_QUAD, 0.1, 2)         # the plain sequence, asynchronously
+        a.update_tree(C.TREE_QUAD, 0.1, 2)
+        assert all(np.array_equal(x, y) for x, y in zip(a.download(), b.download()))   # download orders itself after the steps
+        b.wait()
+    rp, rv, _, rids, _ = orc.update_bvh(pos, vel, w, delta=0.1, theta=50.0, mode=orc.AS_WRITTEN, nsteps=7, nthreads=16)
+    assert np.array_equal(snaps[3], rids) and np.array_equal(snaps[0], rp) and np.array_equal(snaps[1], rv)
