@@ -324,6 +324,9 @@ int nbody_selftest_exact_sum(const float* x, int64_t n, int tile, int seq_run, f
 int nbody_selftest_exact_sum_chunked(const float* x, int64_t n, int chunk, float* out_sum, int64_t* out_runs_used);
 /* The f64 twin (csrc/exact_sum64.h: 53-bit significands, 64-bit increments), which the device build of f64 BVHs runs. */
 int nbody_selftest_exact_sum_f64(const double* x, int64_t n, int tile, int seq_run, double* out_sum, int64_t* out_restarts);
+/* ... and its segmented form for long chains (runs prepared per segment for a predicted binade, used only when the
+ * prediction and the run's bounds hold for the true state); *out_runs_used counts the runs that were applied. */
+int nbody_selftest_exact_sum_f64_segmented(const double* x, int64_t n, int seg, double* out_sum, int64_t* out_runs_used);
 /* Restarts of that scan during the last device BVH build of this context (diagnostic; 0 after a host build). */
 int nbody_bvh_build_restarts(const nbody_ctx* ctx);
 /* 1 if the last tree build of this context ran on the device, 0 if the host builder did it (the device builders

@@ -116,6 +116,7 @@ _SIGS = {
     "nbody_render_rgba_dev": (C.c_int, [_vp, C.c_int64, C.c_int, _vp, _vp, _vp, C.c_uint32, C.c_uint32, _vp, _vp]),
     "nbody_selftest_exact_sum": (C.c_int, [_vp, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int64)]),
     "nbody_selftest_exact_sum_f64": (C.c_int, [_vp, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "nbody_selftest_exact_sum_f64_segmented": (C.c_int, [_vp, C.c_int64, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "nbody_selftest_exact_sum_chunked": (C.c_int, [_vp, C.c_int64, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int64)]),
     "nbody_bvh_build_restarts": (C.c_int, [_vp]),
     "nbody_last_build_on_device": (C.c_int, [_vp]),
@@ -233,6 +234,14 @@ def selftest_exact_sum_f64(x, tile=4096, seq_run=16):
     check(None, load().nbody_selftest_exact_sum_f64(_ptr(x) if x.size else None, x.size, int(tile), int(seq_run),
                                                     C.byref(out), C.byref(st)))
     return np.float64(out.value), st.value
+
+
+def selftest_exact_sum_f64_segmented(x, seg=8192):
+    """CPU emulation of the segmented f64 fold (runs per segment, predicted binades) -> (sum, runs applied)."""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    out, used = C.c_double(0), _i64(0)
+    check(None, load().nbody_selftest_exact_sum_f64_segmented(_ptr(x) if x.size else None, x.size, int(seg), C.byref(out), C.byref(used)))
+    return np.float64(out.value), used.value
 
 
 def selftest_exact_sum_chunked(x, chunk=2048):

@@ -14,12 +14,13 @@ enum : int {
   kB64NodeCount = 1,  // nodes made so far (breadth-first ids)
   kB64MaxDepth = 2,
   kB64Stops = 3,      // restarts of the exact-sum scan (diagnostic)
+  kB64RunsUsed = 4,   // segments of long chains whose prepared run was applied (diagnostic)
   kB64FlagWords = 16,
 };
 
 struct Bvh64Layout {
-  int node_cap, open_cap, chunk_cap;
-  size_t flags, opencount, chunkcount, zero_end, P, ID, nbegin, nlen, ndepth, nchild, nleaf, ncx, ncy, nsplit, naxis, nk, nchunk0, nsub, npre,
+  int node_cap, open_cap, chunk_cap, seg_cap;
+  size_t flags, opencount, chunkcount, segcount, zero_end, nseg0, seg_node, seg_index, seg_sum, seg_min, seg_max, seg_prefix, seg_pred, seg_run, P, ID, nbegin, nlen, ndepth, nchild, nleaf, ncx, ncy, nsplit, naxis, nk, nchunk0, nsub, npre,
       nsum, nmin, nmax, nmean, ncog, nmass, openq, ch_node, ch_index, ch_l, ch_r, ch_loff, ch_roff, lidx, ridx, total;
 };
 Bvh64Layout bvh64_layout(int64_t n, int leaf_size);

@@ -56,7 +56,13 @@ struct Ptrs {
   int* openq;       // [level & 1][open_cap]
   int *ch_node, *ch_index, *ch_l, *ch_r, *ch_loff, *ch_roff;  // the current level's chunk table
   uint32_t *lidx, *ridx;
-  int node_cap, open_cap, chunk_cap, n;
+  // long nodes (> kLongNode points): their chains cut into kSeg-addend segments with a prepared run each
+  int* segcount;  // [level]
+  int *nseg0, *seg_node, *seg_index;
+  double2 *seg_sum, *seg_min, *seg_max, *seg_prefix;
+  uint64_t* seg_pred;       // [seg][coord]: predicted (sign << 32 | E), 0 = no run
+  xsum64::Run* seg_run;     // [seg][coord]
+  int node_cap, open_cap, chunk_cap, seg_cap, n;
 };
 
 Ptrs make_ptrs(char* s, const Bvh64Layout& L, int n) {
@@ -77,7 +83,13 @@ Ptrs make_ptrs(char* s, const Bvh64Layout& L, int n) {
   a.ch_node = (int*)(s + L.ch_node); a.ch_index = (int*)(s + L.ch_index); a.ch_l = (int*)(s + L.ch_l); a.ch_r = (int*)(s + L.ch_r);
   a.ch_loff = (int*)(s + L.ch_loff); a.ch_roff = (int*)(s + L.ch_roff);
   a.lidx = (uint32_t*)(s + L.lidx); a.ridx = (uint32_t*)(s + L.ridx);
-  a.node_cap = L.node_cap; a.open_cap = L.open_cap; a.chunk_cap = L.chunk_cap; a.n = n;
+  a.segcount = (int*)(s + L.segcount);
+  a.nseg0 = (int*)(s + L.nseg0); a.seg_node = (int*)(s + L.seg_node); a.seg_index = (int*)(s + L.seg_index);
+  a.seg_sum = (double2*)(s + L.seg_sum); a.seg_min = (double2*)(s + L.seg_min); a.seg_max = (double2*)(s + L.seg_max);
+  a.seg_prefix = (double2*)(s + L.seg_prefix);
+  a.seg_pred = (uint64_t*)(s + L.seg_pred);
+  a.seg_run = (xsum64::Run*)(s + L.seg_run);
+  a.node_cap = L.node_cap; a.open_cap = L.open_cap; a.chunk_cap = L.chunk_cap; a.seg_cap = L.seg_cap; a.n = n;
   return a;
 }
 
@@ -109,6 +121,133 @@ __global__ __launch_bounds__(256) void b64_init(Ptrs a, const double2* __restric
 
 // ---- per level -------------------------------------------------------------------------------------------------------
 constexpr int kSmallNode = 256;  // nodes up to this long are folded by one thread per coordinate, in order (b64_fold_small)
+constexpr int kSeg = 8192;        // a long node's chain is cut into segments of this many addends (= the fold's tile), ...
+constexpr int kLongNode = 65536;  // ... long meaning more points than this: their runs are prepared by the whole chip
+
+// ---- long nodes: the chain's segments prepared in parallel ---------------------------------------------------------------
+// One work-group walks a long node's chain (b64_fold below), ~10 us per 8192-addend scan round on its one compute unit: 5 ms
+// for a 4 M-point root.  But a segment's effect on the chain — the map {state at its start} -> {state at its end} — can be
+// prepared by any other work-group beforehand, IF it is told which binade the chain will be in: that is predicted from
+// plain f64 partial sums, and the run carries the bounds that prove, when it is applied, that every add inside stayed in
+// that binade (exact_sum64.h: Run, run_fits).  A wrong prediction or a crossing costs that segment's scan, never a bit.
+__global__ __launch_bounds__(64) void b64_seg_plan(Ptrs a, int level) {
+  const int nopen = a.opencount[level] < a.open_cap ? a.opencount[level] : a.open_cap;
+  const int lane = threadIdx.x;
+  for (int q = blockIdx.x; q < nopen; q += gridDim.x) {
+    const int node = a.openq[(size_t)(level & 1) * a.open_cap + q];
+    const int len = a.nlen[node];
+    const int ns = len > kLongNode ? len / kSeg : 0;  // whole segments only: the tail is scanned
+    int s0 = -1;
+    if (lane == 0) {
+      if (ns > 0) {
+        s0 = atomicAdd(&a.segcount[level], ns);
+        if (s0 + ns > a.seg_cap) s0 = -1;  // (cannot happen: the table holds every whole segment of a level)
+      }
+      a.nseg0[node] = s0;
+    }
+    s0 = __shfl(s0, 0, 64);
+    if (s0 >= 0)
+      for (int k = lane; k < ns; k += 64) {
+        a.seg_node[s0 + k] = node;
+        a.seg_index[s0 + k] = k;
+      }
+  }
+}
+
+// plain f64 sum (any order: it only predicts), min and max of every segment
+__global__ __launch_bounds__(512) void b64_seg_sums(Ptrs a, int level) {
+  __shared__ double red[3][8];
+  const int nseg = a.segcount[level] < a.seg_cap ? a.segcount[level] : a.seg_cap;
+  const int comp = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int sg = blockIdx.x; sg < nseg; sg += gridDim.x) {
+    const int node = a.seg_node[sg], k = a.seg_index[sg];
+    const double* __restrict__ X = reinterpret_cast<const double*>(a.P + a.nbegin[node] + (size_t)k * kSeg) + comp;
+    double sum = 0.0, mn = kMaxD, mx = 0.0;
+    for (int e = tid; e < kSeg; e += 512) {
+      const double v = X[2 * (size_t)e];
+      sum += v;
+      mn = sse_min(mn, v);
+      mx = sse_max(mx, v);
+    }
+    for (int d = 32; d >= 1; d >>= 1) {
+      sum += __shfl_xor(sum, d, 64);
+      mn = sse_min(mn, __shfl_xor(mn, d, 64));
+      mx = sse_max(mx, __shfl_xor(mx, d, 64));
+    }
+    if (lane == 0) { red[0][wave] = sum; red[1][wave] = mn; red[2][wave] = mx; }
+    __syncthreads();
+    if (tid == 0) {
+      for (int w = 1; w < 8; ++w) { sum += red[0][w]; mn = sse_min(mn, red[1][w]); mx = sse_max(mx, red[2][w]); }
+      if (comp == 0) { a.seg_sum[sg].x = sum; a.seg_min[sg].x = mn; a.seg_max[sg].x = mx; }
+      else { a.seg_sum[sg].y = sum; a.seg_min[sg].y = mn; a.seg_max[sg].y = mx; }
+    }
+    __syncthreads();
+  }
+}
+
+// the predicted value of the chain at the start of every segment: a thread per long node and coordinate
+__global__ __launch_bounds__(64) void b64_seg_prefix(Ptrs a, int level) {
+  const int nopen = a.opencount[level] < a.open_cap ? a.opencount[level] : a.open_cap;
+  const int t = blockIdx.x * 64 + threadIdx.x;
+  const int q = t >> 1, comp = t & 1;
+  if (q >= nopen) return;
+  const int node = a.openq[(size_t)(level & 1) * a.open_cap + q];
+  const int s0 = a.nseg0[node];
+  if (s0 < 0) return;
+  const int ns = a.nlen[node] / kSeg;
+  double p = 0.0;
+  for (int k = 0; k < ns; ++k) {
+    if (comp == 0) { a.seg_prefix[s0 + k].x = p; p += a.seg_sum[s0 + k].x; }
+    else { a.seg_prefix[s0 + k].y = p; p += a.seg_sum[s0 + k].y; }
+  }
+}
+
+__device__ __forceinline__ int64_t shfl_up_i64(int64_t v, int d) { return (int64_t)shfl_up_u64((uint64_t)v, d); }
+__device__ __forceinline__ xsum64::Run shfl_up_run(const xsum64::Run& r, int d) {
+  xsum64::Run o;
+  for (int p = 0; p < 2; ++p) { o.a[p] = shfl_up_i64(r.a[p], d); o.lo[p] = shfl_up_i64(r.lo[p], d); o.hi[p] = shfl_up_i64(r.hi[p], d); }
+  return o;
+}
+
+// the run of every segment, for the binade its two ends are predicted to lie in
+__global__ __launch_bounds__(512) void b64_seg_runs(Ptrs a, int level) {
+  __shared__ double stage[kSeg + kSeg / 16];
+  __shared__ xsum64::Run wrun[8];
+  const int nseg = a.segcount[level] < a.seg_cap ? a.segcount[level] : a.seg_cap;
+  const int comp = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int sg = blockIdx.x; sg < nseg; sg += gridDim.x) {
+    const double p0 = comp == 0 ? a.seg_prefix[sg].x : a.seg_prefix[sg].y;
+    const double p1 = p0 + (comp == 0 ? a.seg_sum[sg].x : a.seg_sum[sg].y);
+    xsum64::Chain c;
+    if (!xsum64::predict_binade(p0, p1, c)) {  // (uniform) the chain's start, a crossing, a sum near zero: scanned by the fold
+      if (tid == 0) a.seg_pred[2 * (size_t)sg + comp] = 0;
+      continue;
+    }
+    const int node = a.seg_node[sg], k = a.seg_index[sg];
+    const double* __restrict__ X = reinterpret_cast<const double*>(a.P + a.nbegin[node] + (size_t)k * kSeg) + comp;
+    for (int e = tid; e < kSeg; e += 512) stage[e + (e >> 4)] = X[2 * (size_t)e];
+    __syncthreads();
+    xsum64::Run r = xsum64::run_none();
+#pragma unroll 4
+    for (int j = 0; j < 16; ++j) {
+      const int e = tid * 16 + j;
+      r = xsum64::run_then(r, xsum64::run_of(xsum64::step_of(stage[e + (e >> 4)], c.sign, c.E)));
+    }
+    for (int d = 1; d < 64; d <<= 1) {  // in thread order: lane 63 ends up with the wave's run
+      const xsum64::Run o = shfl_up_run(r, d);
+      if (lane >= d) r = xsum64::run_then(o, r);
+    }
+    if (lane == 63) wrun[wave] = r;
+    __syncthreads();
+    if (tid == 0) {
+      xsum64::Run t = wrun[0];
+      for (int w = 1; w < 8; ++w) t = xsum64::run_then(t, wrun[w]);
+      a.seg_run[2 * (size_t)sg + comp] = t;
+      a.seg_pred[2 * (size_t)sg + comp] = (c.sign << 32) | c.E;
+    }
+    __syncthreads();
+  }
+}
 
 // One coordinate of the fold of bvh_tree.rs:58-61 over a node: min, max and the sum exactly as the sequential chain rounds it.
 // A scan round covers TILE = NT * EPT consecutive addends: they are fetched coalesced (the rows are double2: a thread reading
@@ -132,6 +271,7 @@ __global__ __launch_bounds__(NT) void b64_fold(Ptrs a, int level) {
     double mn = kMaxD, mx = 0.0;  // min from f64::MAX, max from 0.0 (bvh_tree.rs:59): order-free without NaNs
     double s = 0.0;               // the chain; uniform across the group
     int pos = 0, stops = 0;
+    const int seg0 = (TILE == kSeg && len > kLongNode) ? a.nseg0[node] : -1;  // this node's prepared segments, if any
     while (pos < len) {
       xsum64::Chain c;
       if (!xsum64::chain_open(s, c)) {  // not inside a binade (zero, subnormal, a power of two, non-finite): real adds
@@ -146,7 +286,27 @@ __global__ __launch_bounds__(NT) void b64_fold(Ptrs a, int level) {
         pos += cnt;
         continue;
       }
-      const int cnt = len - pos < TILE ? len - pos : TILE;
+      int cnt = len - pos < TILE ? len - pos : TILE;
+      if (seg0 >= 0) {
+        const int in_seg = pos & (kSeg - 1);
+        if (in_seg == 0 && pos + kSeg <= len) {  // a whole prepared segment: if its run holds from here, take it in one step
+          const size_t sg = 2 * (size_t)(seg0 + (pos >> 13)) + comp;
+          static_assert(kSeg == 1 << 13, "pos >> 13 is the segment index");
+          if (a.seg_pred[sg] == ((c.sign << 32) | c.E)) {
+            const xsum64::Run r = a.seg_run[sg];
+            if (xsum64::run_fits(c.S, r)) {
+              s = xsum64::chain_value(c, (uint64_t)((int64_t)c.S + r.a[c.S & 1ull]));
+              const double2 smn = a.seg_min[sg >> 1], smx = a.seg_max[sg >> 1];
+              mn = sse_min(mn, comp == 0 ? smn.x : smn.y);
+              mx = sse_max(mx, comp == 0 ? smx.x : smx.y);
+              pos += kSeg;
+              if (tid == 0) atomicAdd(&a.flags[kB64RunsUsed], 1);
+              continue;
+            }
+          }
+        }
+        if (cnt > kSeg - in_seg) cnt = kSeg - in_seg;  // stay aligned with the segments
+      }
       const int end = pos + cnt;
       for (int e = tid; e < cnt; e += NT) stage[e + (e >> 4)] = X[2 * (size_t)(pos + e)];
       if (tid == 0) sh_bad = INT_MAX;
@@ -619,7 +779,15 @@ Bvh64Layout bvh64_layout(int64_t n, int leaf_size) {
   L.flags = take(sizeof(int) * kB64FlagWords);
   L.opencount = take(sizeof(int) * (kB64Levels + 2));
   L.chunkcount = take(sizeof(int) * (kB64Levels + 2));
+  L.segcount = take(sizeof(int) * (kB64Levels + 2));
   L.zero_end = off;
+  const size_t SC = N / (size_t)kSeg + N / (size_t)kLongNode + 8;  // whole segments of the long nodes of one level
+  L.seg_cap = (int)SC;
+  L.nseg0 = take(4 * C);
+  L.seg_node = take(4 * SC); L.seg_index = take(4 * SC);
+  L.seg_sum = take(16 * SC); L.seg_min = take(16 * SC); L.seg_max = take(16 * SC); L.seg_prefix = take(16 * SC);
+  L.seg_pred = take(16 * SC);
+  L.seg_run = take(2 * sizeof(xsum64::Run) * SC);
   L.P = take(16 * N);
   L.ID = take(4 * N);
   L.nbegin = take(4 * C); L.nlen = take(4 * C); L.ndepth = take(4 * C); L.nchild = take(4 * C); L.nleaf = take(4 * C);
@@ -661,6 +829,13 @@ hipError_t bvh64_levels(hipStream_t s, int n, int leaf_size, int level_begin, in
     // the fold: a scan round covers 16 addends per thread — 512 threads (8192 addends) for the few long chains of the top
     // levels, 256 below; nodes of <= 256 points are added in order, a thread per node and coordinate
     const int64_t gbig = std::min<int64_t>(go, (int64_t)n / kSmallNode + 1);  // blocks stride over the queue: this many is plenty
+    if (width <= 32 && n > kLongNode) {  // long chains (they only occur up here): their segments' runs first, on the whole chip
+      const int64_t gs = std::min<int64_t>(L.seg_cap, 4096);
+      b64_seg_plan<<<dim3((unsigned)go), dim3(64), 0, s>>>(a, level);
+      b64_seg_sums<<<dim3((unsigned)gs, 2), dim3(512), 0, s>>>(a, level);
+      b64_seg_prefix<<<dim3((unsigned)((2 * go + 63) / 64)), dim3(64), 0, s>>>(a, level);
+      b64_seg_runs<<<dim3((unsigned)gs, 2), dim3(512), 0, s>>>(a, level);
+    }
     if (width <= 32) b64_fold<512, 16><<<dim3((unsigned)gbig, 2), dim3(512), 0, s>>>(a, level);
     else b64_fold<256, 16><<<dim3((unsigned)gbig, 2), dim3(256), 0, s>>>(a, level);
     b64_fold_small<<<dim3((unsigned)((2 * go + 255) / 256)), dim3(256), 0, s>>>(a, level);

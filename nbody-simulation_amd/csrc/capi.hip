@@ -518,8 +518,8 @@ int bvh_build_device64(nbody_ctx* c, State<double>& s) {
     if (rc) return rc;
   }
   if (env_int("NBODY_TRACE", 0) != 0)
-    std::fprintf(stderr, "[nbody] device bvh build (f64): %d nodes, depth %d, %d levels enqueued, %d scan restarts, fallback %d\n",
-                 hostf[kB64NodeCount], hostf[kB64MaxDepth], lv_end, hostf[kB64Stops], hostf[kB64Fallback]);
+    std::fprintf(stderr, "[nbody] device bvh build (f64): %d nodes, depth %d, %d levels enqueued, %d scan restarts, %d prepared runs used, fallback %d\n",
+                 hostf[kB64NodeCount], hostf[kB64MaxDepth], lv_end, hostf[kB64Stops], hostf[kB64RunsUsed], hostf[kB64Fallback]);
   const int m = hostf[kB64NodeCount];
   if (hostf[kB64Fallback] != 0 || m <= 0 || m > L.node_cap) return 1;
   GatherArgs<double> g{};  // rows into tree order, as the in-place partition leaves `self.particles` (bvh_tree.rs:73-77)
@@ -2043,6 +2043,11 @@ NB_API int nbody_selftest_exact_sum_chunked(const float* x, int64_t n, int chunk
 NB_API int nbody_selftest_exact_sum_f64(const double* x, int64_t n, int tile, int seq_run, double* out_sum, int64_t* out_restarts) {
   if ((!x && n > 0) || n < 0 || tile < 1 || seq_run < 1 || !out_sum) return NBODY_ERR_INVALID;
   *out_sum = xsum64::emulate_fold(x, n, tile, seq_run, out_restarts);
+  return NBODY_OK;
+}
+NB_API int nbody_selftest_exact_sum_f64_segmented(const double* x, int64_t n, int seg, double* out_sum, int64_t* out_runs_used) {
+  if ((!x && n > 0) || n < 0 || seg < 1 || !out_sum) return NBODY_ERR_INVALID;
+  *out_sum = xsum64::emulate_fold_segmented(x, n, seg, out_runs_used);
   return NBODY_OK;
 }
 NB_API int nbody_bvh_build_restarts(const nbody_ctx* ctx) {

@@ -78,6 +78,78 @@ NB_HD64 Step compose(Step f, Step g) {
   return h;
 }
 
+// ---- whole runs of addends, so that a long chain can be cut into segments that are prepared in parallel ----------------
+// (exact_sum.h's Run with 64-bit words.)  A run seen from a chain in one binade: the total increment of S and the extremes
+// of every intermediate S, relative to the S the run starts from, for an even (index 0) / odd (1) start.  If
+// S + lo > 2^52 and S + hi < 2^53 for the actual start, every add of the run stayed in the binade and S + a is the exact
+// result.  Saturating at +-2^60: beyond that a run is unusable anyway (a poison step is 2^62, saturated on entry).
+struct Run {
+  int64_t a[2], lo[2], hi[2];
+};
+constexpr int64_t kRunSat = 1ll << 60;  // two saturated values still add without wrapping
+NB_HD64 int64_t run_sat(int64_t v) { return v > kRunSat ? kRunSat : (v < -kRunSat ? -kRunSat : v); }
+NB_HD64 Run run_of(Step f) {
+  Run r;
+  r.a[0] = r.lo[0] = r.hi[0] = run_sat((int64_t)f.a0);
+  r.a[1] = r.lo[1] = r.hi[1] = run_sat((int64_t)f.a1);
+  return r;
+}
+NB_HD64 Run run_none() { return Run{{0, 0}, {0, 0}, {0, 0}}; }
+// f first, then g
+NB_HD64 Run run_then(const Run& f, const Run& g) {
+  Run h;
+  for (int p = 0; p < 2; ++p) {
+    const int q = (int)((p + f.a[p]) & 1);
+    const int64_t ga = q ? g.a[1] : g.a[0], glo = q ? g.lo[1] : g.lo[0], ghi = q ? g.hi[1] : g.hi[0];
+    h.a[p] = run_sat(f.a[p] + ga);
+    const int64_t gl = run_sat(f.a[p] + glo), gh = run_sat(f.a[p] + ghi);
+    h.lo[p] = f.lo[p] < gl ? f.lo[p] : gl;
+    h.hi[p] = f.hi[p] > gh ? f.hi[p] : gh;
+  }
+  return h;
+}
+NB_HD64 bool run_fits(uint64_t S, const Run& r) {
+  const int p = (int)(S & 1ull);
+  return (int64_t)S + r.lo[p] > (int64_t)kLo && (int64_t)S + r.hi[p] < (int64_t)kHi;
+}
+// The binade a chain is predicted to be in over a segment whose exact prefix sums start at `p0` and end at `p1` (any f64
+// evaluation of them: the prediction only has to be right often, the run's own bounds decide): both ends inside one binade
+// and at least 2^-20 (relatively) away from its edges.  false: no run is prepared for the segment.
+NB_HD64 bool predict_binade(double p0, double p1, Chain& c) {
+  Chain c1;
+  if (!chain_open(p0, c) || !chain_open(p1, c1) || c.E != c1.E || c.sign != c1.sign) return false;
+  const uint64_t margin = 1ull << 32;  // 2^-20 of the binade's 2^52 steps
+  return c.S > kLo + margin && c.S < kHi - margin && c1.S > kLo + margin && c1.S < kHi - margin;
+}
+
+// CPU emulation of the segmented fold (bvh_build64.hip: b64_seg_sums / b64_seg_runs / the segment test of b64_fold): every
+// `seg`-long segment's run is prepared for the binade its ends are PREDICTED to be in (from plain f64 partial sums); the
+// walk uses a run only if the prediction and the run's bounds hold for the true state, and scans the segment otherwise.
+inline double emulate_fold_segmented(const double* x, int64_t n, int seg, int64_t* used_runs) {
+  double s = 0.0, prefix = 0.0;
+  int64_t used = 0;
+  for (int64_t c0 = 0; c0 < n; c0 += seg) {
+    const int64_t c1 = c0 + seg < n ? c0 + seg : n;
+    double total = 0.0;
+    for (int64_t k = c0; k < c1; ++k) total += x[k];
+    Chain pred;
+    const bool have = c1 - c0 == seg && predict_binade(prefix, prefix + total, pred);
+    Run r = run_none();
+    if (have)
+      for (int64_t k = c0; k < c1; ++k) r = run_then(r, run_of(step_of(x[k], pred.sign, pred.E)));
+    Chain cur;
+    if (have && chain_open(s, cur) && cur.E == pred.E && cur.sign == pred.sign && run_fits(cur.S, r)) {
+      s = chain_value(cur, (uint64_t)((int64_t)cur.S + r.a[cur.S & 1ull]));
+      ++used;
+    } else {
+      for (int64_t k = c0; k < c1; ++k) s = s + x[k];
+    }
+    prefix += total;
+  }
+  if (used_runs) *used_runs = used;
+  return s;
+}
+
 // CPU emulation of the device fold's control flow (bvh_build64.hip, fold64: `tile` addends scanned at once, `seq_run` real
 // adds after a stop), to check the functions above against the plain loop.  Returns the sum; *stops counts the restarts.
 inline double emulate_fold(const double* x, int64_t n, int tile, int seq_run, int64_t* stops) {

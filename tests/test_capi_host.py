@@ -255,6 +255,35 @@ def test_exact_sum_scan_f64_reproduces_the_sequential_chain(nb, tile, seq_run):
         assert _bits64(got) == _bits64(want) or (np.isnan(got) and np.isnan(want)), (name, got, want)
 
 
+@pytest.mark.parametrize("seg", [8192, 64, 8])
+def test_segmented_exact_sum_f64_reproduces_the_sequential_chain(nb, seg):
+    """Long f64 chains are cut into segments whose runs are prepared for a predicted binade; a run may only be used when
+    the prediction and its bounds hold for the true state, so the result is the plain loop's whatever the data — and on
+    ordinary coordinates nearly every segment's run is used."""
+    C = nb._capi
+    rng = np.random.default_rng(141)
+    cases = {}
+    for n in (0, 1, 65, 5000, 200003):
+        cases[f"uniform{n}"] = rng.random(n) * 1e5
+        cases[f"negative{n}"] = -rng.random(n) * 1e5
+        cases[f"centred{n}"] = rng.standard_normal(n) * 3e4
+        cases[f"f32grid{n}"] = (rng.random(n) * 1e5).astype(np.float32).astype(np.float64)
+        cases[f"halves_pm{n}"] = rng.integers(-1000, 1000, n) * 0.5
+        cases[f"wide{n}"] = 10.0 ** rng.uniform(-100, 100, n) * rng.choice([-1.0, 1.0], n)
+        cases[f"tiny_ulps{n}"] = 1.0 + rng.integers(-3, 4, n) * 2.0 ** -53
+    for name, bad in (("inf", np.inf), ("nan", np.nan), ("big", 1.7e308)):
+        x = rng.random(50000) * 1e5
+        x[25000] = bad
+        cases[name] = x
+    for name, x in cases.items():
+        x = np.asarray(x, np.float64)
+        got, used = C.selftest_exact_sum_f64_segmented(x, seg)
+        want = _seq_sum_f64(x)
+        assert _bits64(got) == _bits64(want) or (np.isnan(got) and np.isnan(want)), (name, got, want)
+        if name == "uniform200003":
+            assert used >= (200003 // seg) * 0.7, used        # all but the segments in which the sum crosses a power of two
+
+
 def test_exact_sum_scan_f64_random_bit_patterns(nb):
     C = nb._capi
     rng = np.random.default_rng(5)
