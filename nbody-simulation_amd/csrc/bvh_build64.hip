@@ -120,6 +120,8 @@ __global__ __launch_bounds__(256) void b64_init(Ptrs a, const double2* __restric
 }
 
 // ---- per level -------------------------------------------------------------------------------------------------------
+constexpr int kWideLevels = 32;   // levels with at most this many nodes may hold long ones: 8192-addend tiles, prepared segments
+                                  // (kLongNode 16384 / 512 levels measured no better: 10.7 vs 10.2 ms at N = 4 M)
 constexpr int kSmallNode = 256;  // nodes up to this long are folded by one thread per coordinate, in order (b64_fold_small)
 constexpr int kSeg = 8192;        // a long node's chain is cut into segments of this many addends (= the fold's tile), ...
 constexpr int kLongNode = 65536;  // ... long meaning more points than this: their runs are prepared by the whole chip
@@ -829,14 +831,14 @@ hipError_t bvh64_levels(hipStream_t s, int n, int leaf_size, int level_begin, in
     // the fold: a scan round covers 16 addends per thread — 512 threads (8192 addends) for the few long chains of the top
     // levels, 256 below; nodes of <= 256 points are added in order, a thread per node and coordinate
     const int64_t gbig = std::min<int64_t>(go, (int64_t)n / kSmallNode + 1);  // blocks stride over the queue: this many is plenty
-    if (width <= 32 && n > kLongNode) {  // long chains (they only occur up here): their segments' runs first, on the whole chip
+    if (width <= kWideLevels && n > kLongNode) {  // long chains (they only occur up here): their segments' runs first, on the whole chip
       const int64_t gs = std::min<int64_t>(L.seg_cap, 4096);
       b64_seg_plan<<<dim3((unsigned)go), dim3(64), 0, s>>>(a, level);
       b64_seg_sums<<<dim3((unsigned)gs, 2), dim3(512), 0, s>>>(a, level);
       b64_seg_prefix<<<dim3((unsigned)((2 * go + 63) / 64)), dim3(64), 0, s>>>(a, level);
       b64_seg_runs<<<dim3((unsigned)gs, 2), dim3(512), 0, s>>>(a, level);
     }
-    if (width <= 32) b64_fold<512, 16><<<dim3((unsigned)gbig, 2), dim3(512), 0, s>>>(a, level);
+    if (width <= kWideLevels) b64_fold<512, 16><<<dim3((unsigned)gbig, 2), dim3(512), 0, s>>>(a, level);
     else b64_fold<256, 16><<<dim3((unsigned)gbig, 2), dim3(256), 0, s>>>(a, level);
     b64_fold_small<<<dim3((unsigned)((2 * go + 255) / 256)), dim3(256), 0, s>>>(a, level);
     const bool by_wave = width <= 64;  // a wave per open node while nodes are few and long, a thread per node after
