@@ -263,3 +263,33 @@ def test_config5_as_stated_rehearsed_on_one_gpu(nb, orc):
     rel = (err - slack) / norm
     print(f"[config 5 on one GPU] e_gpu on {len(tg)} sampled targets: median {np.median(err / norm):.2e} max {(err / norm).max():.2e}")
     assert np.all(rel <= ACC_RTOL), float(rel.max())
+
+
+def test_contexts_give_their_device_memory_back(nb):
+    """Create, step (direct, BVH ahead of the host, quad, f64 BVH on the device), destroy — thirty times, single-device and
+    multi-device: the device's free memory ends where it started (events, streams, pinned buffers, workers included)."""
+    import torch
+    C = nb._capi
+    pos, vel, w = nb.scenes.plummer(30000, seed=308)
+    p64, v64 = pos.astype(np.float64), vel.astype(np.float64)
+
+    def cycle(make):
+        with make() as c:
+            c.upload(pos, vel, w)
+            c.update_direct(0.1, 2)
+            c.update_tree(C.TREE_BVH, 0.1, 3)
+            c.update_tree(C.TREE_QUAD, 0.1, 1)
+            c.snapshot_begin()
+            c.snapshot_end()
+            c.upload(p64, v64, w)
+            c.update_tree(C.TREE_BVH, 0.1, 2)
+
+    for make in (lambda: C.Context(0), lambda: C.MultiContext([0, 0, 0], C.EXCHANGE_PEER, 2), lambda: C.MultiContext([0], C.EXCHANGE_RCCL)):
+        cycle(make)                                     # first use: lazily created runtime state (RCCL, code objects) stays
+        torch.cuda.synchronize()
+        free0, _ = torch.cuda.mem_get_info(0)
+        for _ in range(30):
+            cycle(make)
+        torch.cuda.synchronize()
+        free1, _ = torch.cuda.mem_get_info(0)
+        assert free0 - free1 < 64 << 20, (free0 - free1) / 2**20
