@@ -2105,6 +2105,9 @@ int ctx_fail(nbody_ctx* c, int code, const std::string& msg) { return fail(c, co
 int ctx_upload(nbody_ctx* c, bool f64, int64_t n, const void* pos, const void* vel, const uint32_t* w) {
   return f64 ? upload<double>(c, n, (const double*)pos, (const double*)vel, w) : upload<float>(c, n, (const float*)pos, (const float*)vel, w);
 }
+int ctx_update_tree(nbody_ctx* c, bool f64, int kind, double delta, int n_steps, nbody_counting* counter) {
+  return f64 ? update_tree<double>(c, kind, delta, n_steps, counter) : update_tree<float>(c, kind, (float)delta, n_steps, counter);
+}
 int ctx_update_tree_shard(nbody_ctx* c, bool f64, int kind, double delta, int64_t begin, int64_t count, nbody_counting* counter) {
   return f64 ? update_tree_shard<double>(c, kind, delta, begin, count, counter)
              : update_tree_shard<float>(c, kind, (float)delta, begin, count, counter);

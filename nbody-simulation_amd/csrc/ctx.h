@@ -177,6 +177,7 @@ int ctx_fail(nbody_ctx* c, int code, const std::string& msg);  // c == NULL: the
 int ctx_create_single(nbody_ctx** out, int device_id);
 void ctx_destroy_single(nbody_ctx* c);
 int ctx_upload(nbody_ctx* c, bool f64, int64_t n, const void* pos, const void* vel, const uint32_t* w);
+int ctx_update_tree(nbody_ctx* c, bool f64, int kind, double delta, int n_steps, nbody_counting* counter);  // the single-device call
 int ctx_update_tree_shard(nbody_ctx* c, bool f64, int kind, double delta, int64_t begin, int64_t count, nbody_counting* counter);
 int ctx_export_slice(nbody_ctx* c, int64_t begin, int64_t count, void* rows, void* pos, void* vel);
 int ctx_import_rows(nbody_ctx* c, int64_t n_rows, const void* rows, const void* pos, const void* vel);

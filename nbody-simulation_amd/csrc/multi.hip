@@ -583,6 +583,23 @@ int multi_update_tree(nbody_ctx* front, bool f64, int kind, double delta, int n_
   nbody_ctx* p = nullptr;
   int rc = multi_primary(front, &p);  // whole rows on every device before the trees are built
   if (rc) return rc;
+  if (M.G == 1 && env_int("NBODY_MULTI_FORCE_EXCHANGE", 0) == 0) {
+    // one device: nothing to shard or exchange — the single-device step driver, steps ahead of the host and all (the
+    // tests set NBODY_MULTI_FORCE_EXCHANGE=1 to push a lone rank through the sliced step and its one-rank all-gather)
+    nbody_counting c1{};
+    rc = ctx_update_tree(p, f64, kind, delta, n_steps, &c1);
+    if (rc) { front->err = p->err; return rc; }
+    front->counting.build_bvh += c1.build_bvh;
+    front->counting.sum_gravity += c1.sum_gravity;
+    front->counting.post_calculations += c1.post_calculations;
+    if (counter) {
+      counter->build_bvh += c1.build_bvh;
+      counter->sum_gravity += c1.sum_gravity;
+      counter->post_calculations += c1.post_calculations;
+    }
+    front->steps_done += (uint64_t)n_steps;
+    return NBODY_OK;
+  }
   nbody_counting c0{};
   double exchange_s = 0.0;
   int who = 0;

@@ -62,8 +62,9 @@ def test_one_device_rccl_direct_bit_identical(nb, n):
 
 @pytest.mark.parametrize("kind_name,dtype,order", [("bvh", F32, "as_written"), ("bvh", F32, "consistent"), ("quad", F32, "consistent"),
                                                    ("quad", np.float64, "consistent"), ("bvh", np.float64, "as_written")])
-def test_one_device_rccl_tree_bit_identical(nb, kind_name, dtype, order):
+def test_one_device_rccl_tree_bit_identical(nb, monkeypatch, kind_name, dtype, order):
     C = nb._capi
+    monkeypatch.setenv("NBODY_MULTI_FORCE_EXCHANGE", "1")   # the sliced step + the one-rank all-gather, not the shortcut
     kind = C.TREE_BVH if kind_name == "bvh" else C.TREE_QUAD
     n = 30011
     pos, vel, _ = nb.scenes.plummer(n, seed=302, dtype=dtype)
@@ -263,6 +264,22 @@ def test_config5_as_stated_rehearsed_on_one_gpu(nb, orc):
     rel = (err - slack) / norm
     print(f"[config 5 on one GPU] e_gpu on {len(tg)} sampled targets: median {np.median(err / norm):.2e} max {(err / norm).max():.2e}")
     assert np.all(rel <= ACC_RTOL), float(rel.max())
+
+
+def test_one_device_takes_the_single_device_step_driver(nb, monkeypatch, capfd):
+    """With one device there is nothing to shard: tree steps on a multi context run the single-device driver (f32 BVH steps
+    enqueued ahead of the host), not the sliced step + exchange."""
+    C = nb._capi
+    pos, vel, w = nb.scenes.galaxy()
+    pos, vel, w = pos[::3].copy(), vel[::3].copy(), w[::3].copy()
+    monkeypatch.setenv("NBODY_TRACE", "1")
+    with _single(nb, pos, vel, w) as s, _multi(nb, [0], pos, vel, w, C.EXCHANGE_PEER) as m:
+        cm = C.Counting()
+        s.update_tree(C.TREE_BVH, 0.1, 5)
+        capfd.readouterr()
+        m.update_tree(C.TREE_BVH, 0.1, 5, cm)
+        assert capfd.readouterr().err.count("step ahead: build verdict 1") == 4
+        assert _same_rows(s.download(), m.download()) and cm.build_bvh > 0 and m.counting().sum_gravity > 0
 
 
 def test_contexts_give_their_device_memory_back(nb):
