@@ -349,27 +349,38 @@ __global__ __launch_bounds__(256) void direct_fast(const DirectArgs a) {
 // then (near/far split) the near sources with the clamp, in ascending body index, then integrates.
 __global__ __launch_bounds__(256) void direct_finish(const DirectArgs a, int n_gsplit, int add_near) {
   if (!gate_open(a)) return;
-  int t = blockIdx.x * 256 + threadIdx.x;
-  if (t >= a.n_tgt) return;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const bool live = t < a.n_tgt;
   float ax = 0.f, ay = 0.f;
-  for (int g = 0; g < n_gsplit; ++g) {
-    float2 r = a.partial[(size_t)g * a.n_tgt + t];
-    ax += r.x;
-    ay += r.y;
-  }
+  if (live)
+    for (int g = 0; g < n_gsplit; ++g) {
+      float2 r = a.partial[(size_t)g * a.n_tgt + t];
+      ax += r.x;
+      ay += r.y;
+    }
   if (add_near) {
+    // the near sources (ascending body index) come through LDS, 256 at a time: read straight from memory each target pays
+    // three dependent loads per source (index, position, mass), ~1 us of latency apiece
+    __shared__ float2 npos[256];
+    __shared__ float nmass[256];
     const int m = a.flags[kFlagNearCount];
-    const float2 pi = a.pos_all[a.tgt_begin + t];
+    const float2 pi = live ? a.pos_all[a.tgt_begin + t] : make_float2(0.f, 0.f);
     float nx = 0.f, ny = 0.f;
-    for (int q = 0; q < m; ++q) {
-      const uint32_t j = a.near_list[q];
-      const float2 pj = a.pos_all[j];
-      fast_pair<false, false>(pi.x, pi.y, pj.x, pj.y, a.mass_all[j], a.clamp, nx, ny);
+    for (int base = 0; base < m; base += 256) {
+      const int cnt = m - base < 256 ? m - base : 256;
+      if ((int)threadIdx.x < cnt) {
+        const uint32_t j = a.near_list[base + threadIdx.x];
+        npos[threadIdx.x] = a.pos_all[j];
+        nmass[threadIdx.x] = a.mass_all[j];
+      }
+      __syncthreads();
+      for (int q = 0; q < cnt; ++q) fast_pair<false, false>(pi.x, pi.y, npos[q].x, npos[q].y, nmass[q], a.clamp, nx, ny);
+      __syncthreads();
     }
     ax += nx;
     ay += ny;
   }
-  integrate_store(a, t, ax, ay);
+  if (live) integrate_store(a, t, ax, ay);
 }
 
 // ------------------------------------------------------------------------------------------------ EXACT
