@@ -176,6 +176,13 @@ struct Pool {
 constexpr int kMaxChunks = 16;
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
+// The calling thread's current device is its own business: calls that visit several devices put it back.
+struct DeviceGuard {
+  int prev = -1;
+  DeviceGuard() { if (hipGetDevice(&prev) != hipSuccess) prev = -1; }
+  ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
 }  // namespace
 
 struct Multi {
@@ -432,6 +439,7 @@ int tree_worker(Multi& M, int d, int kind, double delta, int n_steps, nbody_coun
 }
 
 template <class T> int replicate_rows(Multi& M) {
+  DeviceGuard guard;
   nbody_ctx* P = M.sub[0];
   auto state = [](nbody_ctx* c) -> State<T>& {
     if constexpr (sizeof(T) == 8) return c->sd; else return c->sf;
@@ -516,6 +524,7 @@ int multi_upload(nbody_ctx* front, bool f64, int64_t n, const void* pos, const v
   M.xoff_vel = M.xoff_pos + align256(rows * e2);
   M.xsec = M.xoff_vel + align256(rows * e2);
   const size_t need = M.xsec * (size_t)M.G;
+  DeviceGuard guard;
   if (need > M.xbuf_bytes) {
     for (int d = 0; d < M.G; ++d) {
       hipError_t e = hipSetDevice(M.dev[(size_t)d]);
@@ -650,6 +659,7 @@ NB_API int nbody_create_multi_ex(nbody_ctx** out, int n_devices, const int* devi
     return ctx_fail(nullptr, NBODY_ERR_NOMEM, "nbody_create_multi: out of host memory");
   }
   front->multi = M;
+  DeviceGuard guard;
   nbody_default_params(&front->params);
   M->G = n_devices;
   M->dev = ids;
