@@ -29,6 +29,8 @@
 #include <hip/hip_runtime.h>
 #include <limits.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <cstdio>
 
 #include "bvh_build.h"
 #include "exact_sum.h"
@@ -132,12 +134,6 @@ BvhPtrs make_ptrs(char* s, const BvhBuildLayout& L) {
 __device__ __forceinline__ float sse_min(float a, float b) { return a < b ? a : b; }
 __device__ __forceinline__ float sse_max(float a, float b) { return a > b ? a : b; }
 
-__device__ __forceinline__ xsum::Step shfl_up_step(xsum::Step v, int d) {
-  xsum::Step r;
-  r.a0 = (uint32_t)__shfl_up((int)v.a0, d, 64);
-  r.a1 = (uint32_t)__shfl_up((int)v.a1, d, 64);
-  return r;
-}
 __device__ __forceinline__ float lane_value(float v, int k) {  // k uniform
   return xsum::u2f((uint32_t)__builtin_amdgcn_readlane((int)xsum::f2u(v), k));
 }
@@ -204,13 +200,83 @@ __device__ __forceinline__ void chain_run(PosPtr P, int begin, int count, int la
   }
 }
 
+// ---- one coordinate out of LDS ------------------------------------------------------------------------------------------
+// A window of a node's coordinate, laid out so that neither of its two readers meets a bank conflict: a scan thread
+// takes 8 consecutive addends (a row each, the threads side by side), the chain's wave takes 16 consecutive ones.
+template <int NT> struct StageView {
+  static constexpr int kRow = NT + 8;  // 8 rows, 8 banks apart
+  static constexpr int kWords = 8 * kRow;
+  float* b;
+  __device__ __forceinline__ static int at(int e) { return (e & 7) * kRow + (e >> 3); }
+  __device__ __forceinline__ float operator[](int e) const { return b[at(e)]; }
+};
+__device__ __forceinline__ void chain_add16_one(float& s, float v) {
+  asm volatile("s_nop 1" ::: "memory");
+#define NB_ADD(K) add_row_lane<K>(s, v);
+  NB_ADD(0) NB_ADD(1) NB_ADD(2) NB_ADD(3) NB_ADD(4) NB_ADD(5) NB_ADD(6) NB_ADD(7)
+  NB_ADD(8) NB_ADD(9) NB_ADD(10) NB_ADD(11) NB_ADD(12) NB_ADD(13) NB_ADD(14) NB_ADD(15)
+#undef NB_ADD
+}
+__device__ __forceinline__ void chain_add_some_one(float& s, float v, int cnt) {  // cnt < 16, uniform
+  asm volatile("s_nop 1" ::: "memory");
+#define NB_ADD(K) if (K < cnt) add_row_lane<K>(s, v);
+  NB_ADD(0) NB_ADD(1) NB_ADD(2) NB_ADD(3) NB_ADD(4) NB_ADD(5) NB_ADD(6) NB_ADD(7)
+  NB_ADD(8) NB_ADD(9) NB_ADD(10) NB_ADD(11) NB_ADD(12) NB_ADD(13) NB_ADD(14)
+#undef NB_ADD
+}
+// s += V[begin .. begin+count) in order, by one wave (chain_run for one coordinate); mn / mx take the same values
+template <class Src>
+__device__ __forceinline__ void chain_run_one(const Src& V, int begin, int count, int lane, float& s, float& mn, float& mx) {
+  const int sub = lane & 15;
+  const int end = begin + count;
+  float q = 0.f;
+  if (begin + sub < end) q = V[begin + sub];
+  for (int p = begin; p < end; p += 16) {
+    float nq = 0.f;
+    if (p + 16 + sub < end) nq = V[p + 16 + sub];
+    const int cnt = end - p;
+    if (cnt >= 16) {
+      mn = sse_min(mn, q);
+      mx = sse_max(mx, q);
+      chain_add16_one(s, q);
+    } else {
+      if (sub < cnt) { mn = sse_min(mn, q); mx = sse_max(mx, q); }
+      chain_add_some_one(s, q, cnt);
+    }
+    q = nq;
+  }
+}
+
+// ---- scans over the lanes by DPP (a ds_bpermute per step costs a trip through the LDS pipe) -----------------------------------
+// The value CTRL brings to this lane, 0 where it brings none (0, 0 is the identity step).
+template <int CTRL, int ROWS> __device__ __forceinline__ uint32_t dpp_or_zero(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROWS, 0xf, false);
+}
+template <int CTRL, int ROWS> __device__ __forceinline__ xsum::Step dpp_step(xsum::Step v) {
+  return xsum::Step{dpp_or_zero<CTRL, ROWS>(v.a0), dpp_or_zero<CTRL, ROWS>(v.a1)};
+}
+// inclusive scan over the wave's 64 lanes, in lane order
+__device__ __forceinline__ xsum::Step wave_scan_steps(xsum::Step v) {
+  v = xsum::compose(dpp_step<0x111, 0xf>(v), v);  // row_shr:1
+  v = xsum::compose(dpp_step<0x112, 0xf>(v), v);  // row_shr:2
+  v = xsum::compose(dpp_step<0x114, 0xf>(v), v);  // row_shr:4
+  v = xsum::compose(dpp_step<0x118, 0xf>(v), v);  // row_shr:8
+  v = xsum::compose(dpp_step<0x142, 0xa>(v), v);  // row_bcast:15 into rows 1 and 3
+  v = xsum::compose(dpp_step<0x143, 0xc>(v), v);  // row_bcast:31 into rows 2 and 3
+  return v;
+}
+// the value of the lane before (wave_shr:1), the identity in lane 0
+__device__ __forceinline__ xsum::Step wave_prev_step(xsum::Step v) { return dpp_step<0x138, 0xf>(v); }
+
 // ---- NW waves working on one node --------------------------------------------------------------------------------
 // NW == 1 needs no barrier and no LDS (a wave runs in lock-step); NW > 1 is a whole work-group.
 template <int NW> struct Scratch {
-  xsum::Step w[NW];
+  xsum::Step w[2][NW];     // wave totals of a scan round; two sets, taken in turn (a round that succeeds has one barrier)
+  uint32_t wkind[2][NW];   // per wave: 1 a negative increment, 2 a positive one, 4 a step too large for 32-bit sums
   float redf[2][NW];
   int bad;
   uint32_t bad_s;
+  uint32_t seq_s[2];       // the sum after a run of real adds; two slots, taken in turn
 };
 
 template <int NW> __device__ __forceinline__ void group_sync() {
@@ -237,98 +303,143 @@ template <int NW> __device__ __forceinline__ unsigned group_sum(unsigned v, unsi
   }
 }
 
+#ifdef NB_FOLD_TIMING
+__device__ unsigned long long g_fold_t[8];
+#define NB_FT_ADD(k, v) { if (tid == 0) atomicAdd(&g_fold_t[k], (unsigned long long)(v)); }
+#else
+#define NB_FT_ADD(k, v)
+#endif
 // One coordinate (comp 0: x, 1: y) of the fold of bvh_tree.rs:58-61 over P[0, len): min, max, and the sum exactly as
 // the sequential chain rounds it.  Every thread of the group returns the same values.  The two coordinates are
 // independent chains: they run on different work-groups.
 // EPT: consecutive addends per thread and scan (the scan's fixed cost is per thread: more addends each = cheaper).
-template <int NW, int EPT>
-__device__ __forceinline__ void exact_fold(const float2* P, int begin, int len, float s_in, int comp, int tid, Scratch<NW>* sh,
-                                           float& out_sum, float& out_min, float& out_max, int& stops) {
-  // the chain over P[begin, len), entered with the running sum s_in (0.0 and begin = 0 for a whole node)
+// chain_off: how many addends of the chain came before P[0] (P may be a window of the node staged in LDS).
+template <int NW, int EPT, class Src>
+__device__ __forceinline__ void exact_fold(const Src& P, int begin, int len, float s_in, int tid, Scratch<NW>* sh,
+                                           float& out_sum, float& out_min, float& out_max, int& stops, int chain_off = 0) {
+  // the chain over P[begin, len) (one coordinate), entered with the running sum s_in (0.0 and begin = 0 for a whole node)
+  static_assert(NW > 1 && EPT == 8, "a work-group of several waves, a row of the stage per addend of a thread");
   constexpr int TILE = NW * 64 * EPT;
+  constexpr int kSmall = 1 << 24;  // wave totals below this: NW of them add up without wrapping
   const int lane = tid & 63, wave = tid >> 6;
   float s = s_in;  // uniform across the group
   float mn = kMaxF, mx = 0.f;
   int pos = begin;
-  bool seq = false;  // decided from s: a chain at 0.0 is not in any binade yet
+  int par = 0, qar = 0;
+  bool seq = false;       // decided from s: a chain at 0.0 is not in any binade yet
+  bool foreseen = false;  // the last thing done was a run of real adds up to a crossing that was seen coming
   while (pos < len) {
     xsum::Chain ch;
     if (!seq) seq = !xsum::chain_open(s, ch);
-    if (seq) {  // real adds by ONE wave; the others wait for the result
-      int cnt = pos == 0 ? kChainStart : kSeqRun;
-      cnt = len - pos < cnt ? len - pos : cnt;
-      if (wave == 0) {
-        Box bx;
-        float sx = s, sy = s;
-        chain_run(P, pos, cnt, lane, sx, sy, bx);
-        s = comp ? sy : sx;
-        mn = sse_min(mn, comp ? bx.mny : bx.mnx);
-        mx = sse_max(mx, comp ? bx.mxy : bx.mxx);
-      }
-      if constexpr (NW > 1) {
-        if (tid == 0) sh->bad_s = xsum::f2u(s);
-        __syncthreads();
-        s = xsum::u2f(sh->bad_s);
-      }
-      pos += cnt;
-      seq = false;
-      continue;
-    }
+    const int gp = chain_off + pos;  // addends behind the chain
     // A chain of same-signed addends leaves its binade about every time the number of addends doubles: near the
     // start of the chain short scans lose less work to the restart than full ones.
-    int span = pos > 64 ? pos : 64;
+    int span = gp > 64 ? gp : 64;
     span = span < TILE ? span : TILE;
+    int seq_cnt = gp == 0 ? kChainStart : kSeqRun;
+    if (!seq && !foreseen) {
+      // ... and where it leaves can be seen coming: gp addends made S ulps, so 2^24 is another gp * (2^24 - S) / S
+      // addends away if they go on like that.  The scan stops a little short of that point and real adds carry the
+      // chain across (they need no binade), instead of a whole scan failing there and starting over.  A guess: a
+      // chain that does something else is scanned and stopped as ever.
+      const float rem = (float)gp * ((float)(xsum::kHi - ch.S) / (float)ch.S);
+      const int irem = rem < 1.0e9f ? (int)rem : 1000000000;
+      const int safe = irem - (irem >> 5) - 8;
+      if (safe < 64) {
+        seq = true;
+        seq_cnt = irem + (irem >> 4) + kSeqRun;
+        seq_cnt = seq_cnt < 512 ? seq_cnt : 512;
+        foreseen = true;
+      } else {
+        span = span < safe ? span : safe;
+      }
+    } else {
+      foreseen = false;
+    }
+    if (seq) {  // real adds by ONE wave; the others wait for the result
+#ifdef NB_FOLD_TIMING
+      const long long tq0 = wall_clock64();
+#endif
+      const int cnt = len - pos < seq_cnt ? len - pos : seq_cnt;
+      if (wave == 0) chain_run_one(P, pos, cnt, lane, s, mn, mx);
+      if (tid == 0) sh->seq_s[qar] = xsum::f2u(s);
+      __syncthreads();
+      s = xsum::u2f(sh->seq_s[qar]);
+      qar ^= 1;
+      pos += cnt;
+      seq = false;
+#ifdef NB_FOLD_TIMING
+      NB_FT_ADD(0, wall_clock64() - tq0) NB_FT_ADD(2, 1)
+#endif
+      continue;
+    }
+#ifdef NB_FOLD_TIMING
+    const long long tr0 = wall_clock64();
+#endif
     const int limit = pos + span < len ? pos + span : len;
     const int base = pos + tid * EPT;
     xsum::Step f[EPT];
     xsum::Step t{0u, 0u};
+    int imin = 0, imax = 0;  // extremes of the increments: their signs, and whether 32-bit totals can be trusted
 #pragma unroll
     for (int j = 0; j < EPT; ++j) f[j] = xsum::Step{0u, 0u};
     if (base < limit) {
 #pragma unroll
       for (int j = 0; j < EPT; ++j) {
         if (base + j < limit) {
-          const float2 q = P[base + j];
-          const float v = comp ? q.y : q.x;
+          const float v = P[base + j];
           f[j] = xsum::step_of(v, ch.sign, ch.E);
           mn = sse_min(mn, v);
           mx = sse_max(mx, v);
+          const int i0 = (int)f[j].a0, i1 = (int)f[j].a1;
+          imin = min(imin, min(i0, i1));
+          imax = max(imax, max(i0, i1));
         }
         t = xsum::compose(t, f[j]);
       }
     }
-    xsum::Step inc = t;  // inclusive scan inside the wave
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const xsum::Step o = shfl_up_step(inc, d);
-      if (lane >= d) inc = xsum::compose(o, inc);
+    const xsum::Step inc = wave_scan_steps(t);  // inclusive scan inside the wave
+    xsum::Step ex = wave_prev_step(inc);        // exclusive: everything before my addends
+    {  // (an increment is below 2^22 in size unless it is the poison: 512 of one sign stay below 2^31)
+      const uint32_t kind = (__ballot(imin < 0) != 0ull ? 1u : 0u) | (__ballot(imax > 0) != 0ull ? 2u : 0u) |
+                            (__ballot(imax >= (1 << 23)) != 0ull ? 4u : 0u);
+      if (lane == 63) { sh->w[par][wave] = inc; sh->wkind[par][wave] = kind; }
     }
-    xsum::Step ex = shfl_up_step(inc, 1);  // exclusive: everything before my addends
-    if (lane == 0) ex = xsum::Step{0u, 0u};
+    if (tid == 0) sh->bad = INT_MAX;
+    __syncthreads();
+    // every wave scans the NW wave totals for itself (lanes 0..NW-1): no second barrier
+    xsum::Step wi{0u, 0u};
+    uint32_t wk = 0u;
+    if (lane < NW) { wi = sh->w[par][lane]; wk = sh->wkind[par][lane]; }
+    const int w0 = (int)wi.a0, w1 = (int)wi.a1;
+    if (w0 <= -kSmall || w0 >= kSmall || w1 <= -kSmall || w1 >= kSmall) wk |= 4u;
+    const uint32_t kind = (__ballot((wk & 1u) != 0u) != 0ull ? 1u : 0u) | (__ballot((wk & 2u) != 0u) != 0ull ? 2u : 0u) |
+                          (__ballot((wk & 4u) != 0u) != 0ull ? 4u : 0u);
+    static_assert(NW <= 16, "the wave totals are scanned inside one row of 16 lanes");
+    wi = xsum::compose(dpp_step<0x111, 0xf>(wi), wi);
+    if constexpr (NW > 2) wi = xsum::compose(dpp_step<0x112, 0xf>(wi), wi);
+    if constexpr (NW > 4) wi = xsum::compose(dpp_step<0x114, 0xf>(wi), wi);
+    if constexpr (NW > 8) wi = xsum::compose(dpp_step<0x118, 0xf>(wi), wi);
     xsum::Step tot;
-    if constexpr (NW > 1) {
-      if (lane == 63) sh->w[wave] = inc;
-      if (tid == 0) sh->bad = INT_MAX;
-      __syncthreads();
-      // every wave scans the NW wave totals for itself (lanes 0..NW-1): no second barrier
-      xsum::Step wi{0u, 0u};
-      if (lane < NW) wi = sh->w[lane];
-#pragma unroll
-      for (int d = 1; d < NW; d <<= 1) {
-        const xsum::Step o = shfl_up_step(wi, d);
-        if (lane >= d) wi = xsum::compose(o, wi);
-      }
-      tot.a0 = (uint32_t)__builtin_amdgcn_readlane((int)wi.a0, NW - 1);
-      tot.a1 = (uint32_t)__builtin_amdgcn_readlane((int)wi.a1, NW - 1);
-      if (wave > 0) {
-        xsum::Step pw;  // all the waves before mine
-        pw.a0 = (uint32_t)__builtin_amdgcn_readlane((int)wi.a0, wave - 1);
-        pw.a1 = (uint32_t)__builtin_amdgcn_readlane((int)wi.a1, wave - 1);
-        ex = xsum::compose(pw, ex);
-      }
-    } else {
-      tot.a0 = (uint32_t)__builtin_amdgcn_readlane((int)inc.a0, 63);
-      tot.a1 = (uint32_t)__builtin_amdgcn_readlane((int)inc.a1, 63);
+    tot.a0 = (uint32_t)__builtin_amdgcn_readlane((int)wi.a0, NW - 1);
+    tot.a1 = (uint32_t)__builtin_amdgcn_readlane((int)wi.a1, NW - 1);
+    par ^= 1;
+    // Increments of one sign only (the usual case: coordinates of one sign) move S one way: every intermediate S lies
+    // between the first and the last, so the last one being inside the binade says all were.  The totals are exact:
+    // every wave's is below 2^24 in size, NW of them cannot wrap.
+    if (kind != 3u && kind < 4u && xsum::in_binade(xsum::apply(ch.S, tot))) {
+      s = xsum::chain_value(ch, xsum::apply(ch.S, tot));
+      pos += span;
+#ifdef NB_FOLD_TIMING
+      NB_FT_ADD(1, wall_clock64() - tr0) NB_FT_ADD(3, 1)
+#endif
+      continue;
+    }
+    if (wave > 0) {
+      xsum::Step pw;  // all the waves before mine
+      pw.a0 = (uint32_t)__builtin_amdgcn_readlane((int)wi.a0, wave - 1);
+      pw.a1 = (uint32_t)__builtin_amdgcn_readlane((int)wi.a1, wave - 1);
+      ex = xsum::compose(pw, ex);
     }
     uint32_t S = xsum::apply(ch.S, ex);
     int bad = INT_MAX;
@@ -350,42 +461,74 @@ __device__ __forceinline__ void exact_fold(const float2* P, int begin, int len, 
       const int o = __shfl_xor(first_bad, d, 64);
       first_bad = o < first_bad ? o : first_bad;
     }
-    if constexpr (NW > 1) {
-      if (lane == 0 && first_bad != INT_MAX) atomicMin(&sh->bad, first_bad);
-      __syncthreads();
-      first_bad = sh->bad;
-    }
+    if (lane == 0 && first_bad != INT_MAX) atomicMin(&sh->bad, first_bad);
+    __syncthreads();
+    first_bad = sh->bad;
     if (first_bad == INT_MAX) {
       s = xsum::chain_value(ch, xsum::apply(ch.S, tot));
       pos += span;
     } else {  // the chain is exact up to the addend before first_bad; that addend takes a real add
-      uint32_t v;
-      if constexpr (NW > 1) {
-        if (bad == first_bad) sh->bad_s = bs;
-        __syncthreads();
-        v = sh->bad_s;
-      } else {
-        v = (uint32_t)__builtin_amdgcn_readlane((int)bs, first_bad / EPT);
-      }
-      s = xsum::chain_value(ch, v);
+      if (bad == first_bad) sh->bad_s = bs;
+      __syncthreads();
+      s = xsum::chain_value(ch, sh->bad_s);
       pos += first_bad;
       seq = true;
       ++stops;
     }
-    if constexpr (NW > 1) __syncthreads();  // sh is rewritten by the next round
+    __syncthreads();  // sh->bad, bad_s are rewritten by the next round
+#ifdef NB_FOLD_TIMING
+    NB_FT_ADD(1, wall_clock64() - tr0) NB_FT_ADD(3, 1) NB_FT_ADD(7, 1)
+#endif
   }
   for (int d = 32; d >= 1; d >>= 1) {
     mn = sse_min(mn, __shfl_xor(mn, d, 64));
     mx = sse_max(mx, __shfl_xor(mx, d, 64));
   }
-  if constexpr (NW > 1) {
-    if (lane == 0) { sh->redf[0][wave] = mn; sh->redf[1][wave] = mx; }
+  if (lane == 0) { sh->redf[0][wave] = mn; sh->redf[1][wave] = mx; }
+  __syncthreads();
+  for (int w = 0; w < NW; ++w) {
+    mn = sse_min(mn, sh->redf[0][w]);
+    mx = sse_max(mx, sh->redf[1][w]);
+  }
+  __syncthreads();
+  out_sum = s;
+  out_min = mn;
+  out_max = mx;
+}
+
+// exact_fold over P[lo, hi) of a node in memory, a window of NW * 64 * EPT points at a time out of LDS.  The chain is a
+// sequence of short dependent rounds (a scan, a stop at every power of two the sum crosses, a few real adds, the next scan):
+// read from memory every round pays a trip to L2; the window is fetched once, the next one while this one is folded.
+template <int NW, int EPT>
+__device__ __forceinline__ void staged_fold(const float2* __restrict__ P, int lo, int hi, float s_in, int comp, int tid,
+                                            Scratch<NW>* sh, float* stage, float& out_sum, float& out_min, float& out_max,
+                                            int& stops) {
+  constexpr int NT = NW * 64, T = NT * EPT;
+  const StageView<NT> view{stage};
+  const float* __restrict__ X = reinterpret_cast<const float*>(P) + comp;
+  float s = s_in, mn = kMaxF, mx = 0.f;
+  float nx[EPT];
+#pragma unroll
+  for (int k = 0; k < EPT; ++k) {
+    const int e = lo + tid + k * NT;
+    nx[k] = e < hi ? X[2 * (size_t)e] : 0.f;
+  }
+  for (int t0 = lo; t0 < hi; t0 += T) {
+    const int cnt = hi - t0 < T ? hi - t0 : T;
+    __syncthreads();  // the window before this one has been read to the end
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) stage[StageView<NT>::at(tid + k * NT)] = nx[k];
     __syncthreads();
-    for (int w = 0; w < NW; ++w) {
-      mn = sse_min(mn, sh->redf[0][w]);
-      mx = sse_max(mx, sh->redf[1][w]);
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      const int e = t0 + T + tid + k * NT;
+      nx[k] = e < hi ? X[2 * (size_t)e] : 0.f;
     }
-    __syncthreads();
+    float ts, tmn, tmx;
+    exact_fold<NW, EPT>(view, 0, cnt, s, tid, sh, ts, tmn, tmx, stops, t0);
+    s = ts;
+    mn = sse_min(mn, tmn);
+    mx = sse_max(mx, tmx);
   }
   out_sum = s;
   out_min = mn;
@@ -526,11 +669,9 @@ __global__ __launch_bounds__(256) void bvh_chunk_sums(BvhPtrs a, int level) {
 
 __device__ __forceinline__ xsum::Run shfl_down_run(const xsum::Run& r, int d) {
   xsum::Run o;
-  for (int p = 0; p < 2; ++p) {
-    o.a[p] = __shfl_down(r.a[p], d, 64);
-    o.lo[p] = __shfl_down(r.lo[p], d, 64);
-    o.hi[p] = __shfl_down(r.hi[p], d, 64);
-  }
+  o.a0 = __shfl_down(r.a0, d, 64); o.a1 = __shfl_down(r.a1, d, 64);
+  o.lo0 = __shfl_down(r.lo0, d, 64); o.lo1 = __shfl_down(r.lo1, d, 64);
+  o.hi0 = __shfl_down(r.hi0, d, 64); o.hi1 = __shfl_down(r.hi1, d, 64);
   return o;
 }
 
@@ -544,7 +685,7 @@ __host__ __device__ inline int run_mult(int len) {
 }
 constexpr int kRunRec = 24;  // ints per chunk and coordinate: sign, E_a (0: no run), E_b, u0, u1, run A (6), run B (6), pad
 __device__ __forceinline__ void store_run(int* o, const xsum::Run& r) {
-  o[0] = r.a[0]; o[1] = r.a[1]; o[2] = r.lo[0]; o[3] = r.lo[1]; o[4] = r.hi[0]; o[5] = r.hi[1];
+  o[0] = r.a0; o[1] = r.a1; o[2] = r.lo0; o[3] = r.lo1; o[4] = r.hi0; o[5] = r.hi1;
 }
 // ordered reduction over the wave: lane 0 ends with r(lane 0) then r(lane 1) then ...
 __device__ __forceinline__ xsum::Run wave_run_in_order(xsum::Run r, int lane) {
@@ -712,6 +853,7 @@ __global__ __launch_bounds__(512) void bvh_big_fold(BvhPtrs a, int level, int us
   constexpr int kRecBatch = 64;
   __shared__ Scratch<8> sh;
   __shared__ __attribute__((aligned(16))) int recs[kRecBatch * kRunRec];
+  __shared__ float stage[StageView<512>::kWords];
   const int tid = threadIdx.x;
   const int comp = blockIdx.y;  // 0: x, 1: y
   const int nq = a.bigcount[level];
@@ -722,6 +864,9 @@ __global__ __launch_bounds__(512) void bvh_big_fold(BvhPtrs a, int level, int us
     const int b = a.nbegin[node], len = a.nlen[node];
     const float2* P = (const float2*)(a.P + b);
     float sum, mn, mx;
+#ifdef NB_FOLD_TIMING
+    const long long tn0 = wall_clock64();
+#endif
     if (use_runs && len > kRunLen) {
       const int c0 = a.nchunk0[node], nch = (len + kChunk - 1) / kChunk;
       const int rm = run_mult(len), rlen = rm * kChunk, nrun = (nch + rm - 1) / rm;  // run chunks: <= 64 of them
@@ -740,8 +885,8 @@ __global__ __launch_bounds__(512) void bvh_big_fold(BvhPtrs a, int level, int us
             const int fE = fr[1];
             if (fE == 0) { valid = false; break; }
             xsum::Run fa, fb;
-            fa.a[0] = fr[5]; fa.a[1] = fr[6]; fa.lo[0] = fr[7]; fa.lo[1] = fr[8]; fa.hi[0] = fr[9]; fa.hi[1] = fr[10];
-            fb.a[0] = fr[11]; fb.a[1] = fr[12]; fb.lo[0] = fr[13]; fb.lo[1] = fr[14]; fb.hi[0] = fr[15]; fb.hi[1] = fr[16];
+            fa.a0 = fr[5]; fa.a1 = fr[6]; fa.lo0 = fr[7]; fa.lo1 = fr[8]; fa.hi0 = fr[9]; fa.hi1 = fr[10];
+            fb.a0 = fr[11]; fb.a1 = fr[12]; fb.lo0 = fr[13]; fb.lo1 = fr[14]; fb.hi0 = fr[15]; fb.hi1 = fr[16];
             const bool whole = fr[3] >= cntf;  // one run over the whole chunk
             if (f == f0) { sign = fr[0]; Ea = fE; Eb = fE; }
             if (fr[0] != sign) { valid = false; break; }
@@ -764,8 +909,8 @@ __global__ __launch_bounds__(512) void bvh_big_fold(BvhPtrs a, int level, int us
           if (!crossed) { u0 = pos; u1 = pos; }
           int* o = recs + tid * kRunRec;
           o[0] = sign; o[1] = valid ? Ea : 0; o[2] = Eb; o[3] = u0; o[4] = u1;
-          o[5] = A.a[0]; o[6] = A.a[1]; o[7] = A.lo[0]; o[8] = A.lo[1]; o[9] = A.hi[0]; o[10] = A.hi[1];
-          o[11] = B.a[0]; o[12] = B.a[1]; o[13] = B.lo[0]; o[14] = B.lo[1]; o[15] = B.hi[0]; o[16] = B.hi[1];
+          o[5] = A.a0; o[6] = A.a1; o[7] = A.lo0; o[8] = A.lo1; o[9] = A.hi0; o[10] = A.hi1;
+          o[11] = B.a0; o[12] = B.a1; o[13] = B.lo0; o[14] = B.lo1; o[15] = B.hi0; o[16] = B.hi1;
         }
         __syncthreads();
         int ci = b0;
@@ -792,11 +937,11 @@ __global__ __launch_bounds__(512) void bvh_big_fold(BvhPtrs a, int level, int us
                   good = xsum::chain_open(t, ch) && (int)ch.E == rec[1 + part] && (int)ch.sign == rec[0];
                   if (good) {
                     xsum::Run r;
-                    r.a[0] = rec[5 + 6 * part]; r.a[1] = rec[6 + 6 * part];
-                    r.lo[0] = rec[7 + 6 * part]; r.lo[1] = rec[8 + 6 * part];
-                    r.hi[0] = rec[9 + 6 * part]; r.hi[1] = rec[10 + 6 * part];
+                    r.a0 = rec[5 + 6 * part]; r.a1 = rec[6 + 6 * part];
+                    r.lo0 = rec[7 + 6 * part]; r.lo1 = rec[8 + 6 * part];
+                    r.hi0 = rec[9 + 6 * part]; r.hi1 = rec[10 + 6 * part];
                     good = xsum::run_fits(ch.S, r);
-                    if (good) { t = xsum::chain_value(ch, (uint32_t)((int)ch.S + r.a[ch.S & 1u])); ++u; }
+                    if (good) { t = xsum::chain_value(ch, (uint32_t)((int)ch.S + ((ch.S & 1u) ? r.a1 : r.a0))); ++u; }
                   }
                 }
                 if (good && part == 0 && u1 > u0) {  // the addends around the power of two: real adds
@@ -822,7 +967,7 @@ __global__ __launch_bounds__(512) void bvh_big_fold(BvhPtrs a, int level, int us
             const int* rec = recs + (ci - b0) * kRunRec;
             const int lo = ci * rlen, hi = lo + rlen < len ? lo + rlen : len;
             float dmn, dmx;
-            exact_fold<8, 8>(P, lo, hi, sum, comp, tid, &sh, sum, dmn, dmx, stops);
+            staged_fold<8, 8>(P, lo, hi, sum, comp, tid, &sh, stage, sum, dmn, dmx, stops);
             (void)rec;
             ++ci;
           }
@@ -849,8 +994,11 @@ __global__ __launch_bounds__(512) void bvh_big_fold(BvhPtrs a, int level, int us
       __syncthreads();
       if (tid == 0 && used) atomicAdd(&a.flags[kBvhRunsUsed], used);
     } else {
-      exact_fold<8, 8>(P, 0, len, 0.f, comp, tid, &sh, sum, mn, mx, stops);
+      staged_fold<8, 8>(P, 0, len, 0.f, comp, tid, &sh, stage, sum, mn, mx, stops);
     }
+#ifdef NB_FOLD_TIMING
+    NB_FT_ADD(4, wall_clock64() - tn0) NB_FT_ADD(5, 1) NB_FT_ADD(6, len)
+#endif
     if (tid == 0) {
       float* box = (float*)&a.nbox[node];
       box[comp] = mn;
@@ -1463,6 +1611,9 @@ hipError_t bvh_build_begin(hipStream_t s, const void* pos, int n, char* scratch,
   return hipGetLastError();
 }
 
+#ifdef NB_FOLD_TIMING
+static void bvh_debug_fold_times(hipStream_t s);
+#endif
 hipError_t bvh_build_levels(hipStream_t s, int n, int leaf_size, int level_begin, int level_end, char* scratch,
                             const BvhBuildLayout& L) {
   BvhPtrs a = make_ptrs(scratch, L);
@@ -1477,6 +1628,10 @@ hipError_t bvh_build_levels(hipStream_t s, int n, int leaf_size, int level_begin
       bvh_chunk_runs<<<dim3((unsigned)gc), dim3(256), 0, s>>>(a, level);
     }
     bvh_big_fold<<<dim3((unsigned)gb, 2), dim3(512), 0, s>>>(a, level, use_runs);
+#ifdef NB_FOLD_TIMING
+    std::fprintf(stderr, "level %d: ", level);
+    bvh_debug_fold_times(s);
+#endif
     bvh_big_count<<<dim3((unsigned)gc), dim3(256), 0, s>>>(a, level, leaf_size);
     bvh_big_ranks<<<dim3((unsigned)gc), dim3(256), 0, s>>>(a, level);
     bvh_big_swap<<<dim3((unsigned)gc), dim3(256), 0, s>>>(a, level);
@@ -1512,6 +1667,17 @@ __global__ void bvh_verdict_kernel(const int* __restrict__ flags, const int* __r
 }
 }  // namespace
 
+#ifdef NB_FOLD_TIMING
+static void bvh_debug_fold_times(hipStream_t s) {
+  unsigned long long h[8] = {};
+  (void)hipStreamSynchronize(s);
+  (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_fold_t), sizeof(h));
+  std::fprintf(stderr, "[fold timing, 10 ns ticks] seq %llu in %llu runs; scan %llu in %llu rounds; nodes %llu ticks over %llu chains, %llu points; %llu slow rounds\n",
+               h[0], h[2], h[1], h[3], h[4], h[5], h[6], h[7]);
+  unsigned long long z[8] = {};
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fold_t), z, sizeof(z));
+}
+#endif
 hipError_t bvh_build_verdict(hipStream_t s, int level_end, char* scratch, const BvhBuildLayout& L, int* verdict) {
   hipLaunchKernelGGL(bvh_verdict_kernel, dim3(1), dim3(1), 0, s, (const int*)(scratch + L.flags), (const int*)(scratch + L.bigcount),
                      level_end, L.node_cap, verdict);

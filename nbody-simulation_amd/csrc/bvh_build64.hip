@@ -207,7 +207,9 @@ __global__ __launch_bounds__(64) void b64_seg_prefix(Ptrs a, int level) {
 __device__ __forceinline__ int64_t shfl_up_i64(int64_t v, int d) { return (int64_t)shfl_up_u64((uint64_t)v, d); }
 __device__ __forceinline__ xsum64::Run shfl_up_run(const xsum64::Run& r, int d) {
   xsum64::Run o;
-  for (int p = 0; p < 2; ++p) { o.a[p] = shfl_up_i64(r.a[p], d); o.lo[p] = shfl_up_i64(r.lo[p], d); o.hi[p] = shfl_up_i64(r.hi[p], d); }
+  o.a0 = shfl_up_i64(r.a0, d); o.a1 = shfl_up_i64(r.a1, d);
+  o.lo0 = shfl_up_i64(r.lo0, d); o.lo1 = shfl_up_i64(r.lo1, d);
+  o.hi0 = shfl_up_i64(r.hi0, d); o.hi1 = shfl_up_i64(r.hi1, d);
   return o;
 }
 
@@ -297,7 +299,7 @@ __global__ __launch_bounds__(NT) void b64_fold(Ptrs a, int level) {
           if (a.seg_pred[sg] == ((c.sign << 32) | c.E)) {
             const xsum64::Run r = a.seg_run[sg];
             if (xsum64::run_fits(c.S, r)) {
-              s = xsum64::chain_value(c, (uint64_t)((int64_t)c.S + r.a[c.S & 1ull]));
+              s = xsum64::chain_value(c, (uint64_t)((int64_t)c.S + ((c.S & 1ull) ? r.a1 : r.a0)));
               const double2 smn = a.seg_min[sg >> 1], smx = a.seg_max[sg >> 1];
               mn = sse_min(mn, comp == 0 ? smn.x : smn.y);
               mx = sse_max(mx, comp == 0 ? smx.x : smx.y);

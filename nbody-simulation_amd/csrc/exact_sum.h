@@ -90,7 +90,7 @@ NB_HD Step compose(Step f, Step g) {
 // start, every add of the run stayed in the binade and S + a is the exact result.  Saturating at +-2^29: beyond that a
 // run is unusable anyway (a poison step is 2^30, saturated on entry).
 struct Run {
-  int32_t a[2], lo[2], hi[2];
+  int32_t a0, a1, lo0, lo1, hi0, hi1;  // scalars: the compiler turns a select between two array elements into an indexed load from scratch
 };
 // How close (relatively) to a power of two a predicted prefix may come and still be trusted.  The f32 chain drifts from the
 // exact prefix by ~sqrt(n) half-ulps (worst case n): 2^-13 covers millions of addends; if it is ever too tight, the run's
@@ -101,27 +101,33 @@ constexpr int32_t kRunSat = 1 << 29;  // two saturated values still add without 
 NB_HD int32_t run_sat(int32_t v) { return v > kRunSat ? kRunSat : (v < -kRunSat ? -kRunSat : v); }
 NB_HD Run run_of(Step f) {
   Run r;
-  r.a[0] = r.lo[0] = r.hi[0] = run_sat((int32_t)f.a0);
-  r.a[1] = r.lo[1] = r.hi[1] = run_sat((int32_t)f.a1);
+  r.a0 = r.lo0 = r.hi0 = run_sat((int32_t)f.a0);
+  r.a1 = r.lo1 = r.hi1 = run_sat((int32_t)f.a1);
   return r;
 }
-NB_HD Run run_none() { return Run{{0, 0}, {0, 0}, {0, 0}}; }  // an open chain has S inside the binade: offsets 0 fit
-// f first, then g
+NB_HD Run run_none() { return Run{0, 0, 0, 0, 0, 0}; }  // an open chain has S inside the binade: offsets 0 fit
+// f first, then g.  All values travel as scalars: given `const Run&` the compiler fuses `q ? g.a1 : g.a0` into one load at a
+// computed address before it has inlined the call, and the run then lives in scratch memory on the device.
+NB_HD void run_then_from(int p, int32_t fa, int32_t flo, int32_t fhi, int32_t ga0, int32_t ga1, int32_t glo0, int32_t glo1, int32_t ghi0, int32_t ghi1,
+                   int32_t& ha, int32_t& hlo, int32_t& hhi) {
+  const bool q = (((p + fa)) & 1) != 0;
+  const int32_t ga = q ? ga1 : ga0, glo = q ? glo1 : glo0, ghi = q ? ghi1 : ghi0;
+  ha = run_sat(fa + ga);
+  const int32_t gl = run_sat(fa + glo), gh = run_sat(fa + ghi);
+  hlo = flo < gl ? flo : gl;
+  hhi = fhi > gh ? fhi : gh;
+}
 NB_HD Run run_then(const Run& f, const Run& g) {
+  const int32_t ga0 = g.a0, ga1 = g.a1, glo0 = g.lo0, glo1 = g.lo1, ghi0 = g.hi0, ghi1 = g.hi1;
   Run h;
-  for (int p = 0; p < 2; ++p) {
-    const int q = (p + f.a[p]) & 1;
-    const int32_t ga = q ? g.a[1] : g.a[0], glo = q ? g.lo[1] : g.lo[0], ghi = q ? g.hi[1] : g.hi[0];
-    h.a[p] = run_sat(f.a[p] + ga);
-    const int32_t gl = run_sat(f.a[p] + glo), gh = run_sat(f.a[p] + ghi);
-    h.lo[p] = f.lo[p] < gl ? f.lo[p] : gl;
-    h.hi[p] = f.hi[p] > gh ? f.hi[p] : gh;
-  }
+  run_then_from(0, f.a0, f.lo0, f.hi0, ga0, ga1, glo0, glo1, ghi0, ghi1, h.a0, h.lo0, h.hi0);
+  run_then_from(1, f.a1, f.lo1, f.hi1, ga0, ga1, glo0, glo1, ghi0, ghi1, h.a1, h.lo1, h.hi1);
   return h;
 }
 NB_HD bool run_fits(uint32_t S, const Run& r) {
-  const int p = (int)(S & 1u);
-  return (int64_t)S + r.lo[p] > (int64_t)kLo && (int64_t)S + r.hi[p] < (int64_t)kHi;
+  const int32_t lo0 = r.lo0, lo1 = r.lo1, hi0 = r.hi0, hi1 = r.hi1;
+  const bool p = (S & 1u) != 0u;
+  return (int64_t)S + (p ? lo1 : lo0) > (int64_t)kLo && (int64_t)S + (p ? hi1 : hi0) < (int64_t)kHi;
 }
 
 // CPU emulation of the device fold's control flow (tile = `tile` addends scanned at once, `seq_run` real adds after a
@@ -179,7 +185,7 @@ inline float emulate_fold_chunked(const float* x, int64_t n, int chunk, int64_t*
       for (int64_t k = c0; k < c1; ++k) r = run_then(r, run_of(step_of(x[k], pred.sign, pred.E)));
     Chain cur;
     if (have && chain_open(s, cur) && cur.E == pred.E && cur.sign == pred.sign && run_fits(cur.S, r)) {
-      s = chain_value(cur, (uint32_t)((int64_t)cur.S + r.a[cur.S & 1u]));
+      s = chain_value(cur, (uint32_t)((int64_t)cur.S + ((cur.S & 1u) ? r.a1 : r.a0)));
       ++used;
     } else {
       for (int64_t k = c0; k < c1; ++k) s = s + x[k];
@@ -201,7 +207,7 @@ inline float emulate_fold_chunked2(const float* x, int64_t n, int chunk, int seg
   auto take = [&](const Run& r, uint32_t sign, uint32_t E, int64_t b, int64_t e) {
     Chain cur;
     if (e > b && chain_open(s, cur) && cur.E == E && cur.sign == sign && run_fits(cur.S, r)) {
-      s = chain_value(cur, (uint32_t)((int64_t)cur.S + r.a[cur.S & 1u]));
+      s = chain_value(cur, (uint32_t)((int64_t)cur.S + ((cur.S & 1u) ? r.a1 : r.a0)));
       ++used;
     } else {
       real(b, e);

@@ -84,33 +84,39 @@ NB_HD64 Step compose(Step f, Step g) {
 // S + lo > 2^52 and S + hi < 2^53 for the actual start, every add of the run stayed in the binade and S + a is the exact
 // result.  Saturating at +-2^60: beyond that a run is unusable anyway (a poison step is 2^62, saturated on entry).
 struct Run {
-  int64_t a[2], lo[2], hi[2];
+  int64_t a0, a1, lo0, lo1, hi0, hi1;  // scalars, as in exact_sum.h
 };
 constexpr int64_t kRunSat = 1ll << 60;  // two saturated values still add without wrapping
 NB_HD64 int64_t run_sat(int64_t v) { return v > kRunSat ? kRunSat : (v < -kRunSat ? -kRunSat : v); }
 NB_HD64 Run run_of(Step f) {
   Run r;
-  r.a[0] = r.lo[0] = r.hi[0] = run_sat((int64_t)f.a0);
-  r.a[1] = r.lo[1] = r.hi[1] = run_sat((int64_t)f.a1);
+  r.a0 = r.lo0 = r.hi0 = run_sat((int64_t)f.a0);
+  r.a1 = r.lo1 = r.hi1 = run_sat((int64_t)f.a1);
   return r;
 }
-NB_HD64 Run run_none() { return Run{{0, 0}, {0, 0}, {0, 0}}; }
-// f first, then g
+NB_HD64 Run run_none() { return Run{0, 0, 0, 0, 0, 0}; }
+// f first, then g.  All values travel as scalars: given `const Run&` the compiler fuses `q ? g.a1 : g.a0` into one load at a
+// computed address before it has inlined the call, and the run then lives in scratch memory on the device.
+NB_HD64 void run_then_from(int p, int64_t fa, int64_t flo, int64_t fhi, int64_t ga0, int64_t ga1, int64_t glo0, int64_t glo1, int64_t ghi0, int64_t ghi1,
+                   int64_t& ha, int64_t& hlo, int64_t& hhi) {
+  const bool q = (((int)(p + fa)) & 1) != 0;
+  const int64_t ga = q ? ga1 : ga0, glo = q ? glo1 : glo0, ghi = q ? ghi1 : ghi0;
+  ha = run_sat(fa + ga);
+  const int64_t gl = run_sat(fa + glo), gh = run_sat(fa + ghi);
+  hlo = flo < gl ? flo : gl;
+  hhi = fhi > gh ? fhi : gh;
+}
 NB_HD64 Run run_then(const Run& f, const Run& g) {
+  const int64_t ga0 = g.a0, ga1 = g.a1, glo0 = g.lo0, glo1 = g.lo1, ghi0 = g.hi0, ghi1 = g.hi1;
   Run h;
-  for (int p = 0; p < 2; ++p) {
-    const int q = (int)((p + f.a[p]) & 1);
-    const int64_t ga = q ? g.a[1] : g.a[0], glo = q ? g.lo[1] : g.lo[0], ghi = q ? g.hi[1] : g.hi[0];
-    h.a[p] = run_sat(f.a[p] + ga);
-    const int64_t gl = run_sat(f.a[p] + glo), gh = run_sat(f.a[p] + ghi);
-    h.lo[p] = f.lo[p] < gl ? f.lo[p] : gl;
-    h.hi[p] = f.hi[p] > gh ? f.hi[p] : gh;
-  }
+  run_then_from(0, f.a0, f.lo0, f.hi0, ga0, ga1, glo0, glo1, ghi0, ghi1, h.a0, h.lo0, h.hi0);
+  run_then_from(1, f.a1, f.lo1, f.hi1, ga0, ga1, glo0, glo1, ghi0, ghi1, h.a1, h.lo1, h.hi1);
   return h;
 }
 NB_HD64 bool run_fits(uint64_t S, const Run& r) {
-  const int p = (int)(S & 1ull);
-  return (int64_t)S + r.lo[p] > (int64_t)kLo && (int64_t)S + r.hi[p] < (int64_t)kHi;
+  const int64_t lo0 = r.lo0, lo1 = r.lo1, hi0 = r.hi0, hi1 = r.hi1;
+  const bool p = (S & 1ull) != 0ull;
+  return (int64_t)S + (p ? lo1 : lo0) > (int64_t)kLo && (int64_t)S + (p ? hi1 : hi0) < (int64_t)kHi;
 }
 // The binade a chain is predicted to be in over a segment whose exact prefix sums start at `p0` and end at `p1` (any f64
 // evaluation of them: the prediction only has to be right often, the run's own bounds decide): both ends inside one binade
@@ -139,7 +145,7 @@ inline double emulate_fold_segmented(const double* x, int64_t n, int seg, int64_
       for (int64_t k = c0; k < c1; ++k) r = run_then(r, run_of(step_of(x[k], pred.sign, pred.E)));
     Chain cur;
     if (have && chain_open(s, cur) && cur.E == pred.E && cur.sign == pred.sign && run_fits(cur.S, r)) {
-      s = chain_value(cur, (uint64_t)((int64_t)cur.S + r.a[cur.S & 1ull]));
+      s = chain_value(cur, (uint64_t)((int64_t)cur.S + ((cur.S & 1ull) ? r.a1 : r.a0)));
       ++used;
     } else {
       for (int64_t k = c0; k < c1; ++k) s = s + x[k];
