@@ -41,7 +41,10 @@ namespace {
 
 constexpr int kEPT = 4;          // consecutive points per thread in the rank-list passes
 constexpr int kSeqRun = 16;      // real adds after every stop of the scan
-constexpr int kChainStart = 256; // real adds at the start of a long node's chain (the sum doubles too often there)
+#ifndef NB_CHAIN_START
+#define NB_CHAIN_START 512
+#endif
+constexpr int kChainStart = NB_CHAIN_START; // real adds at the start of a long node's chain (the sum doubles too often there)
 constexpr int kSub = 2048;       // nodes up to this long are built, subtree and all, by one work-group in LDS
 constexpr int kSubWaves = 8;     // waves of a subtree work-group
 constexpr int kChunk = 2048;     // points per work-group in the multi-group passes over a long node
@@ -201,50 +204,114 @@ __device__ __forceinline__ void chain_run(PosPtr P, int begin, int count, int la
 }
 
 // ---- one coordinate out of LDS ------------------------------------------------------------------------------------------
-// A window of a node's coordinate, laid out so that neither of its two readers meets a bank conflict: a scan thread
-// takes 8 consecutive addends (a row each, the threads side by side), the chain's wave takes 16 consecutive ones.
+// s + X[0] + X[STRIDE] + ... (count addends, in order) from LDS, the same address in every lane (a broadcast read); count
+// uniform.  The adds depend on one another, the reads do not: the next 16 words are on their way while these 16 are added,
+// else every batch waits out the LDS latency (13+ clocks per addend instead of the 4-5 of a dependent add).  Two register
+// sets taken in turn; the sched_group_barriers keep the scheduler from sinking the reads below the adds they overlap.
+#define NB_CHAIN_LOAD(dst, from) _Pragma("unroll") for (int j_ = 0; j_ < 16; ++j_) dst[j_] = X[STRIDE * ((from) + j_)];
+#define NB_CHAIN_ADD(src) _Pragma("unroll") for (int j_ = 0; j_ < 16; ++j_) s = s + src[j_]; \
+  __builtin_amdgcn_sched_group_barrier(0x100, 16, 0); __builtin_amdgcn_sched_group_barrier(0x002, 16, 0);
+template <int STRIDE>
+__device__ __forceinline__ float chain_lds(const float* X, int count, float s) {
+  count = __builtin_amdgcn_readfirstlane(count);
+  int k = 0;
+  if (count >= 16) {
+    float va[16], vb[16];
+    NB_CHAIN_LOAD(va, 0)
+    for (; k + 48 <= count; k += 32) {  // va holds [k, k + 16) here
+      NB_CHAIN_LOAD(vb, k + 16)
+      NB_CHAIN_ADD(va)
+      NB_CHAIN_LOAD(va, k + 32)
+      NB_CHAIN_ADD(vb)
+    }
+    if (k + 32 <= count) {
+      NB_CHAIN_LOAD(vb, k + 16)
+      NB_CHAIN_ADD(va)
+      NB_CHAIN_ADD(vb)
+      k += 32;
+    } else {
+      NB_CHAIN_ADD(va)
+      k += 16;
+    }
+  }
+  for (; k < count; ++k) s = s + X[STRIDE * k];
+  return s;
+}
+#undef NB_CHAIN_LOAD
+#undef NB_CHAIN_ADD
+// both coordinates of P[0 .. count) at once (two independent chains share the reads)
+__device__ __forceinline__ void chain_lds_xy(const float2* P, int count, float& sx, float& sy) {
+  count = __builtin_amdgcn_readfirstlane(count);
+  int k = 0;
+#define NB_CHAIN_LOAD(dst, from) _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) dst[j_] = P[(from) + j_];
+#define NB_CHAIN_ADD(src) _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) { sx = sx + src[j_].x; sy = sy + src[j_].y; } \
+  __builtin_amdgcn_sched_group_barrier(0x100, 8, 0); __builtin_amdgcn_sched_group_barrier(0x002, 16, 0);
+  if (count >= 8) {
+    float2 va[8], vb[8];
+    NB_CHAIN_LOAD(va, 0)
+    for (; k + 24 <= count; k += 16) {  // va holds [k, k + 8) here
+      NB_CHAIN_LOAD(vb, k + 8)
+      NB_CHAIN_ADD(va)
+      NB_CHAIN_LOAD(va, k + 16)
+      NB_CHAIN_ADD(vb)
+    }
+    if (k + 16 <= count) {
+      NB_CHAIN_LOAD(vb, k + 8)
+      NB_CHAIN_ADD(va)
+      NB_CHAIN_ADD(vb)
+      k += 16;
+    } else {
+      NB_CHAIN_ADD(va)
+      k += 8;
+    }
+  }
+#undef NB_CHAIN_LOAD
+#undef NB_CHAIN_ADD
+  for (; k < count; ++k) { sx = sx + P[k].x; sy = sy + P[k].y; }
+}
+
+// A window of a node's coordinate.  A scan thread takes 8 consecutive addends: one word of padding after every 8 puts the
+// threads of a wave 9 words apart (all 64 banks); the chain reads the window front to back, 8 words at fixed offsets from
+// one address.
 template <int NT> struct StageView {
-  static constexpr int kRow = NT + 8;  // 8 rows, 8 banks apart
-  static constexpr int kWords = 8 * kRow;
+  static constexpr int kWords = NT * 9 + 8;
   float* b;
-  __device__ __forceinline__ static int at(int e) { return (e & 7) * kRow + (e >> 3); }
+  __device__ __forceinline__ static int at(int e) { return e + (e >> 3); }
   __device__ __forceinline__ float operator[](int e) const { return b[at(e)]; }
 };
-__device__ __forceinline__ void chain_add16_one(float& s, float v) {
-  asm volatile("s_nop 1" ::: "memory");
-#define NB_ADD(K) add_row_lane<K>(s, v);
-  NB_ADD(0) NB_ADD(1) NB_ADD(2) NB_ADD(3) NB_ADD(4) NB_ADD(5) NB_ADD(6) NB_ADD(7)
-  NB_ADD(8) NB_ADD(9) NB_ADD(10) NB_ADD(11) NB_ADD(12) NB_ADD(13) NB_ADD(14) NB_ADD(15)
-#undef NB_ADD
-}
-__device__ __forceinline__ void chain_add_some_one(float& s, float v, int cnt) {  // cnt < 16, uniform
-  asm volatile("s_nop 1" ::: "memory");
-#define NB_ADD(K) if (K < cnt) add_row_lane<K>(s, v);
-  NB_ADD(0) NB_ADD(1) NB_ADD(2) NB_ADD(3) NB_ADD(4) NB_ADD(5) NB_ADD(6) NB_ADD(7)
-  NB_ADD(8) NB_ADD(9) NB_ADD(10) NB_ADD(11) NB_ADD(12) NB_ADD(13) NB_ADD(14)
-#undef NB_ADD
-}
-// s += V[begin .. begin+count) in order, by one wave (chain_run for one coordinate); mn / mx take the same values
-template <class Src>
-__device__ __forceinline__ void chain_run_one(const Src& V, int begin, int count, int lane, float& s, float& mn, float& mx) {
-  const int sub = lane & 15;
-  const int end = begin + count;
-  float q = 0.f;
-  if (begin + sub < end) q = V[begin + sub];
-  for (int p = begin; p < end; p += 16) {
-    float nq = 0.f;
-    if (p + 16 + sub < end) nq = V[p + 16 + sub];
-    const int cnt = end - p;
-    if (cnt >= 16) {
-      mn = sse_min(mn, q);
-      mx = sse_max(mx, q);
-      chain_add16_one(s, q);
-    } else {
-      if (sub < cnt) { mn = sse_min(mn, q); mx = sse_max(mx, q); }
-      chain_add_some_one(s, q, cnt);
+// s += V[begin .. begin+count) in order, in every lane of every wave that calls (begin, count uniform): all lanes read the
+// same LDS word (a broadcast) and add it, 8 clocks per add (node_in_lds below does the same).  No result to hand round.
+template <int NT>
+__device__ __forceinline__ void chain_run_all(const StageView<NT>& V, int begin, int count, float& s) {
+  int e = __builtin_amdgcn_readfirstlane(begin);
+  const int end = e + __builtin_amdgcn_readfirstlane(count);
+  for (; e < end && (e & 7) != 0; ++e) s = s + V[e];
+  if (e + 8 <= end) {  // groups of 8 addends at fixed offsets from one address, the next group in flight
+    const float* g = V.b + (e + (e >> 3));
+#define NB_CHAIN_LOAD(dst, grp) _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) dst[j_] = g[9 * (grp) + j_];
+#define NB_CHAIN_ADD(src) _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) s = s + src[j_]; \
+  __builtin_amdgcn_sched_group_barrier(0x100, 8, 0); __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+    float va[8], vb[8];
+    NB_CHAIN_LOAD(va, 0)
+    for (; e + 24 <= end; e += 16, g += 18) {  // va holds [e, e + 8) here
+      NB_CHAIN_LOAD(vb, 1)
+      NB_CHAIN_ADD(va)
+      NB_CHAIN_LOAD(va, 2)
+      NB_CHAIN_ADD(vb)
     }
-    q = nq;
+    if (e + 16 <= end) {
+      NB_CHAIN_LOAD(vb, 1)
+      NB_CHAIN_ADD(va)
+      NB_CHAIN_ADD(vb)
+      e += 16;
+    } else {
+      NB_CHAIN_ADD(va)
+      e += 8;
+    }
+#undef NB_CHAIN_LOAD
+#undef NB_CHAIN_ADD
   }
+  for (; e < end; ++e) s = s + V[e];
 }
 
 // ---- scans over the lanes by DPP (a ds_bpermute per step costs a trip through the LDS pipe) -----------------------------------
@@ -276,7 +343,6 @@ template <int NW> struct Scratch {
   float redf[2][NW];
   int bad;
   uint32_t bad_s;
-  uint32_t seq_s[2];       // the sum after a run of real adds; two slots, taken in turn
 };
 
 template <int NW> __device__ __forceinline__ void group_sync() {
@@ -325,7 +391,7 @@ __device__ __forceinline__ void exact_fold(const Src& P, int begin, int len, flo
   float s = s_in;  // uniform across the group
   float mn = kMaxF, mx = 0.f;
   int pos = begin;
-  int par = 0, qar = 0;
+  int par = 0;
   bool seq = false;       // decided from s: a chain at 0.0 is not in any binade yet
   bool foreseen = false;  // the last thing done was a run of real adds up to a crossing that was seen coming
   while (pos < len) {
@@ -348,7 +414,7 @@ __device__ __forceinline__ void exact_fold(const Src& P, int begin, int len, flo
       if (safe < 64) {
         seq = true;
         seq_cnt = irem + (irem >> 4) + kSeqRun;
-        seq_cnt = seq_cnt < 512 ? seq_cnt : 512;
+        seq_cnt = seq_cnt < NW * 64 ? seq_cnt : NW * 64;
         foreseen = true;
       } else {
         span = span < safe ? span : safe;
@@ -356,16 +422,17 @@ __device__ __forceinline__ void exact_fold(const Src& P, int begin, int len, flo
     } else {
       foreseen = false;
     }
-    if (seq) {  // real adds by ONE wave; the others wait for the result
+    if (seq) {  // real adds, by every wave for itself: nothing to wait for, nothing to pass on
 #ifdef NB_FOLD_TIMING
       const long long tq0 = wall_clock64();
 #endif
       const int cnt = len - pos < seq_cnt ? len - pos : seq_cnt;
-      if (wave == 0) chain_run_one(P, pos, cnt, lane, s, mn, mx);
-      if (tid == 0) sh->seq_s[qar] = xsum::f2u(s);
-      __syncthreads();
-      s = xsum::u2f(sh->seq_s[qar]);
-      qar ^= 1;
+      chain_run_all(P, pos, cnt, s);
+      for (int i = tid; i < cnt; i += NW * 64) {
+        const float v = P[pos + i];
+        mn = sse_min(mn, v);
+        mx = sse_max(mx, v);
+      }
       pos += cnt;
       seq = false;
 #ifdef NB_FOLD_TIMING
@@ -1013,7 +1080,7 @@ __global__ __launch_bounds__(512) void bvh_big_fold(BvhPtrs a, int level, int us
 __global__ __launch_bounds__(256) void bvh_big_count(BvhPtrs a, int level, int leaf_size) {
   __shared__ unsigned red[2][4];
   __shared__ int last_flag;
-  __shared__ int kid[2], kid_c0[2], kid_n[2];
+  __shared__ int kid[2], kid_c0[2], kid_n[2], drawn[6];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nc = a.chunkcount[level];
   const int* ch_node = a.ch_node + (size_t)(level & 1) * a.cap_chunk;
@@ -1074,32 +1141,61 @@ __global__ __launch_bounds__(256) void bvh_big_count(BvhPtrs a, int level, int l
       carry += total;
       __syncthreads();
     }
+    // The counters this node draws from (node ids, the list of nodes above the subtrees, the next level's queue and chunks
+    // per long child) are independent of one another: six threads ask at once, one round trip instead of six in a row.
+    {
+      const int d = a.ndepth[node];
+      if (tid < 6) {
+        const int side = tid & 1;
+        const int cl = side ? len - m : m;
+        const bool inner = cl > leaf_size && d + 1 < kBvhKeyDepth;  // make_children's rule
+        int got = -1;
+        if (tid == 0) got = alloc_nodes(a, 2);
+        else if (tid == 1) got = atomicAdd(&a.flags[kBvhTopCount], 2);  // node ids: at most cap of them
+        else if (tid < 4) {
+          if (inner && cl > kSub) got = atomicAdd(&a.bigcount[level + 1], 1);
+        } else if (inner && cl > kSub) {
+          got = atomicAdd(&a.chunkcount[level + 1], (cl + kChunk - 1) / kChunk);  // its chunks for the next level's passes
+        }
+        drawn[tid] = got;
+      }
+    }
+    __syncthreads();
     if (tid == 0) {
       kid[0] = kid[1] = -1;
       a.nsplit[node] = m | (on_x ? (int)0x80000000 : 0);
       bool leaf[2];
-      const int first = alloc_nodes(a, 2);
+      const int first = drawn[0];
       if (first >= 0) {
         make_children(a, node, first, b, len, m, leaf_size, leaf);
-        const int tslot = atomicAdd(&a.flags[kBvhTopCount], 2);  // node ids: at most cap of them
+        const int tslot = drawn[1];
         a.topq[tslot] = first;
         a.topq[tslot + 1] = first + 1;
         for (int side = 0; side < 2; ++side) {
           if (leaf[side]) continue;
           const int cl = side ? len - m : m;
+          const int slot = drawn[2 + side];
           if (cl > kSub) {
-            const int slot = atomicAdd(&a.bigcount[level + 1], 1);
             if (slot < a.cap_big) a.bigq[(size_t)((level + 1) & 1) * a.cap_big + slot] = first + side;
             else a.flags[kBvhFallback] = 1;
-            const int cn = (cl + kChunk - 1) / kChunk;  // its chunks for the next level's passes
-            const int cc0 = atomicAdd(&a.chunkcount[level + 1], cn);
+            const int cn = (cl + kChunk - 1) / kChunk;
+            const int cc0 = drawn[4 + side];
             a.nchunk0[first + side] = cc0;
             if (cc0 + cn > a.cap_chunk) a.flags[kBvhFallback] = 1;
             else { kid[side] = first + side; kid_c0[side] = cc0; kid_n[side] = cn; }
           } else {
-            const int slot = atomicAdd(&a.flags[kBvhSubCount], 1);
-            a.subq[slot] = first + side;  // at most one entry per node: cap entries
+            a.subq[atomicAdd(&a.flags[kBvhSubCount], 1)] = first + side;  // at most one entry per node: cap entries
           }
+        }
+      } else {
+        // No ids left: the build is declined (alloc_nodes raised the flag), but the queue slots and chunks drawn above are
+        // read by the next level's passes all the same.  They get this node again: valid, and nobody looks at the result.
+        for (int side = 0; side < 2; ++side) {
+          const int cl = side ? len - m : m;
+          if (drawn[2 + side] < 0) continue;
+          if (drawn[2 + side] < a.cap_big) a.bigq[(size_t)((level + 1) & 1) * a.cap_big + drawn[2 + side]] = node;
+          const int cn = (cl + kChunk - 1) / kChunk;
+          if (drawn[4 + side] + cn <= a.cap_chunk) { kid[side] = node; kid_c0[side] = drawn[4 + side]; kid_n[side] = cn; }
         }
       }
     }
@@ -1207,6 +1303,10 @@ struct SubLds {
   int lcount[2];
   int idbase;  // first id of the children made at this level (one allocation per level)
   int loff[kBvhKeyDepth + 2];  // where each level of the subtree starts in its list of internal nodes
+  // nodes_by_groups: per wave partial results, per node sums
+  float4 gbox[kSubWaves];
+  float2 gsum[kSubWaves];
+  unsigned gcx[kSubWaves], gcy[kSubWaves], gtot[kSubWaves], gbad[kSubWaves];
 };
 
 // One node whose points are s.P[lb, lb+len): fold, axis, partition, children — by ONE wave.  Up to kSub points the
@@ -1221,12 +1321,7 @@ __device__ __forceinline__ void node_in_lds(const BvhPtrs& a, SubLds& s, int gbe
   // the chain: every lane reads the same LDS word (a broadcast) and adds it — 8 clocks per add, measured against 14 for
   // the DPP broadcast and 10 for v_readlane (tools/chain_microbench.hip)
   float sx = 0.f, sy = 0.f;
-#pragma unroll 16
-  for (int k = 0; k < len; ++k) {
-    const float2 q = P[k];
-    sx = sx + q.x;
-    sy = sy + q.y;
-  }
+  chain_lds_xy(P, len, sx, sy);
   const float hx = sx / (float)len, hy = sy / (float)len;  // :67
   Box box;
   unsigned cx = 0u, cy = 0u;
@@ -1348,6 +1443,130 @@ __device__ __forceinline__ void leaf_by_wave(const BvhPtrs& a, int leaf, PosPtr 
   }
 }
 
+// The first levels of a subtree have fewer nodes than the work-group has waves: G waves share a node (nc * G <= kSubWaves).
+// What node_in_lds does, spread out: the two chains (one add after the other) get a wave each; box, counts, rank lists and
+// swaps are split G ways.  Every wave runs the same number of barriers
+// (the longest node of the level sets the number of rank-list rounds).
+template <int G>
+__device__ __forceinline__ void nodes_by_groups(const BvhPtrs& a, SubLds& s, int gbegin, int cur, int nc, int idbase, int tid,
+                                                int leaf_size) {
+  static_assert(G >= 2 && kSubWaves % G == 0, "at least one wave beside the chain's");
+  constexpr int TILE = 64 * kEPT;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int grp = wave / G, gw = wave % G, w0 = grp * G;
+  const bool act = grp < nc;
+  const int lb = act ? s.lb[cur][grp] : 0, len = act ? s.ll[cur][grp] : 0, gid = act ? s.lg[cur][grp] : 0;
+  int maxlen = 0;
+  for (int e = 0; e < nc; ++e) maxlen = maxlen > (int)s.ll[cur][e] ? maxlen : (int)s.ll[cur][e];
+  float2* P = s.P + lb;
+  uint16_t* I = s.I + lb;
+  uint16_t* L = s.L + lb;
+  uint16_t* R = s.R + lb;
+  // the two chains, a wave each (one dependent add per point instead of two)
+  if (gw < 2) {
+    const float sc = chain_lds<2>(reinterpret_cast<const float*>(P) + gw, len, 0.f);
+    if (lane == 0) (gw ? s.gsum[grp].y : s.gsum[grp].x) = sc;
+  }
+  __syncthreads();
+  const float2 sum = s.gsum[grp];
+  const float hx = sum.x / (float)len, hy = sum.y / (float)len;  // :67
+  Box box;
+  unsigned cx = 0u, cy = 0u;
+  for (int i = gw * 64 + lane; i < len; i += G * 64) {
+    const float2 q = P[i];
+    box.add(q);
+    cx += q.x > hx;
+    cy += q.y > hy;
+  }
+  box.reduce_wave();
+  cx = group_sum<1>(cx, nullptr, lane);
+  cy = group_sum<1>(cy, nullptr, lane);
+  if (lane == 0) {
+    s.gbox[wave] = make_float4(box.mnx, box.mny, box.mxx, box.mxy);
+    s.gcx[wave] = cx;
+    s.gcy[wave] = cy;
+  }
+  __syncthreads();
+  cx = 0u; cy = 0u;
+  box = Box();
+  for (int w = 0; w < G; ++w) {
+    const float4 bx = s.gbox[w0 + w];
+    box.mnx = sse_min(box.mnx, bx.x); box.mny = sse_min(box.mny, bx.y);
+    box.mxx = sse_max(box.mxx, bx.z); box.mxy = sse_max(box.mxy, bx.w);
+    cx += s.gcx[w0 + w];
+    cy += s.gcy[w0 + w];
+  }
+  bool on_x;
+  const int m = choose_axis(len, (int)cx, (int)cy, on_x);
+  unsigned carry = 0u, nbad = 0u;
+  for (int r0 = 0; r0 < maxlen; r0 += G * TILE) {
+    const int base = r0 + gw * TILE + lane * kEPT;
+    bool pr[kEPT];
+    unsigned mine = 0u;
+#pragma unroll
+    for (int j = 0; j < kEPT; ++j) {
+      pr[j] = false;
+      if (base + j < len) {
+        const float2 q = P[base + j];
+        pr[j] = on_x ? q.x > hx : q.y > hy;
+        mine += pr[j];
+      }
+    }
+    unsigned inc = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const unsigned o = (unsigned)__shfl_up((int)inc, d, 64);
+      if (lane >= d) inc += o;
+    }
+    if (lane == 63) s.gtot[wave] = inc;
+    __syncthreads();
+    unsigned before = carry, total = 0u;
+    for (int w = 0; w < G; ++w) {
+      const unsigned v = s.gtot[w0 + w];
+      if (w < gw) before += v;
+      total += v;
+    }
+    unsigned t = before + inc - mine;
+#pragma unroll
+    for (int j = 0; j < kEPT; ++j) {
+      const int i = base + j;
+      if (i < len) {
+        if (i < m && !pr[j]) { L[i - (int)t] = (uint16_t)i; ++nbad; }
+        else if (i >= m && pr[j]) R[m - (int)t - 1] = (uint16_t)i;
+        t += pr[j];
+      }
+    }
+    carry += total;
+    __syncthreads();  // gtot is rewritten by the next round; after the last one: the rank lists are complete
+  }
+  nbad = group_sum<1>(nbad, nullptr, lane);
+  if (lane == 0) s.gbad[wave] = nbad;
+  __syncthreads();
+  nbad = 0u;
+  for (int w = 0; w < G; ++w) nbad += s.gbad[w0 + w];
+  for (int k = gw * 64 + lane; k < (int)nbad; k += G * 64) {
+    const int l = L[k], r = R[k];
+    const float2 pl = P[l], pr = P[r];
+    P[l] = pr; P[r] = pl;
+    const uint16_t il = I[l], ir = I[r];
+    I[l] = ir; I[r] = il;
+  }
+  if (act && gw == 0 && lane == 0) {
+    a.nbox[gid] = make_float4(box.mnx, box.mny, box.mxx, box.mxy);
+    bool leaf[2];
+    const int first = idbase + 2 * grp;
+    make_children(a, gid, first, gbegin + lb, len, m, leaf_size, leaf);
+    const int nxt = cur ^ 1;
+    for (int side = 0; side < 2; ++side) {
+      if (leaf[side]) continue;
+      const int slot = atomicAdd(&s.lcount[nxt], 1);
+      s.lb[nxt][slot] = (uint16_t)(side ? lb + m : lb);
+      s.ll[nxt][slot] = (uint16_t)(side ? len - m : m);
+      s.lg[nxt][slot] = first + side;
+    }
+  }
+}
+
 __global__ __launch_bounds__(kSubWaves * 64) void bvh_subtrees(BvhPtrs a, const uint32_t* __restrict__ weight, int leaf_size,
                                                               int sub_start) {
   __shared__ SubLds s;
@@ -1397,8 +1616,12 @@ __global__ __launch_bounds__(kSubWaves * 64) void bvh_subtrees(BvhPtrs a, const 
       if (idbase < 0) break;
       nint += nc;
       ++nlev;
-      for (int e = wave; e < nc; e += kSubWaves)  // a wave per node
-        node_in_lds(a, s, b, s.lb[cur][e], s.ll[cur][e], s.lg[cur][e], idbase + 2 * e, lane, cur ^ 1, leaf_size);
+      if (nc == 1) nodes_by_groups<kSubWaves>(a, s, b, cur, nc, idbase, tid, leaf_size);
+      else if (nc == 2) nodes_by_groups<kSubWaves / 2>(a, s, b, cur, nc, idbase, tid, leaf_size);
+      else if (nc <= 4) nodes_by_groups<kSubWaves / 4>(a, s, b, cur, nc, idbase, tid, leaf_size);
+      else
+        for (int e = wave; e < nc; e += kSubWaves)  // a wave per node
+          node_in_lds(a, s, b, s.lb[cur][e], s.ll[cur][e], s.lg[cur][e], idbase + 2 * e, lane, cur ^ 1, leaf_size);
       __syncthreads();
       if (tid == 0) s.lcount[cur] = 0;
       cur ^= 1;
@@ -1465,9 +1688,13 @@ __global__ __launch_bounds__(kSubWaves * 64) void bvh_subtrees(BvhPtrs a, const 
 // The nodes above the subtrees (topq): leaves hanging directly off a long node, then the long nodes themselves,
 // deepest level first.  One work-group: a few hundred nodes (a few thousand at N = 4M).
 __global__ __launch_bounds__(256) void bvh_top_upward(BvhPtrs a, const uint32_t* __restrict__ weight) {
+  constexpr int kKeep = 4096;       // entries whose (id, depth) stay in LDS; more than that are read again every level
+  __shared__ int s_id[kKeep];
+  __shared__ int16_t s_depth[kKeep];  // depth of a long internal node, -1: not one (a leaf, a subtree root)
+  __shared__ int s_dmax;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n_top = a.flags[kBvhTopCount];
-  if (tid == 0) a.flags[kBvhBadIndex] = 0;
+  if (tid == 0) { a.flags[kBvhBadIndex] = 0; s_dmax = -1; }
   for (int e = wave; e < n_top; e += 4) {
     const int id = a.topq[e];
     if (!a.nleaf[id]) continue;
@@ -1476,19 +1703,38 @@ __global__ __launch_bounds__(256) void bvh_top_upward(BvhPtrs a, const uint32_t*
     leaf_by_wave(a, id, (const float2*)(a.P + b), a.nlen[id], lane, weight, [&](int i) { return ids[i]; });
   }
   __syncthreads();
-  for (int d = a.flags[kBvhMaxDepth]; d >= 0; --d) {
+  // what each entry is, once: the level loops below visit every entry at every depth
+  const auto describe = [&](int e, int& id) {
+    id = a.topq[e];
+    return (!a.nleaf[id] && a.nlen[id] > kSub) ? a.ndepth[id] : -1;
+  };
+  int dmax = -1;
+  for (int e = tid; e < n_top; e += 256) {
+    int id;
+    const int d = describe(e, id);
+    if (e < kKeep) { s_id[e] = id; s_depth[e] = (int16_t)d; }
+    dmax = d > dmax ? d : dmax;
+  }
+  if (dmax >= 0) atomicMax(&s_dmax, dmax);
+  __syncthreads();
+  dmax = s_dmax;  // deepest long node: the tree below it belongs to the subtrees
+  const auto entry = [&](int e, int& id) {
+    if (e < kKeep) { id = s_id[e]; return (int)s_depth[e]; }
+    return describe(e, id);
+  };
+  for (int d = dmax; d >= 0; --d) {
     for (int e = tid; e < n_top; e += 256) {
-      const int id = a.topq[e];
-      if (a.ndepth[id] == d && !a.nleaf[id] && a.nlen[id] > kSub) combine_children(a, id);
+      int id;
+      if (entry(e, id) == d) combine_children(a, id);
     }
     __syncthreads();
   }
   // pre-order numbers, top down: a node, its left subtree, its right subtree (the root has number 0); the nodes inside the
   // subtrees find theirs from here in bvh_emit
-  for (int d = 0; d <= a.flags[kBvhMaxDepth]; ++d) {
+  for (int d = 0; d <= dmax; ++d) {
     for (int e = tid; e < n_top; e += 256) {
-      const int id = a.topq[e];
-      if (a.ndepth[id] == d && !a.nleaf[id] && a.nlen[id] > kSub) {
+      int id;
+      if (entry(e, id) == d) {
         const int c0 = a.nchild[id];
         if (c0 >= 0) {
           a.npre[c0] = a.npre[id] + 1;

@@ -620,6 +620,11 @@ template <class T> int bvh_build_device(nbody_ctx* c, State<T>& s) {
     if (env_int("NBODY_TRACE", 0) != 0)
       std::fprintf(stderr, "[nbody] device bvh build: %d nodes, depth %d, %d subtrees, %d long-node levels, %d scan restarts, %d prepared chunk runs used\n",
                    hostf[kBvhNodeCount], hostf[kBvhMaxDepth], hostf[kBvhSubCount], lv_end, hostf[kBvhStops], hostf[kBvhRunsUsed]);
+#ifdef NB_BVH_TIMING
+    std::fprintf(stderr, "[nbody] bvh_subtrees, slowest group per phase (10 ns ticks): load %d, level 1 %d, level 2 %d, level 3 %d, other levels %d, leaves %d, upward %d, store %d\n",
+                 hostf[kBvhDebug], hostf[kBvhDebug + 1], hostf[kBvhDebug + 2], hostf[kBvhDebug + 3], hostf[kBvhDebug + 4], hostf[kBvhDebug + 5],
+                 hostf[kBvhDebug + 6], hostf[kBvhDebug + 7]);
+#endif
     const int m = hostf[kBvhNodeCount];
     if (m <= 0 || m > L.node_cap || hostf[kBvhBadIndex] != 0) return 1;
     s.cur = 1 - s.cur;
