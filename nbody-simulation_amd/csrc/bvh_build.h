@@ -32,7 +32,8 @@ struct BvhBuildLayout {
 BvhBuildLayout bvh_build_layout(int64_t n, int leaf_size);
 
 // Zeroes the counters, copies the positions into the working array and seeds the root.
-hipError_t bvh_build_begin(hipStream_t s, const void* pos, int n, char* scratch, const BvhBuildLayout& L);
+// flags_clean: the flags and level counters are zero already (the step before left them so: TileTail::clear_flags).
+hipError_t bvh_build_begin(hipStream_t s, const void* pos, int n, char* scratch, const BvhBuildLayout& L, bool flags_clean = false);
 // Levels of long nodes a balanced tree over n points has (the caller enqueues these blind, then asks).
 int bvh_build_first_levels(int64_t n);
 // Enqueues the long-node passes of levels [level_begin, level_end).  bigcount[level_end] != 0 afterwards: more to do.
@@ -46,6 +47,9 @@ hipError_t bvh_build_finish(hipStream_t s, const uint32_t* weight, int n, int le
                             const BvhBuildLayout& L,
                             uint32_t* order_out, void* geom0, void* geom1, void* link, int* depth_out, uint32_t* mass_out,
                             float2* size_out);
+// The permutation where the build leaves it (n words inside `scratch`): with order_out == nullptr bvh_build_finish does not
+// copy it out, the caller's gather reads it here.
+const uint32_t* bvh_build_order(const char* scratch, const BvhBuildLayout& L);
 
 // What the host would conclude from the flags after bvh_build_finish, written on the stream for kernels enqueued ahead
 // of that conclusion: verdict[0] = node count if the build is complete and usable (no fallback, no long node left at

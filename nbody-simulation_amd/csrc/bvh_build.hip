@@ -1849,8 +1849,8 @@ int bvh_build_first_levels(int64_t n) {
   return lv;
 }
 
-hipError_t bvh_build_begin(hipStream_t s, const void* pos, int n, char* scratch, const BvhBuildLayout& L) {
-  hipError_t e = hipMemsetAsync(scratch + L.flags, 0, L.zero_end - L.flags, s);  // flags + level counters
+hipError_t bvh_build_begin(hipStream_t s, const void* pos, int n, char* scratch, const BvhBuildLayout& L, bool flags_clean) {
+  hipError_t e = flags_clean ? hipSuccess : hipMemsetAsync(scratch + L.flags, 0, L.zero_end - L.flags, s);  // flags + level counters
   if (e != hipSuccess) return e;
   BvhPtrs a = make_ptrs(scratch, L);
   bvh_init<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>(a, (const float2*)pos, n);
@@ -1899,8 +1899,10 @@ hipError_t bvh_build_finish(hipStream_t s, const uint32_t* weight, int n, int le
   bvh_emit<<<gm, dim3(256), 0, s>>>(a, (float4*)geom0, (float4*)geom1, (int4*)link, depth_out, mass_out, size_out);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
+  if (!order_out) return hipSuccess;
   return hipMemcpyAsync(order_out, a.ID, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToDevice, s);
 }
+const uint32_t* bvh_build_order(const char* scratch, const BvhBuildLayout& L) { return (const uint32_t*)(scratch + L.ids); }
 
 namespace {
 __global__ void bvh_verdict_kernel(const int* __restrict__ flags, const int* __restrict__ bigcount, int level_end, int node_cap,

@@ -558,6 +558,7 @@ template <class T> int bvh_build_device(nbody_ctx* c, State<T>& s) {
     }
     auto& in = s.set[s.cur];
     auto& out = s.set[1 - s.cur];
+    s.bb_flags_clean = false;
     HIPCHK(c, bvh_build_begin(c->stream, in.pos, n, s.bb_scratch, L));
     int rc = ensure_node_buffers<T>(c, s, (size_t)L.node_cap);
     if (rc) return rc;
@@ -1048,7 +1049,7 @@ template <class T> int bvh_step_ahead(nbody_ctx* c, State<T>& s, T delta, PhaseE
     static_assert(kBvhFlagWords + kBvhLevels <= 128, "flags and level counters travel as one 512-byte block");
     if (L.bigcount - L.flags + kBvhLevels * sizeof(int) > 128 * sizeof(int)) return 1;
     if (!c->spec_dev) {
-      HIPCHK(c, hipMalloc((void**)&c->spec_dev, 2 * sizeof(int)));
+      HIPCHK(c, hipMalloc((void**)&c->spec_dev, (2 + kSpecWords) * sizeof(int)));  // the verdict, then the record packed for the host
       HIPCHK(c, hipHostMalloc((void**)&c->spec_host, kSpecWords * sizeof(int), hipHostMallocDefault));
       HIPCHK(c, hipEventCreateWithFlags(&c->spec_event, hipEventDisableTiming));
     }
@@ -1064,13 +1065,17 @@ template <class T> int bvh_step_ahead(nbody_ctx* c, State<T>& s, T delta, PhaseE
     if (lv_end > 0 && s.bvh_levels_hint > 0 && s.bvh_levels_hint + 1 < lv_end) lv_end = s.bvh_levels_hint + 1;
     if (lv_end > 0) lv_end = std::max(1, env_int("NBODY_BVH_BLIND_LEVELS", lv_end));  // tests: too few levels, the verdict fails
     if (lv_end > kBvhKeyDepth + 1) lv_end = kBvhKeyDepth + 1;
-    HIPCHK(c, bvh_build_begin(c->stream, in.pos, n, s.bb_scratch, L));
+    const bool flags_clean = s.bb_flags_clean;
+    s.bb_flags_clean = false;
+    HIPCHK(c, bvh_build_begin(c->stream, in.pos, n, s.bb_scratch, L, flags_clean));
     if (lv_end > 0) HIPCHK(c, bvh_build_levels(c->stream, n, leaf, 0, lv_end, s.bb_scratch, L));
-    HIPCHK(c, bvh_build_finish(c->stream, in.weight, n, leaf, 0, s.bb_scratch, L, s.order_dev, s.geom0, s.geom1, s.link, s.node_depth,
+    HIPCHK(c, bvh_build_finish(c->stream, in.weight, n, leaf, 0, s.bb_scratch, L, nullptr, s.geom0, s.geom1, s.link, s.node_depth,
                                s.node_mass, s.node_size));
-    HIPCHK(c, bvh_build_verdict(c->stream, lv_end, s.bb_scratch, L, c->spec_dev));
+    int* walk_info = (int*)(s.ws_scratch + WL.info);
     GatherArgs<T> g{};
-    g.perm = s.order_dev;
+    g.perm = bvh_build_order(s.bb_scratch, L);  // read where the build left it, and copied out on the way
+    g.perm_copy = s.order_dev;
+    g.zero8 = walk_info;  // the estimate check's counters (launch_tree_walk_tile_prep below)
     g.n = n;
     g.pos_in = in.pos; g.pos_out = out.pos;
     g.weight_in = in.weight;
@@ -1102,12 +1107,23 @@ template <class T> int bvh_step_ahead(nbody_ctx* c, State<T>& s, T delta, PhaseE
     if (env_int("NBODY_WALK_TILE_POISON", 0) != 0)  // test hook: a history whose scan wraps must be noticed
       HIPCHK(c, hipMemsetAsync(s.wt_hist, 0xFF, (size_t)s.n * 4, c->stream));
     int64_t waves = 0;
-    HIPCHK(c, launch_tree_walk_tile_prep<T>(c->stream, w, s.ws_scratch, WL, tgt_ids, s.wt_hist, 1, shift, &waves));
-    int* walk_info = (int*)(s.ws_scratch + WL.info);
+    // The estimate check's last work-group concludes on the build (the verdict the walk kernel reads), packs verdict, build
+    // flags and walk info for one copy to the host and clears the build's counters for the next step.
+    TileTail tail;
+    tail.flags = (const int*)(s.bb_scratch + L.flags);
+    tail.flag_words = 128;
+    tail.bigcount = (const int*)(s.bb_scratch + L.bigcount);
+    tail.level_end = lv_end;
+    tail.node_cap = L.node_cap;
+    tail.verdict = c->spec_dev;
+    tail.pack = c->spec_dev + 2;
+    tail.clear = (int*)(s.bb_scratch + L.flags);
+    tail.clear_words = (int)((L.zero_end - L.flags) / sizeof(int));
+    tail.info_zeroed = true;
+    HIPCHK(c, launch_tree_walk_tile_prep<T>(c->stream, w, s.ws_scratch, WL, tgt_ids, s.wt_hist, 1, shift, &waves, &tail));
+    s.bb_flags_clean = true;
     int* h = c->spec_host;
-    HIPCHK(c, hipMemcpyAsync(h, c->spec_dev, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(h + 2, s.bb_scratch + L.flags, 128 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(h + 2 + 128, walk_info, 8 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(h, c->spec_dev + 2, (2 + 128 + 8) * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipEventRecord(c->spec_event, c->stream));
     {
       TimerScope ts(c->timer, c->stream);

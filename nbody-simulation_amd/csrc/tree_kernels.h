@@ -50,6 +50,8 @@ template <class T> struct GatherArgs {
   const uint32_t* weight_in; uint32_t* weight_out;
   const uint32_t* ids_in; uint32_t* ids_out;
   T* mass_out;
+  uint32_t* perm_copy = nullptr;  // the permutation itself, written out once more (a step enqueued ahead reads it where the build left it)
+  int* zero8 = nullptr;           // 8 words set to zero by the first thread (counters of a kernel further down the stream)
 };
 
 template <class T> hipError_t launch_tree_walk(hipStream_t s, const WalkArgs<T>& a, bool wave_uniform);

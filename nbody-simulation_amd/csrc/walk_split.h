@@ -33,9 +33,24 @@ hipError_t launch_tree_walk_tile(hipStream_t s, const WalkArgs<T>& a, char* scra
 
 // The same in two halves (preparation: estimate scan, wrap check, budget — info[0..3] final; then the walk kernel), for
 // a caller that enqueues a copy of info and an event in between.
+// tail (estimate 1 only): what a step enqueued ahead of the host needs between its build and its walk rides along with the
+// estimate check instead of costing launches of its own — the check's last work-group also sets the budget, concludes on the
+// build (what bvh_build_verdict would), packs verdict | build flags | info for ONE copy to the host, and clears the build's
+// counters for the next step.
+struct TileTail {
+  const int* flags = nullptr;     // the build's flags and level counters: flag_words of them are packed
+  int flag_words = 0;
+  const int* bigcount = nullptr;  // verdict: no long node left at level_end, no fallback, every node numbered, count <= node_cap
+  int level_end = 0, node_cap = 0;
+  int* verdict = nullptr;         // device: [0] node count or 0 (walk_tile reads it), [1] 0/1
+  int* pack = nullptr;            // verdict (2) | flags (flag_words) | info (8)
+  int* clear = nullptr;           // zeroed once packed
+  int clear_words = 0;
+  bool info_zeroed = false;       // info is zero already (an earlier kernel of the stream did it)
+};
 template <class T>
 hipError_t launch_tree_walk_tile_prep(hipStream_t s, const WalkArgs<T>& a, char* scratch, const WalkSplitLayout& L, const uint32_t* tgt_ids,
-                                      uint32_t* hist, int estimate, int shift, int64_t* grid_waves);
+                                      uint32_t* hist, int estimate, int shift, int64_t* grid_waves, const TileTail* tail = nullptr);
 template <class T>
 hipError_t launch_tree_walk_tile_main(hipStream_t s, const WalkArgs<T>& a, char* scratch, const WalkSplitLayout& L, const uint32_t* tgt_ids,
                                       uint32_t* hist, int64_t grid_waves);

@@ -20,6 +20,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include "bvh_build.h"
 #include "walk_split.h"
 
 namespace nbody {
@@ -546,9 +547,9 @@ __global__ __launch_bounds__(256) void walk_check_wrap_est(EstimateOf est, const
   if (i + 1 == n && (unsigned long long)off[i] + est((int)i) > 0x7fffffffull) info[1] = 1;  // the budget arithmetic is 31 bits wide
 }
 // budget of walk_tile's waves from the estimate's total (see walk_total)
-__global__ void walk_tile_total(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off, int64_t n, const uint32_t* __restrict__ tgt_ids,
-                                const uint32_t* __restrict__ hist, int shift, int64_t extra_waves, int64_t grid_waves,
-                                int* __restrict__ info) {
+__device__ __forceinline__ void tile_total(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off, int64_t n,
+                                           const uint32_t* __restrict__ tgt_ids, const uint32_t* __restrict__ hist, int shift,
+                                           int64_t extra_waves, int64_t grid_waves, int* __restrict__ info) {
   const uint32_t last = n > 0 ? (cnt ? cnt[n - 1] : (hist ? hist[tgt_ids[n - 1]] >> shift : 0u)) : 0u;
   const unsigned long long total = n > 0 ? (unsigned long long)off[n - 1] + last : 0ull;
   info[0] = (int)(total > 0x7fffffffull ? 0x7fffffffull : total);
@@ -563,6 +564,89 @@ __global__ void walk_tile_total(const uint32_t* __restrict__ cnt, const uint32_t
   // the host then repeats the walk without an estimate (64 targets per wave, which always fits)
   if (total / budget + (unsigned long long)(n / 64) + 1 >= (unsigned long long)grid_waves) info[1] = 1;
   info[6] = info[7] = 0;  // this walk's total terms (unsigned long long), accumulated by walk_tile
+}
+__global__ void walk_tile_total(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off, int64_t n, const uint32_t* __restrict__ tgt_ids,
+                                const uint32_t* __restrict__ hist, int shift, int64_t extra_waves, int64_t grid_waves,
+                                int* __restrict__ info) {
+  tile_total(cnt, off, n, tgt_ids, hist, shift, extra_waves, grid_waves, info);
+}
+// walk_check_wrap_est, and in the work-group that finishes last: walk_tile_total and the TileTail duties (walk_split.h).
+// info[4] counts the finished groups, info[5] takes the estimate's total from the thread that meets the last target (zero
+// before, like the rest of info).
+__global__ __launch_bounds__(256) void walk_check_est_tail(EstimateOf est, const uint32_t* __restrict__ off, int64_t n, int64_t extra_waves,
+                                                           int64_t grid_waves, int* __restrict__ info, const TileTail tail) {
+  __shared__ int last_group;
+  const int tid = threadIdx.x;
+  // (few groups, each over many targets: every group ends with an atomic on ONE counter, ~60 ns apiece)
+  // four targets per thread and round, their loads side by side (a dependent gather each: hist[ids[i]])
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i0 = (int64_t)blockIdx.x * 256 + tid; i0 < n; i0 += 4 * stride) {
+    uint32_t o[4], e[4], nx[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int64_t i = i0 + k * stride;
+      o[k] = i < n ? off[i] : 0u;
+      e[k] = i < n ? est((int)i) : 0u;
+      nx[k] = i + 1 < n ? off[i + 1] : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int64_t i = i0 + k * stride;
+      const unsigned long long end = (unsigned long long)o[k] + e[k];
+      if (i + 1 < n && end != (unsigned long long)nx[k]) {
+        info[1] = 1;
+        info[2] = 1;
+      }
+      if (i + 1 == n) {
+        if (end > 0x7fffffffull) info[1] = 1;  // the budget arithmetic is 31 bits wide
+        info[5] = (int)(end > 0x7fffffffull ? 0x7fffffffull : end);
+      }
+    }
+  }
+  __threadfence();  // the flags above, before this group counts as finished
+  __syncthreads();
+  if (tid == 0) last_group = atomicAdd(&info[4], 1) == (int)gridDim.x - 1;
+  __syncthreads();
+  if (!last_group) return;
+  __threadfence();
+  const int my_flag = tail.pack && tid < tail.flag_words ? tail.flags[tid] : 0;  // (on its way while thread 0 works)
+  if (tid == 0) {
+    // what the other groups left, past this compute unit's cache
+    const int wrapped = __hip_atomic_load(&info[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int wrapped2 = __hip_atomic_load(&info[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long total = (unsigned long long)(unsigned)__hip_atomic_load(&info[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int out[8] = {0, wrapped, wrapped2, 0, 0, 0, 0, 0};
+    out[0] = (int)total;
+    // walk_tile_total's arithmetic (a total clipped to 2^31 - 1 has raised the flag already)
+    unsigned long long want = (total + (unsigned long long)extra_waves - 1) / (unsigned long long)extra_waves;
+    uint32_t budget = kTileBudget >> est.shift;
+    if (budget < 64) budget = 64;
+    while (budget < want && budget < (1u << 30)) budget <<= 1;
+    out[3] = (int)budget;
+    if (total / budget + (unsigned long long)(n / 64) + 1 >= (unsigned long long)grid_waves) out[1] = 1;
+    out[4] = (int)gridDim.x;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) info[k] = out[k];
+    int v0 = 0, v1 = 0;
+    if (tail.verdict) {
+      const int m = tail.flags[kBvhNodeCount];
+      const bool ok = tail.flags[kBvhFallback] == 0 && tail.flags[kBvhBadIndex] == 0 && m > 0 && m <= tail.node_cap &&
+                      (tail.level_end <= 0 || tail.bigcount[tail.level_end] == 0);
+      v0 = ok ? m : 0;
+      v1 = ok ? 1 : 0;
+      tail.verdict[0] = v0;
+      tail.verdict[1] = v1;
+    }
+    if (tail.pack) {
+      tail.pack[0] = v0;
+      tail.pack[1] = v1;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) tail.pack[2 + tail.flag_words + k] = out[k];
+    }
+  }
+  if (tail.pack && tid < tail.flag_words) tail.pack[2 + tid] = my_flag;
+  __syncthreads();  // the flags are in registers or packed: the next build's counters may go
+  for (int k = tid; k < tail.clear_words; k += 256) tail.clear[k] = 0;
 }
 
 inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -629,14 +713,16 @@ hipError_t launch_tree_walk_split(hipStream_t s, const WalkArgs<float>& a, char*
 // event between the two.  *grid_waves carries the wave count from the one to the other.
 template <class T>
 hipError_t launch_tree_walk_tile_prep(hipStream_t s, const WalkArgs<T>& a, char* scratch, const WalkSplitLayout& L, const uint32_t* tgt_ids,
-                                      uint32_t* hist, int estimate, int shift, int64_t* grid_waves) {
+                                      uint32_t* hist, int estimate, int shift, int64_t* grid_waves, const TileTail* tail) {
   const bool have_history = estimate != 0;  // 1: from hist; 2: none at all (every wave takes 64 targets)
   *grid_waves = 0;
+  if (tail && (estimate != 1 || a.n_tgt <= 0 || tail->flag_words > 256)) return hipErrorInvalidValue;  // the tail rides on the history estimate's check
   if (a.n_tgt <= 0) return hipSuccess;
   uint32_t* cnt = (uint32_t*)(scratch + L.cnt);
   uint32_t* off = (uint32_t*)(scratch + L.off);
   int* info = (int*)(scratch + L.info);
-  hipError_t e = hipMemsetAsync(info, 0, 32, s);
+  hipError_t e = hipSuccess;
+  if (!(tail && tail->info_zeroed)) e = hipMemsetAsync(info, 0, 32, s);
   if (e != hipSuccess) return e;
   size_t tb = L.cub_temp_bytes;
   if (!have_history) {  // no counts of an earlier walk over these targets: count (exact, so shift 0)
@@ -655,7 +741,7 @@ hipError_t launch_tree_walk_tile_prep(hipStream_t s, const WalkArgs<T>& a, char*
     if (need > tb) return hipErrorInvalidValue;
     e = hipcub::DeviceScan::ExclusiveSum((void*)(scratch + L.cub_temp), tb, est, off, (int)a.n_tgt, s);
     if (e != hipSuccess) return e;
-    if (estimate == 1)
+    if (estimate == 1 && !tail)
       walk_check_wrap_est<<<dim3((unsigned)((a.n_tgt + 255) / 256)), dim3(256), 0, s>>>(EstimateOf{hist, tgt_ids, shift}, off, a.n_tgt, info);
   }
   const char* ew = getenv("NBODY_WALK_TILE_WAVES");  // development override of kTileWaves
@@ -665,6 +751,14 @@ hipError_t launch_tree_walk_tile_prep(hipStream_t s, const WalkArgs<T>& a, char*
   if (bt) extra = a.n_tgt / bt;
   if (extra < 1) extra = 1;
   const int64_t twaves = extra + a.n_tgt / 64 + 4;  // upper bound of g(t) + 1 (budget >= ceil(total / extra))
+  *grid_waves = twaves;
+  if (tail) {
+    int64_t groups = a.n_tgt / 2048;
+    groups = groups < 32 ? 32 : (groups > 512 ? 512 : groups);
+    walk_check_est_tail<<<dim3((unsigned)groups), dim3(256), 0, s>>>(EstimateOf{hist, tgt_ids, shift}, off, a.n_tgt, extra, twaves,
+                                                                                      info, *tail);
+    return hipGetLastError();
+  }
   walk_tile_total<<<dim3(1), dim3(1), 0, s>>>(have_history ? nullptr : cnt, off, a.n_tgt, tgt_ids, estimate == 1 ? hist : nullptr, shift, extra,
                                               twaves, info);
   *grid_waves = twaves;
@@ -691,15 +785,17 @@ template <class T>
 hipError_t launch_tree_walk_tile(hipStream_t s, const WalkArgs<T>& a, char* scratch, const WalkSplitLayout& L, const uint32_t* tgt_ids,
                                  uint32_t* hist, int estimate, int shift) {
   int64_t waves = 0;
-  hipError_t e = launch_tree_walk_tile_prep<T>(s, a, scratch, L, tgt_ids, hist, estimate, shift, &waves);
+  hipError_t e = launch_tree_walk_tile_prep<T>(s, a, scratch, L, tgt_ids, hist, estimate, shift, &waves, nullptr);
   if (e != hipSuccess) return e;
   return launch_tree_walk_tile_main<T>(s, a, scratch, L, tgt_ids, hist, waves);
 }
 
 template hipError_t launch_tree_walk_tile<float>(hipStream_t, const WalkArgs<float>&, char*, const WalkSplitLayout&, const uint32_t*, uint32_t*, int, int);
 template hipError_t launch_tree_walk_tile<double>(hipStream_t, const WalkArgs<double>&, char*, const WalkSplitLayout&, const uint32_t*, uint32_t*, int, int);
-template hipError_t launch_tree_walk_tile_prep<float>(hipStream_t, const WalkArgs<float>&, char*, const WalkSplitLayout&, const uint32_t*, uint32_t*, int, int, int64_t*);
-template hipError_t launch_tree_walk_tile_prep<double>(hipStream_t, const WalkArgs<double>&, char*, const WalkSplitLayout&, const uint32_t*, uint32_t*, int, int, int64_t*);
+template hipError_t launch_tree_walk_tile_prep<float>(hipStream_t, const WalkArgs<float>&, char*, const WalkSplitLayout&, const uint32_t*, uint32_t*, int, int, int64_t*,
+                                                      const TileTail*);
+template hipError_t launch_tree_walk_tile_prep<double>(hipStream_t, const WalkArgs<double>&, char*, const WalkSplitLayout&, const uint32_t*, uint32_t*, int, int, int64_t*,
+                                                       const TileTail*);
 template hipError_t launch_tree_walk_tile_main<float>(hipStream_t, const WalkArgs<float>&, char*, const WalkSplitLayout&, const uint32_t*, uint32_t*, int64_t);
 template hipError_t launch_tree_walk_tile_main<double>(hipStream_t, const WalkArgs<double>&, char*, const WalkSplitLayout&, const uint32_t*, uint32_t*, int64_t);
 
