@@ -45,7 +45,10 @@ constexpr int kSeqRun = 16;      // real adds after every stop of the scan
 #define NB_CHAIN_START 512
 #endif
 constexpr int kChainStart = NB_CHAIN_START; // real adds at the start of a long node's chain (the sum doubles too often there)
-constexpr int kSub = 2048;       // nodes up to this long are built, subtree and all, by one work-group in LDS
+#ifndef NB_KSUB
+#define NB_KSUB 2048
+#endif
+constexpr int kSub = NB_KSUB;       // nodes up to this long are built, subtree and all, by one work-group in LDS
 constexpr int kSubWaves = 8;     // waves of a subtree work-group
 constexpr int kChunk = 2048;     // points per work-group in the multi-group passes over a long node
 constexpr int kRunLen = 16384;   // nodes longer than this have their chain prepared chunk by chunk (bvh_chunk_runs)

@@ -66,15 +66,28 @@ __global__ __launch_bounds__(256) void qb_path_keys(const void* pos_, int n, T r
   idx[i] = (uint32_t)i;
 }
 
-// leaf depth of the particle at sorted position r, stored by particle index
-__global__ __launch_bounds__(256) void qb_leaf_depth(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ idx, int n,
-                                                     int* __restrict__ ld_by_index, int* __restrict__ flags, int sort_levels) {
+// Leaf depth of the particle at sorted position r — and its final position: a leaf's particles stand in index order
+// (the reference pushes them in that order, quad_tree.rs insert), while the sort has ordered them by the child codes
+// below the leaf.  A leaf holds at most 8 particles (9 that share a cell split it), all within 7 places of r: r's rank
+// by index among them is its place.  (This replaces masking the keys and a second, stable sort of all of them.)
+// Writes, at the final position: the key cut at the leaf's depth, the particle's index, the leaf depth.
+__global__ __launch_bounds__(256) void qb_leaf_order(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ idx, int n,
+                                                     uint64_t* __restrict__ keys2, uint32_t* __restrict__ order, int* __restrict__ ld_out,
+                                                     int* __restrict__ flags, int sort_levels) {
   int r = blockIdx.x * 256 + threadIdx.x;
   if (r >= n) return;
+  uint64_t w[17];  // keys[r - 8 .. r + 8]
+#pragma unroll
+  for (int j = 0; j < 17; ++j) {
+    const int s = r - 8 + j;
+    w[j] = (s >= 0 && s < n) ? keys[s] : 0ull;
+  }
   int best = -1;  // longest prefix shared by 9 consecutive keys that include r
-  for (int s = r - 8; s <= r; ++s) {
+#pragma unroll
+  for (int j = 0; j <= 8; ++j) {
+    const int s = r - 8 + j;
     if (s < 0 || s + 8 >= n) continue;
-    int c = common_depth(keys[s], keys[s + 8]);  // sorted: the whole window shares what its ends share
+    const int c = common_depth(w[j], w[j + 8]);  // sorted: the whole window shares what its ends share
     best = c > best ? c : best;
   }
   int ld = best + 1;  // -1 -> the root itself is a leaf (n <= 8)
@@ -85,32 +98,44 @@ __global__ __launch_bounds__(256) void qb_leaf_depth(const uint64_t* __restrict_
   // the sort looked at the first sort_levels child codes only: 9 keys that agree on all of them are in no particular
   // order below, so a leaf that deep has to be found again with more levels sorted
   if (ld > sort_levels) atomicOr(&flags[0], 2);
-  ld_by_index[idx[r]] = ld;
-}
-
-__global__ __launch_bounds__(256) void qb_mask_keys(const uint64_t* __restrict__ keys_by_index, const int* __restrict__ ld_by_index,
-                                                    int n, uint64_t* __restrict__ keys2, uint32_t* __restrict__ idx2) {
-  int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  const int d = ld_by_index[i];
-  const uint64_t k = keys_by_index[i];
-  keys2[i] = d >= kLevels ? k : (d <= 0 ? 0 : (k >> (2 * (kLevels - d))) << (2 * (kLevels - d)));
-  idx2[i] = (uint32_t)i;
+  const uint64_t k = w[8];
+  const int sh = 2 * (kLevels - ld);
+  const uint64_t mine = ld >= kLevels ? k : (ld <= 0 ? 0ull : k >> sh);
+  // my leaf's neighbours: a run around r (when a flag above is up the run may be cut short: the build is redone anyway)
+  int lo = 8, hi = 9;
+#pragma unroll
+  for (int j = 7; j >= 1; --j) {
+    const int s = r - 8 + j;
+    const uint64_t o = ld >= kLevels ? w[j] : (ld <= 0 ? 0ull : w[j] >> sh);
+    if (lo == j + 1 && s >= 0 && o == mine) lo = j;
+  }
+#pragma unroll
+  for (int j = 9; j <= 15; ++j) {
+    const int s = r - 8 + j;
+    const uint64_t o = ld >= kLevels ? w[j] : (ld <= 0 ? 0ull : w[j] >> sh);
+    if (hi == j && s < n && o == mine) hi = j + 1;
+  }
+  const uint32_t me = idx[r];
+  int rank = 0;
+  for (int j = lo; j < hi; ++j) rank += idx[r - 8 + j] < me;
+  int p = r - 8 + lo + rank;
+  p = p < n ? p : n - 1;
+  keys2[p] = ld >= kLevels ? k : (ld <= 0 ? 0ull : mine << sh);
+  order[p] = me;
+  ld_out[p] = ld;
 }
 
 // nodes that start at sorted position r: depths first_depth(r) .. leaf_depth(r)
-__global__ __launch_bounds__(256) void qb_node_counts(const uint64_t* __restrict__ keys2, const uint32_t* __restrict__ idx2,
-                                                      const int* __restrict__ ld_by_index, int n, int* __restrict__ ld,
+__global__ __launch_bounds__(256) void qb_node_counts(const uint64_t* __restrict__ keys2, const int* __restrict__ ld, int n,
                                                       int* __restrict__ fd, uint32_t* __restrict__ cnt) {
   int r = blockIdx.x * 256 + threadIdx.x;
   if (r >= n) return;
-  const int l = ld_by_index[idx2[r]];
+  const int l = ld[r];
   int f = 0;
   if (r > 0) {
     const uint64_t a = keys2[r - 1], b = keys2[r];
     f = (a == b) ? kLevels + 1 : common_depth(a, b) + 1;
   }
-  ld[r] = l;
   fd[r] = f;
   cnt[r] = f <= l ? (uint32_t)(l - f + 1) : 0u;
 }
@@ -254,10 +279,9 @@ hipError_t quad_build_phase_a(hipStream_t s, const void* pos, int n, T rx, T ry,
   int* flags = (int*)(scratch + L.flags);
   uint64_t* ka = (uint64_t*)(scratch + L.keys_a);
   uint64_t* kb = (uint64_t*)(scratch + L.keys_b);
-  uint64_t* kbi = (uint64_t*)(scratch + L.keys_by_index);
+  uint64_t* kf = (uint64_t*)(scratch + L.keys_by_index);  // the keys in their final order, cut at the leaf depth (phase B reads them)
   uint32_t* ia = (uint32_t*)(scratch + L.idx_a);
   uint32_t* ib = (uint32_t*)(scratch + L.idx_b);
-  int* ldi = (int*)(scratch + L.ld_by_index);
   int* ld = (int*)(scratch + L.ld);
   int* fd = (int*)(scratch + L.fd);
   uint32_t* cnt = (uint32_t*)(scratch + L.cnt);
@@ -269,9 +293,7 @@ hipError_t quad_build_phase_a(hipStream_t s, const void* pos, int n, T rx, T ry,
     return hipGetLastError();
   }
   const unsigned blocks = (unsigned)((n + 255) / 256);
-  hipLaunchKernelGGL((qb_path_keys<T>), dim3(blocks), dim3(256), 0, s, pos, n, rx, ry, rh, kbi, ia);
-  e = hipMemcpyAsync(ka, kbi, (size_t)n * 8, hipMemcpyDeviceToDevice, s);
-  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((qb_path_keys<T>), dim3(blocks), dim3(256), 0, s, pos, n, rx, ry, rh, ka, ia);
   size_t tb = L.cub_temp_bytes, need = 0;
   {
     hipcub::DoubleBuffer<uint64_t> dk(ka, kb);
@@ -281,24 +303,10 @@ hipError_t quad_build_phase_a(hipStream_t s, const void* pos, int n, T rx, T ry,
     if (need > L.cub_temp_bytes) return hipErrorOutOfMemory;
     e = hipcub::DeviceRadixSort::SortPairs(scratch + L.cub_temp, tb, dk, dv, n, bit0, 62, s);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(qb_leaf_depth, dim3(blocks), dim3(256), 0, s, dk.Current(), dv.Current(), n, ldi, flags, sort_levels);
+    // leaf depths, and every leaf's particles into index order: final keys (cut at the leaf) in kf, final order in order_out
+    hipLaunchKernelGGL(qb_leaf_order, dim3(blocks), dim3(256), 0, s, dk.Current(), dv.Current(), n, kf, order_out, ld, flags, sort_levels);
   }
-  hipLaunchKernelGGL(qb_mask_keys, dim3(blocks), dim3(256), 0, s, kbi, ldi, n, ka, ia);
-  {
-    hipcub::DoubleBuffer<uint64_t> dk(ka, kb);
-    hipcub::DoubleBuffer<uint32_t> dv(ia, ib);
-    tb = L.cub_temp_bytes;
-    e = hipcub::DeviceRadixSort::SortPairs(scratch + L.cub_temp, tb, dk, dv, n, bit0, 62, s);  // stable; masked keys are 0 below
-    if (e != hipSuccess) return e;
-    // keep the sorted keys in keys_a and the order in order_out
-    if (dk.Current() != ka) {
-      e = hipMemcpyAsync(ka, dk.Current(), (size_t)n * 8, hipMemcpyDeviceToDevice, s);
-      if (e != hipSuccess) return e;
-    }
-    e = hipMemcpyAsync(order_out, dv.Current(), (size_t)n * 4, hipMemcpyDeviceToDevice, s);
-    if (e != hipSuccess) return e;
-  }
-  hipLaunchKernelGGL(qb_node_counts, dim3(blocks), dim3(256), 0, s, ka, order_out, ldi, n, ld, fd, cnt);
+  hipLaunchKernelGGL(qb_node_counts, dim3(blocks), dim3(256), 0, s, kf, ld, n, fd, cnt);
   need = 0;
   e = hipcub::DeviceScan::ExclusiveSum(nullptr, need, cnt, base, n, s);
   if (e != hipSuccess) return e;
@@ -316,7 +324,7 @@ template <class T>
 hipError_t quad_build_phase_b(hipStream_t s, const void* pos, const uint32_t* weight, int n, T rx, T ry, T rh, char* scratch,
                               const QuadBuildLayout& L, const uint32_t* order, int n_nodes, int max_depth, void* geom0,
                               void* geom1, void* link, int* depth, uint32_t* mass) {
-  const uint64_t* ka = (const uint64_t*)(scratch + L.keys_a);
+  const uint64_t* ka = (const uint64_t*)(scratch + L.keys_by_index);  // final order, cut at the leaf depth (phase A)
   const int* ld = (const int*)(scratch + L.ld);
   const int* fd = (const int*)(scratch + L.fd);
   const uint32_t* cnt = (const uint32_t*)(scratch + L.cnt);
