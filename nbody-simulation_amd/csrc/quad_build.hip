@@ -74,8 +74,10 @@ __global__ __launch_bounds__(256) void qb_path_keys(const void* pos_, int n, T r
 __global__ __launch_bounds__(256) void qb_leaf_order(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ idx, int n,
                                                      uint64_t* __restrict__ keys2, uint32_t* __restrict__ order, int* __restrict__ ld_out,
                                                      int* __restrict__ flags, int sort_levels) {
+  __shared__ int wave_max[4];
   int r = blockIdx.x * 256 + threadIdx.x;
-  if (r >= n) return;
+  const bool live = r < n;
+  if (!live) r = n - 1;  // (n > 0) a bystander that stays for the barrier; it writes nothing
   uint64_t w[17];  // keys[r - 8 .. r + 8]
 #pragma unroll
   for (int j = 0; j < 17; ++j) {
@@ -120,9 +122,20 @@ __global__ __launch_bounds__(256) void qb_leaf_order(const uint64_t* __restrict_
   for (int j = lo; j < hi; ++j) rank += idx[r - 8 + j] < me;
   int p = r - 8 + lo + rank;
   p = p < n ? p : n - 1;
-  keys2[p] = ld >= kLevels ? k : (ld <= 0 ? 0ull : mine << sh);
-  order[p] = me;
-  ld_out[p] = ld;
+  if (live) {
+    keys2[p] = ld >= kLevels ? k : (ld <= 0 ? 0ull : mine << sh);
+    order[p] = me;
+    ld_out[p] = ld;
+  }
+  // the tree's depth (flags[2]): one atomic per work-group, and only from groups that would raise it
+  int v = ld;
+  for (int o = 32; o > 0; o >>= 1) { const int x = __shfl_xor(v, o); v = x > v ? x : v; }
+  if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k2 = 1; k2 < 4; ++k2) v = wave_max[k2] > v ? wave_max[k2] : v;
+    if (v > __hip_atomic_load(&flags[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&flags[2], v);
+  }
 }
 
 // nodes that start at sorted position r: depths first_depth(r) .. leaf_depth(r)
@@ -151,17 +164,28 @@ __global__ __launch_bounds__(256) void qb_emit_nodes(const uint64_t* __restrict_
   const uint64_t key = keys2[r];
   const int f = fd[r], l = ld[r];
   T ox = rx, oy = ry, h = rh;
+  int bound = -1;  // end of the cell one level up: this level's cell ends no later
   for (int d = 0; d <= l; ++d) {
     if (d >= f) {
       const int j = (int)base[r] + (d - f);
       // extent of the cell: particles sharing the depth-d prefix, starting at r
       const uint64_t pre = prefix(key, d);
-      int lo = r, hi = n;  // first position > r whose prefix differs
+      int lo = r, hi;  // lo: shares the prefix; hi: first known position that does not (or n)
+      if (bound < 0) {  // the shallowest node starting here: gallop (most cells are short; a search over all n keys
+        hi = n;         // is 20 dependent loads)
+        for (int step = 1; lo + step < n; step *= 2) {
+          if (prefix(keys2[lo + step], d) == pre) lo += step;
+          else { hi = lo + step; break; }
+        }
+      } else {
+        hi = bound;
+      }
       while (lo + 1 < hi) {
         int mid = (lo + hi) >> 1;
         if (prefix(keys2[mid], d) == pre) lo = mid; else hi = mid;
       }
       const int end = hi;
+      bound = end;
       const int skip = end < n ? (int)base[end] : n_nodes;
       reinterpret_cast<T4*>(geom0_)[j] = T4{ox, oy, ox + h, oy + h};
       reinterpret_cast<T4*>(geom1_)[j] = T4{(T)0, (T)0, (T)0, h * h};  // height2, quad_tree.rs:19
@@ -237,12 +261,6 @@ __global__ void qb_totals(const uint32_t* __restrict__ cnt, const uint32_t* __re
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   flags[1] = n > 0 ? (int)(base[n - 1] + cnt[n - 1]) : 1;
 }
-__global__ __launch_bounds__(256) void qb_max_depth(const int* __restrict__ ld, int n, int* __restrict__ flags) {
-  int v = 0;  // grid-stride: a few hundred atomics in all (one per wave of <= 512 blocks), not one per 64 particles
-  for (int r = blockIdx.x * 256 + threadIdx.x; r < n; r += gridDim.x * 256) { int w = ld[r]; v = w > v ? w : v; }
-  for (int o = 32; o > 0; o >>= 1) { int w = __shfl_xor(v, o); v = w > v ? w : v; }
-  if ((threadIdx.x & 63) == 0) atomicMax(&flags[2], v);
-}
 
 size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
@@ -315,7 +333,6 @@ hipError_t quad_build_phase_a(hipStream_t s, const void* pos, int n, T rx, T ry,
   e = hipcub::DeviceScan::ExclusiveSum(scratch + L.cub_temp, tb, cnt, base, n, s);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(qb_totals, dim3(1), dim3(1), 0, s, cnt, base, ld, n, flags);
-  hipLaunchKernelGGL(qb_max_depth, dim3(blocks < 512 ? blocks : 512), dim3(256), 0, s, ld, n, flags);
   return hipGetLastError();
 }
 
