@@ -660,6 +660,18 @@ template <class T> int quad_build_device(nbody_ctx* c, State<T>& s) {
   for (;;) {
     HIPCHK(c, quad_build_phase_a<T>(c->stream, in.pos, n, rx, ry, rh, s.qb_scratch, L, s.order_dev, sort_levels));
     HIPCHK(c, hipMemcpyAsync(flags, s.qb_scratch + L.flags, sizeof(flags), hipMemcpyDeviceToHost, c->stream));
+    {
+      // The leaves' own copies of their points, in tree order: enqueued before the host asks for the node count, so the
+      // device gathers while the host waits, and the leaf statistics of phase B read rows that lie side by side.
+      GatherArgs<T> g{};
+      g.perm = s.order_dev;
+      g.n = n;
+      g.pos_in = in.pos; g.pos_out = out.pos;
+      g.weight_in = in.weight;
+      g.weight_out = out.weight;
+      g.mass_out = out.mass;
+      HIPCHK(c, launch_gather<T>(c->stream, g));
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (env_int("NBODY_TRACE", 0) != 0)
       std::fprintf(stderr, "[nbody] device quad build: sorted by %d levels, flags %d, %d nodes, depth %d\n", sort_levels, flags[0], flags[1], flags[2]);
@@ -673,15 +685,8 @@ template <class T> int quad_build_device(nbody_ctx* c, State<T>& s) {
   if (rc) return rc;
   rc = ensure_node_aux<T>(c, s, (size_t)m);
   if (rc) return rc;
-  HIPCHK(c, quad_build_phase_b<T>(c->stream, in.pos, in.weight, n, rx, ry, rh, s.qb_scratch, L, s.order_dev, m, flags[2],
+  HIPCHK(c, quad_build_phase_b<T>(c->stream, out.pos, out.weight, n, rx, ry, rh, s.qb_scratch, L, nullptr, m, flags[2],
                                   s.geom0, s.geom1, s.link, s.node_depth, s.node_mass));
-  GatherArgs<T> g{};  // the leaves' own copies of their points, in tree order
-  g.perm = s.order_dev;
-  g.n = n;
-  g.pos_in = in.pos; g.pos_out = out.pos;
-  g.weight_in = in.weight;
-  g.mass_out = out.mass;
-  HIPCHK(c, launch_gather<T>(c->stream, g));
   s.n_nodes = m;
   s.tree_kind = NBODY_TREE_QUAD;
   s.tree_max_depth = flags[2];

@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256) void qb_leaf_stats(const void* pos_, const uin
   uint32_t ms = 0;
   T ax = 0, ay = 0;
   for (int k = 0; k < lk.z; ++k) {
-    const uint32_t id = order[lk.y + k];
+    const uint32_t id = order ? order[lk.y + k] : (uint32_t)(lk.y + k);  // (no order: pos and weight are in tree order already)
     const T2 q = reinterpret_cast<const T2*>(pos_)[id];
     ms += weight[id];
     ax = ax + q.x;
