@@ -19,6 +19,7 @@
 // the caller falls back to the host builder, which has no such limit.  No sequential chain is longer than 8 elements.
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
+#include <rocprim/rocprim.hpp>
 #include <stdint.h>
 
 #include "quad_build.h"
@@ -314,15 +315,18 @@ hipError_t quad_build_phase_a(hipStream_t s, const void* pos, int n, T rx, T ry,
   hipLaunchKernelGGL((qb_path_keys<T>), dim3(blocks), dim3(256), 0, s, pos, n, rx, ry, rh, ka, ia);
   size_t tb = L.cub_temp_bytes, need = 0;
   {
-    hipcub::DoubleBuffer<uint64_t> dk(ka, kb);
-    hipcub::DoubleBuffer<uint32_t> dv(ia, ib);
-    e = hipcub::DeviceRadixSort::SortPairs(nullptr, need, dk, dv, n, 0, 62, s);  // (size query: the widest sort)
+    // rocprim's own choice below a million keys is a merge sort (a block sort and ~10 merge passes over whole keys, 0.2 ms
+    // at N = 2^20); the Onesweep radix sort looks at the sorted bits only (4-5 passes of 8 bits): taken above 256 k keys
+    using SortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 262144>;
+    rocprim::double_buffer<uint64_t> dk(ka, kb);
+    rocprim::double_buffer<uint32_t> dv(ia, ib);
+    e = rocprim::radix_sort_pairs<SortConfig>(nullptr, need, dk, dv, (size_t)n, 0u, 62u, s);  // (size query: the widest sort)
     if (e != hipSuccess) return e;
     if (need > L.cub_temp_bytes) return hipErrorOutOfMemory;
-    e = hipcub::DeviceRadixSort::SortPairs(scratch + L.cub_temp, tb, dk, dv, n, bit0, 62, s);
+    e = rocprim::radix_sort_pairs<SortConfig>(scratch + L.cub_temp, tb, dk, dv, (size_t)n, (unsigned)bit0, 62u, s);
     if (e != hipSuccess) return e;
     // leaf depths, and every leaf's particles into index order: final keys (cut at the leaf) in kf, final order in order_out
-    hipLaunchKernelGGL(qb_leaf_order, dim3(blocks), dim3(256), 0, s, dk.Current(), dv.Current(), n, kf, order_out, ld, flags, sort_levels);
+    hipLaunchKernelGGL(qb_leaf_order, dim3(blocks), dim3(256), 0, s, dk.current(), dv.current(), n, kf, order_out, ld, flags, sort_levels);
   }
   hipLaunchKernelGGL(qb_node_counts, dim3(blocks), dim3(256), 0, s, kf, ld, n, fd, cnt);
   need = 0;
