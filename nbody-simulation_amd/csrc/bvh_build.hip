@@ -1698,18 +1698,12 @@ __global__ __launch_bounds__(256) void bvh_top_upward(BvhPtrs a, const uint32_t*
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n_top = a.flags[kBvhTopCount];
   if (tid == 0) { a.flags[kBvhBadIndex] = 0; s_dmax = -1; }
-  for (int e = wave; e < n_top; e += 4) {
-    const int id = a.topq[e];
-    if (!a.nleaf[id]) continue;
-    const int b = a.nbegin[id];
-    const uint32_t* ids = a.ID + b;
-    leaf_by_wave(a, id, (const float2*)(a.P + b), a.nlen[id], lane, weight, [&](int i) { return ids[i]; });
-  }
   __syncthreads();
-  // what each entry is, once: the level loops below visit every entry at every depth
-  const auto describe = [&](int e, int& id) {
+  // what each entry is, once (all threads side by side): the loops below visit every entry, the level loops at every depth
+  const auto describe = [&](int e, int& id) {  // depth of a long internal node, -2 a leaf, -1 a subtree's root
     id = a.topq[e];
-    return (!a.nleaf[id] && a.nlen[id] > kSub) ? a.ndepth[id] : -1;
+    if (a.nleaf[id]) return -2;
+    return a.nlen[id] > kSub ? a.ndepth[id] : -1;
   };
   int dmax = -1;
   for (int e = tid; e < n_top; e += 256) {
@@ -1719,6 +1713,15 @@ __global__ __launch_bounds__(256) void bvh_top_upward(BvhPtrs a, const uint32_t*
     dmax = d > dmax ? d : dmax;
   }
   if (dmax >= 0) atomicMax(&s_dmax, dmax);
+  __syncthreads();
+  for (int e = wave; e < n_top; e += 4) {  // leaves hanging directly off a long node: a wave each
+    int id;
+    const int kind = e < kKeep ? (id = s_id[e], (int)s_depth[e]) : describe(e, id);
+    if (kind != -2) continue;
+    const int b = a.nbegin[id];
+    const uint32_t* ids = a.ID + b;
+    leaf_by_wave(a, id, (const float2*)(a.P + b), a.nlen[id], lane, weight, [&](int i) { return ids[i]; });
+  }
   __syncthreads();
   dmax = s_dmax;  // deepest long node: the tree below it belongs to the subtrees
   const auto entry = [&](int e, int& id) {

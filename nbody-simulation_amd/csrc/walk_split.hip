@@ -753,8 +753,8 @@ hipError_t launch_tree_walk_tile_prep(hipStream_t s, const WalkArgs<T>& a, char*
   const int64_t twaves = extra + a.n_tgt / 64 + 4;  // upper bound of g(t) + 1 (budget >= ceil(total / extra))
   *grid_waves = twaves;
   if (tail) {
-    int64_t groups = a.n_tgt / 2048;
-    groups = groups < 32 ? 32 : (groups > 512 ? 512 : groups);
+    int64_t groups = a.n_tgt / 2048;  // (every group ends with an atomic on one counter: few groups, longer loops)
+    groups = groups < 32 ? 32 : (groups > 128 ? 128 : groups);
     walk_check_est_tail<<<dim3((unsigned)groups), dim3(256), 0, s>>>(EstimateOf{hist, tgt_ids, shift}, off, a.n_tgt, extra, twaves,
                                                                                       info, *tail);
     return hipGetLastError();
