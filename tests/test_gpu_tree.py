@@ -307,6 +307,31 @@ def test_device_bvh_build_equals_oracle_tree(nb, orc, ctx, leaf):
         assert np.array_equal(ids, o.ids) and np.array_equal(p, o.pos_perm) and np.array_equal(w2, w[o.ids]), name
 
 
+@pytest.mark.parametrize("scene", ["plummer_1m", "centred_1m5", "negative_700k"])
+def test_device_bvh_build_equals_the_host_builder_on_long_chains(nb, ctx, scene):
+    """The same at sizes where the chain is folded out of LDS windows over many rounds, with prepared chunk runs, crossings
+    seen coming and same-sign rounds proven by their end (bvh_build.hip exact_fold): against the host builder, which adds one
+    point after the other (tree_build.hpp; itself checked against the oracle at the smaller sizes above)."""
+    C = nb._capi
+    rng = np.random.default_rng(23)
+    if scene == "plummer_1m":
+        pos = nb.scenes.plummer(1 << 20, seed=0x5EED0003)[0]
+    elif scene == "centred_1m5":
+        pos = (rng.standard_normal((1_500_000, 2)) * 3e4).astype(F32)   # sums wander through zero: mixed-sign rounds
+    else:
+        pos = (-rng.random((700_000, 2)) * 1e5).astype(F32)             # the chain carries a sign
+    n = pos.shape[0]
+    w = (np.arange(n) % 5 + 1).astype(np.uint32)
+    prm = C.default_params()
+    h = C.host_tree(C.TREE_BVH, pos, w, prm)
+    assert not h["overflow"]
+    ctx.set_params(theta=50.0)
+    ctx.upload(pos, np.zeros_like(pos), w)
+    ctx.accel_tree(C.TREE_BVH, pos[:4])
+    assert ctx.last_build_on_device(), scene
+    _bvh_export_equal(ctx.tree_export(), h)
+
+
 def test_device_and_host_bvh_builds_agree_over_steps(nb, monkeypatch):
     """20 full steps of the reference scene with the device build against 20 with the host build: same rows."""
     pos, vel, w = nb.scenes.galaxy()
