@@ -151,25 +151,6 @@ __device__ __forceinline__ uint32_t load_agent(const uint32_t* p) {
 __device__ __forceinline__ int load_agent(const int* p) { return (int)load_agent(reinterpret_cast<const uint32_t*>(p)); }
 
 // ---- the chain, one add after the other -----------------------------------------------------------------------------
-// s += v[lane K of this row of 16], in every lane: one instruction per add (DPP row_newbcast), no scalar round trip.
-template <int K> __device__ __forceinline__ void add_row_lane(float& s, float v) {
-  asm volatile("v_add_f32_dpp %0, %1, %0 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(s) : "v"(v), "n"(K));
-}
-// Every row of 16 lanes holds the same 16 addends (lane & 15 picks): all 64 lanes carry the same running sums.
-__device__ __forceinline__ void chain_add16(float& sx, float& sy, float2 q) {
-  asm volatile("s_nop 1" ::: "memory");  // q may have just been written by a VALU move: DPP read needs 2 wait states
-#define NB_ADD(K) add_row_lane<K>(sx, q.x); add_row_lane<K>(sy, q.y);
-  NB_ADD(0) NB_ADD(1) NB_ADD(2) NB_ADD(3) NB_ADD(4) NB_ADD(5) NB_ADD(6) NB_ADD(7)
-  NB_ADD(8) NB_ADD(9) NB_ADD(10) NB_ADD(11) NB_ADD(12) NB_ADD(13) NB_ADD(14) NB_ADD(15)
-#undef NB_ADD
-}
-__device__ __forceinline__ void chain_add_some(float& sx, float& sy, float2 q, int cnt) {  // cnt < 16, uniform
-  asm volatile("s_nop 1" ::: "memory");
-#define NB_ADD(K) if (K < cnt) { add_row_lane<K>(sx, q.x); add_row_lane<K>(sy, q.y); }
-  NB_ADD(0) NB_ADD(1) NB_ADD(2) NB_ADD(3) NB_ADD(4) NB_ADD(5) NB_ADD(6) NB_ADD(7)
-  NB_ADD(8) NB_ADD(9) NB_ADD(10) NB_ADD(11) NB_ADD(12) NB_ADD(13) NB_ADD(14)
-#undef NB_ADD
-}
 struct Box {
   float mnx = kMaxF, mny = kMaxF, mxx = 0.f, mxy = 0.f;  // the fold's start values, bvh_tree.rs:42, :59
   __device__ __forceinline__ void add(float2 q) {
@@ -183,30 +164,6 @@ struct Box {
     }
   }
 };
-// sum += P[begin .. begin+count) in order, by one wave; box takes the same points.  The next 16 addends are fetched
-// while the current 16 are added.
-template <class PosPtr>
-__device__ __forceinline__ void chain_run(PosPtr P, int begin, int count, int lane, float& sx, float& sy, Box& box) {
-  const int sub = lane & 15;
-  const int end = begin + count;
-  float2 q = make_float2(0.f, 0.f);
-  if (begin + sub < end) q = P[begin + sub];
-  for (int p = begin; p < end; p += 16) {
-    float2 nq = make_float2(0.f, 0.f);
-    if (p + 16 + sub < end) nq = P[p + 16 + sub];
-    const int cnt = end - p;
-    if (cnt >= 16) {
-      box.add(q);
-      chain_add16(sx, sy, q);
-    } else {
-      if (sub < cnt) box.add(q);
-      chain_add_some(sx, sy, q, cnt);
-    }
-    q = nq;
-  }
-}
-
-// ---- one coordinate out of LDS ------------------------------------------------------------------------------------------
 // s + X[0] + X[STRIDE] + ... (count addends, in order) from LDS, the same address in every lane (a broadcast read); count
 // uniform.  The adds depend on one another, the reads do not: the next 16 words are on their way while these 16 are added,
 // else every batch waits out the LDS latency (13+ clocks per addend instead of the 4-5 of a dependent add).  Two register
@@ -753,7 +710,8 @@ __host__ __device__ inline int run_mult(int len) {
   while (nch > 64 * m) m <<= 1;
   return m;
 }
-constexpr int kRunRec = 24;  // ints per chunk and coordinate: sign, E_a (0: no run), E_b, u0, u1, run A (6), run B (6), pad
+constexpr int kGapCap = 2048;  // real adds around powers of two, per chain and walk, fetched ahead into LDS
+constexpr int kRunRec = 24;  // ints per chunk and coordinate: sign, E_a (0: no run), E_b, u0, u1, run A (6), run B (6), [17] where its real adds lie in `gaps` (bvh_big_fold), pad
 __device__ __forceinline__ void store_run(int* o, const xsum::Run& r) {
   o[0] = r.a0; o[1] = r.a1; o[2] = r.lo0; o[3] = r.lo1; o[4] = r.hi0; o[5] = r.hi1;
 }
@@ -924,6 +882,8 @@ __global__ __launch_bounds__(512) void bvh_big_fold(BvhPtrs a, int level, int us
   __shared__ Scratch<8> sh;
   __shared__ __attribute__((aligned(16))) int recs[kRecBatch * kRunRec];
   __shared__ float stage[StageView<512>::kWords];
+  __shared__ float gaps[kGapCap];
+  __shared__ int gap_total;
   const int tid = threadIdx.x;
   const int comp = blockIdx.y;  // 0: x, 1: y
   const int nq = a.bigcount[level];
@@ -944,6 +904,7 @@ __global__ __launch_bounds__(512) void bvh_big_fold(BvhPtrs a, int level, int us
       int used = 0;
       {  // the chunks' runs are merged, rm at a time, into the <= 64 runs the chain will walk (one thread per merged run)
         const int b0 = 0, nb = nrun;
+        int glen = 0;
         if (tid < nrun) {
           const int f0 = tid * rm, f1 = f0 + rm < nch ? f0 + rm : nch;
           xsum::Run A = xsum::run_none(), B = xsum::run_none();
@@ -981,51 +942,86 @@ __global__ __launch_bounds__(512) void bvh_big_fold(BvhPtrs a, int level, int us
           o[0] = sign; o[1] = valid ? Ea : 0; o[2] = Eb; o[3] = u0; o[4] = u1;
           o[5] = A.a0; o[6] = A.a1; o[7] = A.lo0; o[8] = A.lo1; o[9] = A.hi0; o[10] = A.hi1;
           o[11] = B.a0; o[12] = B.a1; o[13] = B.lo0; o[14] = B.lo1; o[15] = B.hi0; o[16] = B.hi1;
+          glen = valid ? u1 - u0 : 0;  // addends around a power of two, left to real adds
+        }
+        if (tid < 64) {
+          // Those addends are fetched for all runs at once, ahead of the walk (a trip to memory at every crossing is 2 us
+          // of a walk that takes 0.1 us per run): where each run's lie in `gaps` (nrun <= 64: the merging threads are
+          // this wave).  Runs whose addends do not fit are left to the scan.
+          int inc = glen;
+          for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(inc, d, 64);
+            if ((tid & 63) >= d) inc += o;
+          }
+          const int goff = inc - glen;
+          if (tid < nrun) {
+            int* o = recs + tid * kRunRec;
+            o[17] = goff;
+            if (goff + glen > kGapCap) o[1] = 0;
+#ifdef NB_FORCE_SCANS
+            if ((tid % NB_FORCE_SCANS) == 1) o[1] = 0;  // (test builds) every so many runs go to the scan instead
+#endif
+          }
+          if (tid == 63) gap_total = inc < kGapCap ? inc : kGapCap;
+        }
+        __syncthreads();
+        {
+          const float* __restrict__ X = reinterpret_cast<const float*>(P) + comp;
+          const int G = gap_total;
+          for (int g = tid; g < G; g += 512) {
+            int lo_r = 0, hi_r = nrun - 1;  // the run whose addends include the g-th: last one with offset <= g
+            while (lo_r < hi_r) {
+              const int mid = (lo_r + hi_r + 1) >> 1;
+              if (recs[mid * kRunRec + 17] <= g) lo_r = mid; else hi_r = mid - 1;
+            }
+            const int* o = recs + lo_r * kRunRec;
+            const int k = g - o[17];
+            if (o[1] != 0 && k < o[4] - o[3]) gaps[g] = X[2 * (size_t)(lo_r * rlen + o[3] + k)];
+          }
         }
         __syncthreads();
         int ci = b0;
         while (ci < b0 + nb) {  // ... and the chain walks through them in order
           // one wave runs ahead as long as the prepared runs hold (a few dozen instructions per chunk, no barrier) ...
           if (tid < 64) {
-            int u = 0;
+            // The chain's state stays (sign, E, S) from run to run; it turns into a float only where real adds need one.
+            xsum::Chain ch;
+            bool open = xsum::chain_open(sum, ch);
             for (; ci < b0 + nb; ++ci) {
               // the whole record in one go (LDS latency once per chunk, not once per field)
               const int4* rv = reinterpret_cast<const int4*>(recs + (ci - b0) * kRunRec);
               const int4 r0 = rv[0], r1 = rv[1], r2 = rv[2], r3 = rv[3], r4 = rv[4];
-              const int rec[20] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y,
-                                   r2.z, r2.w, r3.x, r3.y, r3.z, r3.w, r4.x, r4.y, r4.z, r4.w};
-              if (rec[1] == 0) break;
+              if (r0.y == 0 || !open) break;  // no run prepared, or a state no run applies to: the scan's
               const int lo = ci * rlen, hi = lo + rlen < len ? lo + rlen : len;
-              const int u0 = rec[3], u1 = rec[4];
-              float t = sum;
+              const int u0 = r0.w, u1 = r1.x;
+              xsum::Chain tc = ch;
               bool good = true;
-#pragma unroll
-              for (int part = 0; part < 2; ++part) {
-                const int pb = part ? lo + u1 : lo, pe = part ? hi : lo + u0;
-                if (good && pe > pb) {
-                  xsum::Chain ch;
-                  good = xsum::chain_open(t, ch) && (int)ch.E == rec[1 + part] && (int)ch.sign == rec[0];
-                  if (good) {
-                    xsum::Run r;
-                    r.a0 = rec[5 + 6 * part]; r.a1 = rec[6 + 6 * part];
-                    r.lo0 = rec[7 + 6 * part]; r.lo1 = rec[8 + 6 * part];
-                    r.hi0 = rec[9 + 6 * part]; r.hi1 = rec[10 + 6 * part];
-                    good = xsum::run_fits(ch.S, r);
-                    if (good) { t = xsum::chain_value(ch, (uint32_t)((int)ch.S + ((ch.S & 1u) ? r.a1 : r.a0))); ++u; }
-                  }
-                }
-                if (good && part == 0 && u1 > u0) {  // the addends around the power of two: real adds
-                  Box bx;
-                  float sx = t, sy = t;
-                  chain_run(P, lo + u0, u1 - u0, tid, sx, sy, bx);
-                  t = comp ? sy : sx;
-                }
+              int u = 0;
+              if (u0 > 0) {  // part A: [lo, lo + u0)
+                xsum::Run r;
+                r.a0 = r1.y; r.a1 = r1.z; r.lo0 = r1.w; r.lo1 = r2.x; r.hi0 = r2.y; r.hi1 = r2.z;
+                good = (int)tc.E == r0.y && (int)tc.sign == r0.x && xsum::run_fits(tc.S, r);
+                tc.S = (uint32_t)((int)tc.S + ((tc.S & 1u) ? r.a1 : r.a0));
+                ++u;
+              }
+              if (good && u1 > u0) {  // the addends around the power of two: real adds, out of `gaps`
+                float t = xsum::chain_value(tc, tc.S);
+                t = chain_lds<1>(gaps + r4.y, u1 - u0, t);
+                good = xsum::chain_open(t, tc);
+              }
+              if (good && lo + u1 < hi) {  // part B: [lo + u1, hi), in the binade above
+                good = (int)tc.E == r0.z && (int)tc.sign == r0.x;
+                xsum::Run r;
+                r.a0 = r2.w; r.a1 = r3.x; r.lo0 = r3.y; r.lo1 = r3.z; r.hi0 = r3.w; r.hi1 = r4.x;
+                good = good && xsum::run_fits(tc.S, r);
+                tc.S = (uint32_t)((int)tc.S + ((tc.S & 1u) ? r.a1 : r.a0));
+                ++u;
               }
               if (!good) break;  // ... a chunk whose run does not hold is everybody's business
-              sum = t;
+              ch = tc;
               used += u;
-              u = 0;
             }
+            if (open) sum = xsum::chain_value(ch, ch.S);
             if (tid == 0) { sh.bad_s = xsum::f2u(sum); sh.bad = ci; }
           }
           __syncthreads();

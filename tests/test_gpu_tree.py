@@ -325,7 +325,7 @@ def test_device_bvh_build_equals_the_host_builder_on_long_chains(nb, ctx, scene)
     prm = C.default_params()
     h = C.host_tree(C.TREE_BVH, pos, w, prm)
     assert not h["overflow"]
-    ctx.set_params(theta=50.0)
+    ctx.set_params(theta=50.0, leaf_size=prm.leaf_size)  # (the shared context keeps whatever the test before it set)
     ctx.upload(pos, np.zeros_like(pos), w)
     ctx.accel_tree(C.TREE_BVH, pos[:4])
     assert ctx.last_build_on_device(), scene
