@@ -12,7 +12,8 @@ constexpr int kBvhKeyDepth = 56;  // deepest level the device build follows; dee
 // flags (int[] at scratch + L.flags)
 enum : int {
   kBvhFallback = 0,   // != 0: the device build declines (buffers, depth, NaN positions): host builder
-  kBvhNodeCount = 1,  // nodes allocated so far (breadth-first ids)
+  kBvhNodeCount = 1,  // node ids handed out so far: a high-water mark (the subtree kernel takes its ids a range at a time and
+                      // may leave the end of a range unused: ids are not dense; kBvhNodes counts the nodes)
   kBvhMaxDepth = 2,
   kBvhStops = 3,      // restarts of the exact-sum scan (diagnostic)
   kBvhSubCount = 4,   // subtree roots queued for bvh_subtrees
@@ -20,7 +21,8 @@ enum : int {
   kBvhRunsUsed = 6,   // chunks of long chains whose prepared run was used (diagnostic)
   kBvhBadIndex = 7,   // bvh_emit met a node it could not number (expected while long nodes are still pending only)
   kBvhDebug = 8,      // 8 words of max-over-groups cycle counts per phase of bvh_subtrees (NB_BVH_TIMING builds)
-  kBvhFlagWords = 16,
+  kBvhNodes = 16,     // nodes of the finished tree (the root's subtree size, written by bvh_top_upward)
+  kBvhFlagWords = 24,
 };
 
 struct BvhBuildLayout {

@@ -573,8 +573,10 @@ __device__ __forceinline__ int choose_axis(int len, int cxs, int cys, bool& on_x
 
 // Children of `node` ([b, b+m) and [b+m, b+len)) with the ids first, first + 1: records and keys.  One thread.
 // leaf[] says which children need no further splitting.
+// depth_max: where the tree's depth is collected; null: the global flag, one atomic per node (the subtree kernel collects per
+// work-group in LDS and reports once: thousands of atomics on one address are the slowest thing a build can do).
 __device__ __forceinline__ void make_children(const BvhPtrs& a, int node, int first, int b, int len, int m, int leaf_size,
-                                              bool leaf[2]) {
+                                              bool leaf[2], int* depth_max = nullptr) {
   const int d = a.ndepth[node];
   a.nchild[node] = first;
   for (int side = 0; side < 2; ++side) {
@@ -593,7 +595,16 @@ __device__ __forceinline__ void make_children(const BvhPtrs& a, int node, int fi
     a.ndone[id] = 0;
     a.nbad[id] = 0;
   }
-  atomicMax(&a.flags[kBvhMaxDepth], d + 1);
+  atomicMax(depth_max ? depth_max : &a.flags[kBvhMaxDepth], d + 1);
+}
+// `count` fresh node ids or -1, without a verdict on the build (the caller has a smaller request to fall back on)
+__device__ __forceinline__ int try_alloc_nodes(const BvhPtrs& a, int count) {
+  const int first = atomicAdd(&a.flags[kBvhNodeCount], count);
+  if (first + count > a.cap) {
+    atomicSub(&a.flags[kBvhNodeCount], count);
+    return -1;
+  }
+  return first;
 }
 // two fresh node ids, or -1 with the fallback flag up when the buffers are full
 __device__ __forceinline__ int alloc_nodes(const BvhPtrs& a, int count) {
@@ -614,6 +625,7 @@ __global__ __launch_bounds__(256) void bvh_init(BvhPtrs a, const float2* __restr
     a.ID[i] = (uint32_t)i;
     if (p.x != p.x || p.y != p.y) a.flags[kBvhFallback] = 1;
   }
+  for (int j = i + 1; j < a.cap; j += gridDim.x * 256) a.ndepth[j] = -1;  // not a node (yet): ids are handed out in ranges
   if (n > kSub && i < (n + kChunk - 1) / kChunk) {  // the root's chunks
     a.ch_node[i] = 0;
     a.ch_index[i] = i;
@@ -1301,6 +1313,8 @@ struct SubLds {
   int lg[2][kSub / 2];                        // ... and breadth-first id
   int lcount[2];
   int idbase;  // first id of the children made at this level (one allocation per level)
+  int depth_max;  // deepest node made by this work-group
+  int id_next, id_end;  // ids this work-group holds (one atomic on the global counter per range, not per level)
   int loff[kBvhKeyDepth + 2];  // where each level of the subtree starts in its list of internal nodes
   // nodes_by_groups: per wave partial results, per node sums
   float4 gbox[kSubWaves];
@@ -1380,7 +1394,7 @@ __device__ __forceinline__ void node_in_lds(const BvhPtrs& a, SubLds& s, int gbe
   if (lane == 0) {
     a.nbox[gid] = make_float4(box.mnx, box.mny, box.mxx, box.mxy);
     bool leaf[2];
-    make_children(a, gid, first, gbegin + lb, len, m, leaf_size, leaf);
+    make_children(a, gid, first, gbegin + lb, len, m, leaf_size, leaf, &s.depth_max);
     for (int side = 0; side < 2; ++side) {
       if (leaf[side]) continue;
       const int slot = atomicAdd(&s.lcount[nxt], 1);
@@ -1554,7 +1568,7 @@ __device__ __forceinline__ void nodes_by_groups(const BvhPtrs& a, SubLds& s, int
     a.nbox[gid] = make_float4(box.mnx, box.mny, box.mxx, box.mxy);
     bool leaf[2];
     const int first = idbase + 2 * grp;
-    make_children(a, gid, first, gbegin + lb, len, m, leaf_size, leaf);
+    make_children(a, gid, first, gbegin + lb, len, m, leaf_size, leaf, &s.depth_max);
     const int nxt = cur ^ 1;
     for (int side = 0; side < 2; ++side) {
       if (leaf[side]) continue;
@@ -1589,6 +1603,8 @@ __global__ __launch_bounds__(kSubWaves * 64) void bvh_subtrees(BvhPtrs a, const 
       s.W[i] = weight[a.ID[b + i]];
     }
     if (tid == 0) {
+      s.depth_max = 0;
+      s.id_next = s.id_end = 0;
       s.lb[0][0] = 0;
       s.ll[0][0] = (uint16_t)len;  // kSub = 4096 fits
       s.lg[0][0] = root;
@@ -1608,7 +1624,26 @@ __global__ __launch_bounds__(kSubWaves * 64) void bvh_subtrees(BvhPtrs a, const 
       for (int e = tid; e < nc; e += kSubWaves * 64) list[nint + e] = s.lg[cur][e];
       if (tid == 0) {
         s.loff[nlev] = nint;
-        s.idbase = alloc_nodes(a, 2 * nc);
+        // ids for this level's children out of the work-group's range; a new range when it runs out.  726 work-groups (1 M
+        // points) asking the one global counter at every level wait ~60 ns per request ahead of them.
+        const int want = 2 * nc;
+        if (s.id_end - s.id_next < want) {
+          // the first range is what ANY tree over these points needs (leaves hold at most leaf_size points: at least
+          // len / leaf_size of them, twice as many nodes less the root's own id) and is used up to the last id; later ones
+          // (a quarter of that) may leave a few ids unused.  If the ids are nearly out, the exact count is asked for.
+          const int sure = 2 * (len / leaf_size) - 2;
+          int range = s.id_end == 0 ? sure : sure / 4;
+          range = range > want ? range : want;
+          int first = range > want ? try_alloc_nodes(a, range) : -1;
+          if (first < 0) {
+            range = want;
+            first = alloc_nodes(a, want);
+          }
+          s.id_next = first;
+          s.id_end = first < 0 ? first : first + range;
+        }
+        s.idbase = s.id_next;
+        if (s.id_next >= 0) s.id_next += want;
       }
       __syncthreads();
       const int idbase = s.idbase;
@@ -1629,7 +1664,10 @@ __global__ __launch_bounds__(kSubWaves * 64) void bvh_subtrees(BvhPtrs a, const 
       if (nlev == 2) NB_STAMP(2)
       if (nlev == 3) NB_STAMP(3)
     }
-    if (tid == 0) s.loff[nlev] = nint;
+    if (tid == 0) {
+      s.loff[nlev] = nint;
+      if (s.depth_max > 0) atomicMax(&a.flags[kBvhMaxDepth], s.depth_max);
+    }
     __syncthreads();
     NB_STAMP(4)
     // leaves: children of the listed nodes that were not split further; a lane each, points still in LDS
@@ -1731,6 +1769,7 @@ __global__ __launch_bounds__(256) void bvh_top_upward(BvhPtrs a, const uint32_t*
     }
     __syncthreads();
   }
+  if (tid == 0) a.flags[kBvhNodes] = a.nsize[0];  // the root's subtree: every node of the tree
   // pre-order numbers, top down: a node, its left subtree, its right subtree (the root has number 0); the nodes inside the
   // subtrees find theirs from here in bvh_emit
   for (int d = 0; d <= dmax; ++d) {
@@ -1754,9 +1793,10 @@ __global__ __launch_bounds__(256) void bvh_top_upward(BvhPtrs a, const uint32_t*
 __global__ __launch_bounds__(256) void bvh_emit(BvhPtrs a, float4* __restrict__ geom0, float4* __restrict__ geom1, int4* __restrict__ link,
                                                 int* __restrict__ depth_out, uint32_t* __restrict__ mass_out,
                                                 float2* __restrict__ size_out) {
-  const int m = a.flags[kBvhNodeCount] < a.cap ? a.flags[kBvhNodeCount] : a.cap;
+  const int ids = a.flags[kBvhNodeCount] < a.cap ? a.flags[kBvhNodeCount] : a.cap;  // ids handed out: not all are nodes
+  const int m = a.flags[kBvhNodes];
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= m) return;
+  if (i >= ids || a.ndepth[i] < 0) return;
   int idx = 0, v = i;
   for (int guard = 0; a.npre[v] < 0 && guard <= kBvhLevels; ++guard) {
     const int p = a.nparent[v];
@@ -1909,8 +1949,8 @@ const uint32_t* bvh_build_order(const char* scratch, const BvhBuildLayout& L) { 
 namespace {
 __global__ void bvh_verdict_kernel(const int* __restrict__ flags, const int* __restrict__ bigcount, int level_end, int node_cap,
                                    int* __restrict__ verdict) {
-  const int m = flags[kBvhNodeCount];
-  const bool ok = flags[kBvhFallback] == 0 && flags[kBvhBadIndex] == 0 && m > 0 && m <= node_cap &&
+  const int m = flags[kBvhNodes];
+  const bool ok = flags[kBvhFallback] == 0 && flags[kBvhBadIndex] == 0 && m > 0 && m <= node_cap && flags[kBvhNodeCount] <= node_cap &&
                   (level_end <= 0 || bigcount[level_end] == 0);
   verdict[0] = ok ? m : 0;
   verdict[1] = ok ? 1 : 0;

@@ -620,14 +620,14 @@ template <class T> int bvh_build_device(nbody_ctx* c, State<T>& s) {
     }
     if (env_int("NBODY_TRACE", 0) != 0)
       std::fprintf(stderr, "[nbody] device bvh build: %d nodes, depth %d, %d subtrees, %d long-node levels, %d scan restarts, %d prepared chunk runs used\n",
-                   hostf[kBvhNodeCount], hostf[kBvhMaxDepth], hostf[kBvhSubCount], lv_end, hostf[kBvhStops], hostf[kBvhRunsUsed]);
+                   hostf[kBvhNodes], hostf[kBvhMaxDepth], hostf[kBvhSubCount], lv_end, hostf[kBvhStops], hostf[kBvhRunsUsed]);
 #ifdef NB_BVH_TIMING
     std::fprintf(stderr, "[nbody] bvh_subtrees, slowest group per phase (10 ns ticks): load %d, level 1 %d, level 2 %d, level 3 %d, other levels %d, leaves %d, upward %d, store %d\n",
                  hostf[kBvhDebug], hostf[kBvhDebug + 1], hostf[kBvhDebug + 2], hostf[kBvhDebug + 3], hostf[kBvhDebug + 4], hostf[kBvhDebug + 5],
                  hostf[kBvhDebug + 6], hostf[kBvhDebug + 7]);
 #endif
-    const int m = hostf[kBvhNodeCount];
-    if (m <= 0 || m > L.node_cap || hostf[kBvhBadIndex] != 0) return 1;
+    const int m = hostf[kBvhNodes];
+    if (m <= 0 || m > L.node_cap || hostf[kBvhNodeCount] > L.node_cap || hostf[kBvhBadIndex] != 0) return 1;
     s.cur = 1 - s.cur;
     s.h_weight_stale = true;
     s.n_nodes = m;
@@ -1145,7 +1145,7 @@ template <class T> int bvh_step_ahead(nbody_ctx* c, State<T>& s, T delta, PhaseE
     const int* bigcount = flags + (L.bigcount - L.flags) / sizeof(int);
     const int* info = h + 2 + 128;
     if (env_int("NBODY_TRACE", 0) != 0) {
-      std::fprintf(stderr, "[nbody] step ahead: build verdict %d (%d nodes, depth %d, fallback %d, %d blind levels)\n", h[1], flags[kBvhNodeCount],
+      std::fprintf(stderr, "[nbody] step ahead: build verdict %d (%d nodes, depth %d, fallback %d, %d blind levels)\n", h[1], flags[kBvhNodes],
                    flags[kBvhMaxDepth], flags[kBvhFallback], lv_end);
       std::fprintf(stderr, "[nbody] tile walk (step ahead): estimate from the last walk (shift %d, total %d), %d per wave, overflow %d\n", shift,
                    info[0], info[3], info[1]);
@@ -1162,7 +1162,7 @@ template <class T> int bvh_step_ahead(nbody_ctx* c, State<T>& s, T delta, PhaseE
     s.bvh_levels_hint = used;
     s.cur = 1 - s.cur;
     s.h_weight_stale = true;
-    s.n_nodes = flags[kBvhNodeCount];
+    s.n_nodes = flags[kBvhNodes];
     s.tree_kind = NBODY_TREE_BVH;
     s.tree_max_depth = flags[kBvhMaxDepth];
     s.tree_host_stale = true;

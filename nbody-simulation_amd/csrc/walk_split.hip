@@ -629,8 +629,9 @@ __global__ __launch_bounds__(256) void walk_check_est_tail(EstimateOf est, const
     for (int k = 0; k < 8; ++k) info[k] = out[k];
     int v0 = 0, v1 = 0;
     if (tail.verdict) {
-      const int m = tail.flags[kBvhNodeCount];
+      const int m = tail.flags[kBvhNodes];
       const bool ok = tail.flags[kBvhFallback] == 0 && tail.flags[kBvhBadIndex] == 0 && m > 0 && m <= tail.node_cap &&
+                      tail.flags[kBvhNodeCount] <= tail.node_cap &&
                       (tail.level_end <= 0 || tail.bigcount[tail.level_end] == 0);
       v0 = ok ? m : 0;
       v1 = ok ? 1 : 0;
