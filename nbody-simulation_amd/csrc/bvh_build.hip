@@ -576,8 +576,8 @@ __device__ __forceinline__ int choose_axis(int len, int cxs, int cys, bool& on_x
 // depth_max: where the tree's depth is collected; null: the global flag, one atomic per node (the subtree kernel collects per
 // work-group in LDS and reports once: thousands of atomics on one address are the slowest thing a build can do).
 __device__ __forceinline__ void make_children(const BvhPtrs& a, int node, int first, int b, int len, int m, int leaf_size,
-                                              bool leaf[2], int* depth_max = nullptr) {
-  const int d = a.ndepth[node];
+                                              bool leaf[2], int* depth_max = nullptr, int depth = -1) {
+  const int d = depth >= 0 ? depth : a.ndepth[node];  // (a caller that knows the node's depth saves the trip to memory)
   a.nchild[node] = first;
   for (int side = 0; side < 2; ++side) {
     const int id = first + side;
@@ -1325,7 +1325,7 @@ struct SubLds {
 // One node whose points are s.P[lb, lb+len): fold, axis, partition, children — by ONE wave.  Up to kSub points the
 // chain is simply added in order (a scan would restart at every doubling of the sum and lose).
 __device__ __forceinline__ void node_in_lds(const BvhPtrs& a, SubLds& s, int gbegin, int lb, int len, int gid, int first, int lane,
-                                            int nxt, int leaf_size) {
+                                            int nxt, int leaf_size, int depth) {
   constexpr int TILE = 64 * kEPT;
   float2* P = s.P + lb;
   uint16_t* I = s.I + lb;
@@ -1394,7 +1394,7 @@ __device__ __forceinline__ void node_in_lds(const BvhPtrs& a, SubLds& s, int gbe
   if (lane == 0) {
     a.nbox[gid] = make_float4(box.mnx, box.mny, box.mxx, box.mxy);
     bool leaf[2];
-    make_children(a, gid, first, gbegin + lb, len, m, leaf_size, leaf, &s.depth_max);
+    make_children(a, gid, first, gbegin + lb, len, m, leaf_size, leaf, &s.depth_max, depth);
     for (int side = 0; side < 2; ++side) {
       if (leaf[side]) continue;
       const int slot = atomicAdd(&s.lcount[nxt], 1);
@@ -1462,7 +1462,7 @@ __device__ __forceinline__ void leaf_by_wave(const BvhPtrs& a, int leaf, PosPtr 
 // (the longest node of the level sets the number of rank-list rounds).
 template <int G>
 __device__ __forceinline__ void nodes_by_groups(const BvhPtrs& a, SubLds& s, int gbegin, int cur, int nc, int idbase, int tid,
-                                                int leaf_size) {
+                                                int leaf_size, int depth) {
   static_assert(G >= 2 && kSubWaves % G == 0, "at least one wave beside the chain's");
   constexpr int TILE = 64 * kEPT;
   const int lane = tid & 63, wave = tid >> 6;
@@ -1568,7 +1568,7 @@ __device__ __forceinline__ void nodes_by_groups(const BvhPtrs& a, SubLds& s, int
     a.nbox[gid] = make_float4(box.mnx, box.mny, box.mxx, box.mxy);
     bool leaf[2];
     const int first = idbase + 2 * grp;
-    make_children(a, gid, first, gbegin + lb, len, m, leaf_size, leaf, &s.depth_max);
+    make_children(a, gid, first, gbegin + lb, len, m, leaf_size, leaf, &s.depth_max, depth);
     const int nxt = cur ^ 1;
     for (int side = 0; side < 2; ++side) {
       if (leaf[side]) continue;
@@ -1595,7 +1595,7 @@ __global__ __launch_bounds__(kSubWaves * 64) void bvh_subtrees(BvhPtrs a, const 
     long long t_prev = wall_clock64();
 #endif
     const int root = a.subq[si];
-    const int b = a.nbegin[root], len = a.nlen[root];
+    const int b = a.nbegin[root], len = a.nlen[root], root_depth = a.ndepth[root];
     int* list = a.lidx + b;  // the subtree's internal nodes, level after level (the global rank lists are free now)
     for (int i = tid; i < len; i += kSubWaves * 64) {
       s.P[i] = a.P[b + i];
@@ -1650,12 +1650,13 @@ __global__ __launch_bounds__(kSubWaves * 64) void bvh_subtrees(BvhPtrs a, const 
       if (idbase < 0) break;
       nint += nc;
       ++nlev;
-      if (nc == 1) nodes_by_groups<kSubWaves>(a, s, b, cur, nc, idbase, tid, leaf_size);
-      else if (nc == 2) nodes_by_groups<kSubWaves / 2>(a, s, b, cur, nc, idbase, tid, leaf_size);
-      else if (nc <= 4) nodes_by_groups<kSubWaves / 4>(a, s, b, cur, nc, idbase, tid, leaf_size);
+      const int depth = root_depth + nlev - 1;  // of this level's nodes (nlev counts this level already)
+      if (nc == 1) nodes_by_groups<kSubWaves>(a, s, b, cur, nc, idbase, tid, leaf_size, depth);
+      else if (nc == 2) nodes_by_groups<kSubWaves / 2>(a, s, b, cur, nc, idbase, tid, leaf_size, depth);
+      else if (nc <= 4) nodes_by_groups<kSubWaves / 4>(a, s, b, cur, nc, idbase, tid, leaf_size, depth);
       else
         for (int e = wave; e < nc; e += kSubWaves)  // a wave per node
-          node_in_lds(a, s, b, s.lb[cur][e], s.ll[cur][e], s.lg[cur][e], idbase + 2 * e, lane, cur ^ 1, leaf_size);
+          node_in_lds(a, s, b, s.lb[cur][e], s.ll[cur][e], s.lg[cur][e], idbase + 2 * e, lane, cur ^ 1, leaf_size, depth);
       __syncthreads();
       if (tid == 0) s.lcount[cur] = 0;
       cur ^= 1;
