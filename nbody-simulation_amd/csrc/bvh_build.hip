@@ -61,8 +61,8 @@ struct BvhPtrs {
   int* bigq;        // [level & 1][cap_big]
   int* subq;        // subtree roots
   int* topq;        // nodes made by the long-node levels (the ones above the subtrees)
-  int* ch_node;     // [level & 1][cap_chunk] chunk -> node
-  int* ch_index;    // [level & 1][cap_chunk] chunk -> index inside the node
+  int4* ch_rec;     // [level & 1][cap_chunk] chunk -> node, index inside the node, the node's begin and length (one load
+                    // tells a chunk's kernel where its points are: the node's other fields and the points travel together)
   double2* ch_sum;  // exact-ish (f64) sums of the chunk's coordinates: only used to PREDICT binades
   float4* ch_box;   // min.x min.y max.x max.y of the chunk
   int* ch_run;      // [chunk][2 coordinates][kRunRec]: see bvh_chunk_runs
@@ -101,8 +101,7 @@ BvhPtrs make_ptrs(char* s, const BvhBuildLayout& L) {
   a.bigq = (int*)(s + L.bigq);
   a.subq = (int*)(s + L.subq);
   a.topq = (int*)(s + L.topq);
-  a.ch_node = (int*)(s + L.ch_node);
-  a.ch_index = (int*)(s + L.ch_index);
+  a.ch_rec = (int4*)(s + L.ch_rec);
   a.ch_sum = (double2*)(s + L.ch_sum);
   a.ch_box = (float4*)(s + L.ch_box);
   a.ch_run = (int*)(s + L.ch_run);
@@ -627,8 +626,7 @@ __global__ __launch_bounds__(256) void bvh_init(BvhPtrs a, const float2* __restr
   }
   for (int j = i + 1; j < a.cap; j += gridDim.x * 256) a.ndepth[j] = -1;  // not a node (yet): ids are handed out in ranges
   if (n > kSub && i < (n + kChunk - 1) / kChunk) {  // the root's chunks
-    a.ch_node[i] = 0;
-    a.ch_index[i] = i;
+    a.ch_rec[i] = make_int4(0, i, 0, n);
   }
   if (i == 0) {  // the top call is unconditional: the root is a Root whatever its length (main.rs:400)
     a.nbegin[0] = 0;
@@ -665,13 +663,12 @@ __global__ __launch_bounds__(256) void bvh_chunk_sums(BvhPtrs a, int level) {
   __shared__ double red[6][4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nc = a.chunkcount[level];
-  const int* ch_node = a.ch_node + (size_t)(level & 1) * a.cap_chunk;
-  const int* ch_index = a.ch_index + (size_t)(level & 1) * a.cap_chunk;
+  const int4* ch_rec = a.ch_rec + (size_t)(level & 1) * a.cap_chunk;
   for (int c = blockIdx.x; c < nc; c += gridDim.x) {
-    const int node = ch_node[c], ci = ch_index[c];
-    const int len = a.nlen[node];
+    const int4 cr = ch_rec[c];
+    const int ci = cr.y, len = cr.w;
     if (len <= kRunLen) continue;
-    const float2* P = a.P + a.nbegin[node];
+    const float2* P = a.P + cr.z;
     const int lo = ci * kChunk, hi = lo + kChunk < len ? lo + kChunk : len;
     double sx = 0.0, sy = 0.0;
     Box bx;
@@ -747,11 +744,10 @@ __global__ __launch_bounds__(256) void bvh_chunk_runs(BvhPtrs a, int level) {
   __shared__ int redi[2][4][4];        // [coordinate][#A, #B, #active, shape ok][wave]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nc = a.chunkcount[level];
-  const int* ch_node = a.ch_node + (size_t)(level & 1) * a.cap_chunk;
-  const int* ch_index = a.ch_index + (size_t)(level & 1) * a.cap_chunk;
+  const int4* ch_rec = a.ch_rec + (size_t)(level & 1) * a.cap_chunk;
   for (int c = blockIdx.x; c < nc; c += gridDim.x) {
-    const int node = ch_node[c], ci = ch_index[c];
-    const int len = a.nlen[node];
+    const int4 cr = ch_rec[c];
+    const int node = cr.x, ci = cr.y, len = cr.w;
     if (len <= kRunLen) continue;
     constexpr int m = 1;  // runs are prepared per chunk; bvh_big_fold merges them into at most 64 per node
     int* rec = a.ch_run + (size_t)c * 2 * kRunRec;
@@ -1091,14 +1087,13 @@ __global__ __launch_bounds__(512) void bvh_big_fold(BvhPtrs a, int level, int us
 __global__ __launch_bounds__(256) void bvh_big_count(BvhPtrs a, int level, int leaf_size) {
   __shared__ unsigned red[2][4];
   __shared__ int last_flag;
-  __shared__ int kid[2], kid_c0[2], kid_n[2], drawn[6];
+  __shared__ int kid[2], kid_c0[2], kid_n[2], kid_b[2], kid_len[2], drawn[6];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nc = a.chunkcount[level];
-  const int* ch_node = a.ch_node + (size_t)(level & 1) * a.cap_chunk;
-  const int* ch_index = a.ch_index + (size_t)(level & 1) * a.cap_chunk;
+  const int4* ch_rec = a.ch_rec + (size_t)(level & 1) * a.cap_chunk;
   for (int c = blockIdx.x; c < nc; c += gridDim.x) {
-    const int node = ch_node[c], ci = ch_index[c];
-    const int b = a.nbegin[node], len = a.nlen[node];
+    const int4 cr = ch_rec[c];
+    const int node = cr.x, ci = cr.y, b = cr.z, len = cr.w;
     const float2 h = a.nmean[node];
     const int lo = ci * kChunk, hi = lo + kChunk < len ? lo + kChunk : len;
     unsigned cx = 0u, cy = 0u;
@@ -1193,7 +1188,7 @@ __global__ __launch_bounds__(256) void bvh_big_count(BvhPtrs a, int level, int l
             const int cc0 = drawn[4 + side];
             a.nchunk0[first + side] = cc0;
             if (cc0 + cn > a.cap_chunk) a.flags[kBvhFallback] = 1;
-            else { kid[side] = first + side; kid_c0[side] = cc0; kid_n[side] = cn; }
+            else { kid[side] = first + side; kid_c0[side] = cc0; kid_n[side] = cn; kid_b[side] = side ? b + m : b; kid_len[side] = cl; }
           } else {
             a.subq[atomicAdd(&a.flags[kBvhSubCount], 1)] = first + side;  // at most one entry per node: cap entries
           }
@@ -1206,19 +1201,17 @@ __global__ __launch_bounds__(256) void bvh_big_count(BvhPtrs a, int level, int l
           if (drawn[2 + side] < 0) continue;
           if (drawn[2 + side] < a.cap_big) a.bigq[(size_t)((level + 1) & 1) * a.cap_big + drawn[2 + side]] = node;
           const int cn = (cl + kChunk - 1) / kChunk;
-          if (drawn[4 + side] + cn <= a.cap_chunk) { kid[side] = node; kid_c0[side] = drawn[4 + side]; kid_n[side] = cn; }
+          if (drawn[4 + side] + cn <= a.cap_chunk) {
+            kid[side] = node; kid_c0[side] = drawn[4 + side]; kid_n[side] = cn; kid_b[side] = b; kid_len[side] = len;
+          }
         }
       }
     }
     __syncthreads();
     for (int side = 0; side < 2; ++side) {  // chunk -> node tables of the long children, by everybody
       if (kid[side] < 0) continue;
-      int* tn = a.ch_node + (size_t)((level + 1) & 1) * a.cap_chunk + kid_c0[side];
-      int* ti = a.ch_index + (size_t)((level + 1) & 1) * a.cap_chunk + kid_c0[side];
-      for (int i = tid; i < kid_n[side]; i += 256) {
-        tn[i] = kid[side];
-        ti[i] = i;
-      }
+      int4* tr = a.ch_rec + (size_t)((level + 1) & 1) * a.cap_chunk + kid_c0[side];
+      for (int i = tid; i < kid_n[side]; i += 256) tr[i] = make_int4(kid[side], i, kid_b[side], kid_len[side]);
     }
     __syncthreads();
   }
@@ -1231,11 +1224,10 @@ __global__ __launch_bounds__(256) void bvh_big_ranks(BvhPtrs a, int level) {
   constexpr int PER = kChunk / 256;  // consecutive points per thread
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nc = a.chunkcount[level];
-  const int* ch_node = a.ch_node + (size_t)(level & 1) * a.cap_chunk;
-  const int* ch_index = a.ch_index + (size_t)(level & 1) * a.cap_chunk;
+  const int4* ch_rec = a.ch_rec + (size_t)(level & 1) * a.cap_chunk;
   for (int c = blockIdx.x; c < nc; c += gridDim.x) {
-    const int node = ch_node[c], ci = ch_index[c];
-    const int b = a.nbegin[node], len = a.nlen[node];
+    const int4 cr = ch_rec[c];
+    const int node = cr.x, ci = cr.y, b = cr.z, len = cr.w;
     const float2 h = a.nmean[node];
     const int sp = a.nsplit[node];
     const bool on_x = sp < 0;
@@ -1282,11 +1274,10 @@ __global__ __launch_bounds__(256) void bvh_big_ranks(BvhPtrs a, int level) {
 
 __global__ __launch_bounds__(256) void bvh_big_swap(BvhPtrs a, int level) {
   const int nc = a.chunkcount[level];
-  const int* ch_node = a.ch_node + (size_t)(level & 1) * a.cap_chunk;
-  const int* ch_index = a.ch_index + (size_t)(level & 1) * a.cap_chunk;
+  const int4* ch_rec = a.ch_rec + (size_t)(level & 1) * a.cap_chunk;
   for (int c = blockIdx.x; c < nc; c += gridDim.x) {
-    const int node = ch_node[c], ci = ch_index[c];
-    const int b = a.nbegin[node];
+    const int4 cr = ch_rec[c];
+    const int node = cr.x, ci = cr.y, b = cr.z;
     const int nbad = a.nbad[node];
     float2* P = a.P + b;
     uint32_t* ID = a.ID + b;
@@ -1853,8 +1844,7 @@ BvhBuildLayout bvh_build_layout(int64_t n, int leaf_size) {
   L.bigq = take(4 * 2 * CB);
   L.subq = take(4 * C);
   L.topq = take(4 * C);
-  L.ch_node = take(4 * 2 * CC);
-  L.ch_index = take(4 * 2 * CC);
+  L.ch_rec = take(16 * 2 * CC);
   L.ch_sum = take(16 * CC);
   L.ch_box = take(16 * CC);
   L.ch_run = take(4 * 48 * CC);  // 2 * kRunRec ints per chunk
