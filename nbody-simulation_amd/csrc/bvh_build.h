@@ -53,9 +53,5 @@ hipError_t bvh_build_finish(hipStream_t s, const uint32_t* weight, int n, int le
 // copy it out, the caller's gather reads it here.
 const uint32_t* bvh_build_order(const char* scratch, const BvhBuildLayout& L);
 
-// What the host would conclude from the flags after bvh_build_finish, written on the stream for kernels enqueued ahead
-// of that conclusion: verdict[0] = node count if the build is complete and usable (no fallback, no long node left at
-// `level_end`, every node numbered, count within the buffers), else 0; verdict[1] = the same as a 0/1 word.
-hipError_t bvh_build_verdict(hipStream_t s, int level_end, char* scratch, const BvhBuildLayout& L, int* verdict);
 
 }  // namespace nbody

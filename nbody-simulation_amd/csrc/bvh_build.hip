@@ -1937,16 +1937,6 @@ hipError_t bvh_build_finish(hipStream_t s, const uint32_t* weight, int n, int le
 }
 const uint32_t* bvh_build_order(const char* scratch, const BvhBuildLayout& L) { return (const uint32_t*)(scratch + L.ids); }
 
-namespace {
-__global__ void bvh_verdict_kernel(const int* __restrict__ flags, const int* __restrict__ bigcount, int level_end, int node_cap,
-                                   int* __restrict__ verdict) {
-  const int m = flags[kBvhNodes];
-  const bool ok = flags[kBvhFallback] == 0 && flags[kBvhBadIndex] == 0 && m > 0 && m <= node_cap && flags[kBvhNodeCount] <= node_cap &&
-                  (level_end <= 0 || bigcount[level_end] == 0);
-  verdict[0] = ok ? m : 0;
-  verdict[1] = ok ? 1 : 0;
-}
-}  // namespace
 
 #ifdef NB_FOLD_TIMING
 static void bvh_debug_fold_times(hipStream_t s) {
@@ -1959,10 +1949,5 @@ static void bvh_debug_fold_times(hipStream_t s) {
   (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fold_t), z, sizeof(z));
 }
 #endif
-hipError_t bvh_build_verdict(hipStream_t s, int level_end, char* scratch, const BvhBuildLayout& L, int* verdict) {
-  hipLaunchKernelGGL(bvh_verdict_kernel, dim3(1), dim3(1), 0, s, (const int*)(scratch + L.flags), (const int*)(scratch + L.bigcount),
-                     level_end, L.node_cap, verdict);
-  return hipGetLastError();
-}
 
 }  // namespace nbody

@@ -35,7 +35,7 @@ hipError_t launch_tree_walk_tile(hipStream_t s, const WalkArgs<T>& a, char* scra
 // a caller that enqueues a copy of info and an event in between.
 // tail (estimate 1 only): what a step enqueued ahead of the host needs between its build and its walk rides along with the
 // estimate check instead of costing launches of its own — the check's last work-group also sets the budget, concludes on the
-// build (what bvh_build_verdict would), packs verdict | build flags | info for ONE copy to the host, and clears the build's
+// build, packs verdict | build flags | info for ONE copy to the host, and clears the build's
 // counters for the next step.
 struct TileTail {
   const int* flags = nullptr;     // the build's flags and level counters: flag_words of them are packed
