@@ -594,7 +594,7 @@ def test_step_ahead_equals_the_plain_sequence(nb, orc, monkeypatch, capfd, order
     order = C.ORDER_AS_WRITTEN if order_name == "as_written" else C.ORDER_CONSISTENT
     pos, vel, w = nb.scenes.galaxy()
     pos, vel, w = pos[::2].copy(), vel[::2].copy(), w[::2].copy()
-    res = {}
+    res, trees = {}, {}
     for ahead in ("1", "0"):
         monkeypatch.setenv("NBODY_STEP_AHEAD", ahead)
         monkeypatch.setenv("NBODY_TRACE", "1")
@@ -609,9 +609,11 @@ def test_step_ahead_equals_the_plain_sequence(nb, orc, monkeypatch, capfd, order
             assert c.last_build_on_device() and c.tree_info().n_nodes > 0
             t = c.tree_export()                                    # the tree of the last (ahead) step is exportable
             assert t["order"].shape[0] == pos.shape[0]
+            trees[ahead] = t
         err = capfd.readouterr().err
         assert (err.count("step ahead: build verdict 1") == 6) == (ahead == "1"), err[-800:]
     assert all(np.array_equal(a, b) for a, b in zip(res["1"], res["0"]))
+    _bvh_export_equal(trees["1"], trees["0"])   # ... and is the tree the phase-by-phase step leaves (node count, order, geometry)
     mode = orc.AS_WRITTEN if order_name == "as_written" else orc.CONSISTENT
     rp, rv, _, rids, _ = orc.update_bvh(pos, vel, w, delta=0.1, theta=50.0, mode=mode, nsteps=7, nthreads=16)
     assert np.array_equal(res["1"][3], rids) and np.array_equal(res["1"][0], rp) and np.array_equal(res["1"][1], rv)
