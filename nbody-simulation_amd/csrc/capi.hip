@@ -628,6 +628,11 @@ template <class T> int bvh_build_device(nbody_ctx* c, State<T>& s) {
 #endif
     const int m = hostf[kBvhNodes];
     if (m <= 0 || m > L.node_cap || hostf[kBvhNodeCount] > L.node_cap || hostf[kBvhBadIndex] != 0) return 1;
+    {  // how many long-node levels this tree had: what a step enqueued ahead of the host enqueues blind next time
+      int used = 0;
+      while (used < kBvhLevels - 1 && hostf[kBvhFlagWords + used] != 0) ++used;
+      s.bvh_levels_hint = used;
+    }
     s.cur = 1 - s.cur;
     s.h_weight_stale = true;
     s.n_nodes = m;
@@ -1067,7 +1072,7 @@ template <class T> int bvh_step_ahead(nbody_ctx* c, State<T>& s, T delta, PhaseE
     // ---- build: as many long-node levels as the last tree had, plus one (a balanced tree's, plus two, the first time)
     const int first_levels = bvh_build_first_levels(n);
     int lv_end = first_levels > 0 ? first_levels + 2 : 0;
-    if (lv_end > 0 && s.bvh_levels_hint > 0 && s.bvh_levels_hint + 1 < lv_end) lv_end = s.bvh_levels_hint + 1;
+    if (lv_end > 0 && s.bvh_levels_hint > 0) lv_end = s.bvh_levels_hint + 1;  // (a lopsided tree has more than a balanced one + 2)
     if (lv_end > 0) lv_end = std::max(1, env_int("NBODY_BVH_BLIND_LEVELS", lv_end));  // tests: too few levels, the verdict fails
     if (lv_end > kBvhKeyDepth + 1) lv_end = kBvhKeyDepth + 1;
     const bool flags_clean = s.bb_flags_clean;

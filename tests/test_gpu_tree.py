@@ -619,6 +619,27 @@ def test_step_ahead_equals_the_plain_sequence(nb, orc, monkeypatch, capfd, order
     assert np.array_equal(res["1"][3], rids) and np.array_equal(res["1"][0], rp) and np.array_equal(res["1"][1], rv)
 
 
+def test_step_ahead_learns_how_many_levels_a_lopsided_tree_has(nb, monkeypatch, capfd):
+    """A tree with more long-node levels than a balanced one's plus two (16 decades of magnitudes: the mean split peels off a
+    few points at a time) fails the first speculation; the phase-by-phase build that follows records how many levels it
+    took, and the steps after that are enqueued ahead with that many (+1) blind levels and stand."""
+    C = nb._capi
+    rng = np.random.default_rng(29)
+    n = 60000
+    pos = (10.0 ** rng.uniform(-8, 8, (n, 2))).astype(F32)
+    monkeypatch.setenv("NBODY_TRACE", "1")
+    with C.Context(0) as c:
+        c.upload(pos, np.zeros_like(pos), np.ones(n, np.uint32))
+        c.update_tree(C.TREE_BVH, 1e-6, 5)
+        assert c.last_build_on_device()
+    err = capfd.readouterr().err
+    lines = [ln for ln in err.splitlines() if "step ahead: build verdict" in ln]
+    assert len(lines) >= 3, err[-1500:]
+    assert all("build verdict 1" in ln for ln in lines[-2:]), lines   # (the first may fail; after that the hint is right)
+    levels = [int(ln.split("long-node levels")[0].split()[-1]) for ln in err.splitlines() if "long-node levels" in ln]
+    assert levels and levels[0] > 7, levels   # more than a balanced tree over 60 000 points (5 levels) + 2
+
+
 @pytest.mark.parametrize("hook", ["NBODY_BVH_BLIND_LEVELS", "NBODY_WALK_TILE_POISON"])
 def test_step_ahead_recovers_when_its_speculation_fails(nb, monkeypatch, capfd, hook):
     """Too few blind build levels (the device verdict says 'long nodes left') and a history whose scan wraps (the walk
