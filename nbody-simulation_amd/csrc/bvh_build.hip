@@ -1720,10 +1720,15 @@ __global__ __launch_bounds__(256) void bvh_top_upward(BvhPtrs a, const uint32_t*
   constexpr int kKeep = 4096;       // entries whose (id, depth) stay in LDS; more than that are read again every level
   __shared__ int s_id[kKeep];
   __shared__ int16_t s_depth[kKeep];  // depth of a long internal node, -1: not one (a leaf, a subtree root)
-  __shared__ int s_dmax;
+  constexpr int kLeafList = 1024;
+  __shared__ int s_dmax, s_nleaf;
+  __shared__ int s_leaf[kLeafList];
+  __shared__ int s_first[kBvhLevels + 2];  // where the entries of each depth begin: the levels append theirs one after the
+                                           // other, so topq is ordered by depth and a level's loop visits its own range only
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n_top = a.flags[kBvhTopCount];
-  if (tid == 0) { a.flags[kBvhBadIndex] = 0; s_dmax = -1; }
+  if (tid == 0) { a.flags[kBvhBadIndex] = 0; s_dmax = -1; s_nleaf = 0; }
+  for (int d = tid; d < kBvhLevels + 2; d += 256) s_first[d] = n_top;
   __syncthreads();
   // what each entry is, once (all threads side by side): the loops below visit every entry, the level loops at every depth
   const auto describe = [&](int e, int& id) {  // depth of a long internal node, -2 a leaf, -1 a subtree's root
@@ -1737,10 +1742,22 @@ __global__ __launch_bounds__(256) void bvh_top_upward(BvhPtrs a, const uint32_t*
     const int d = describe(e, id);
     if (e < kKeep) { s_id[e] = id; s_depth[e] = (int16_t)d; }
     dmax = d > dmax ? d : dmax;
+    int td = a.ndepth[id];
+    td = td < 0 ? 0 : (td > kBvhLevels ? kBvhLevels : td);
+    atomicMin(&s_first[td], e);
+    if (d == -2) {  // a leaf hanging directly off a long node (few): listed, so that the waves below do not search for them
+      const int slot = atomicAdd(&s_nleaf, 1);
+      if (slot < kLeafList) s_leaf[slot] = e;
+    }
   }
   if (dmax >= 0) atomicMax(&s_dmax, dmax);
   __syncthreads();
-  for (int e = wave; e < n_top; e += 4) {  // leaves hanging directly off a long node: a wave each
+  if (tid == 0)  // a depth without entries begins where the next one does
+    for (int d = kBvhLevels; d >= 0; --d) s_first[d] = s_first[d] < s_first[d + 1] ? s_first[d] : s_first[d + 1];
+  __syncthreads();
+  const bool listed = s_nleaf <= kLeafList;
+  for (int k = wave; k < (listed ? s_nleaf : n_top); k += 4) {  // leaves hanging directly off a long node: a wave each
+    const int e = listed ? s_leaf[k] : k;
     int id;
     const int kind = e < kKeep ? (id = s_id[e], (int)s_depth[e]) : describe(e, id);
     if (kind != -2) continue;
@@ -1755,7 +1772,7 @@ __global__ __launch_bounds__(256) void bvh_top_upward(BvhPtrs a, const uint32_t*
     return describe(e, id);
   };
   for (int d = dmax; d >= 0; --d) {
-    for (int e = tid; e < n_top; e += 256) {
+    for (int e = s_first[d] + tid; e < s_first[d + 1]; e += 256) {
       int id;
       if (entry(e, id) == d) combine_children(a, id);
     }
@@ -1765,7 +1782,7 @@ __global__ __launch_bounds__(256) void bvh_top_upward(BvhPtrs a, const uint32_t*
   // pre-order numbers, top down: a node, its left subtree, its right subtree (the root has number 0); the nodes inside the
   // subtrees find theirs from here in bvh_emit
   for (int d = 0; d <= dmax; ++d) {
-    for (int e = tid; e < n_top; e += 256) {
+    for (int e = s_first[d] + tid; e < s_first[d + 1]; e += 256) {
       int id;
       if (entry(e, id) == d) {
         const int c0 = a.nchild[id];
