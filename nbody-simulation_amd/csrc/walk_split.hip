@@ -479,14 +479,40 @@ __global__ __launch_bounds__(256) void walk_tile(const WalkArgs<T> a, const uint
             wave_lds_handoff();
             if (myslot >= 0) {  // lane = target: its row, in slice order
               const T2* __restrict__ r = tile + myslot * kStride;
-              for (int j0 = 0; j0 < rounds8; ++j0) {
-                T2 v[8];
+              if constexpr (sizeof(T) == 4) {
+                // eight terms at a time, the next eight on their way from LDS while these are added (two register sets
+                // taken in turn; left to itself the compiler reads a batch, waits, adds, and reads the next)
+#define NB_ROW_LOAD(dst, blk) _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) dst[j_] = r[(blk) * 8 + j_];
+#define NB_ROW_ADD(src) _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) { ax = ax + src[j_].x; ay = ay + src[j_].y; } \
+  __builtin_amdgcn_sched_group_barrier(0x100, 8, 0); __builtin_amdgcn_sched_group_barrier(0x002, 16, 0);
+                T2 va[8], vb[8];
+                NB_ROW_LOAD(va, 0)
+                int j0 = 0;
+                for (; j0 + 3 <= rounds8; j0 += 2) {  // va holds block j0 here
+                  NB_ROW_LOAD(vb, j0 + 1)
+                  NB_ROW_ADD(va)
+                  NB_ROW_LOAD(va, j0 + 2)
+                  NB_ROW_ADD(vb)
+                }
+                if (j0 + 2 <= rounds8) {
+                  NB_ROW_LOAD(vb, j0 + 1)
+                  NB_ROW_ADD(va)
+                  NB_ROW_ADD(vb)
+                } else {
+                  NB_ROW_ADD(va)
+                }
+#undef NB_ROW_LOAD
+#undef NB_ROW_ADD
+              } else {
+                for (int j0 = 0; j0 < rounds8; ++j0) {
+                  T2 v[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = r[j0 * 8 + j];
+                  for (int j = 0; j < 8; ++j) v[j] = r[j0 * 8 + j];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                  ax = ax + v[j].x;
-                  ay = ay + v[j].y;
+                  for (int j = 0; j < 8; ++j) {
+                    ax = ax + v[j].x;
+                    ay = ay + v[j].y;
+                  }
                 }
               }
             }
