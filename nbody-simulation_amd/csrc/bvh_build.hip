@@ -51,7 +51,10 @@ constexpr int kChainStart = NB_CHAIN_START; // real adds at the start of a long 
 constexpr int kSub = NB_KSUB;       // nodes up to this long are built, subtree and all, by one work-group in LDS
 constexpr int kSubWaves = 8;     // waves of a subtree work-group
 constexpr int kChunk = 2048;     // points per work-group in the multi-group passes over a long node
-constexpr int kRunLen = 16384;   // nodes longer than this have their chain prepared chunk by chunk (bvh_chunk_runs)
+#ifndef NB_RUN_LEN
+#define NB_RUN_LEN 16384
+#endif
+constexpr int kRunLen = NB_RUN_LEN;   // nodes longer than this have their chain prepared chunk by chunk (bvh_chunk_runs)
 constexpr float kMaxF = 3.402823466e+38f;
 
 struct BvhPtrs {
