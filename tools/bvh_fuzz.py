@@ -1,7 +1,7 @@
 """Randomised cross-check of the device BVH build and the step enqueued ahead of the host (not part of the test suite: run on a
 GPU box).  Every case: a random size, leaf size and distribution; the device-built tree against the host builder's, array by
 array, and four steps enqueued ahead against four phase-by-phase steps, row by row.
-    python tools/bvh_fuzz.py [cases=150] [seed=1] [log10 of the smallest size=0] [of the largest=5.6]"""
+    python tools/bvh_fuzz.py [cases=150] [seed=1] [log10 of the smallest size=0] [of the largest=5.6] [f64]"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -11,7 +11,7 @@ cases = int(sys.argv[1]) if len(sys.argv) > 1 else 150
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 lo_exp = float(sys.argv[3]) if len(sys.argv) > 3 else 0.0
 hi_exp = float(sys.argv[4]) if len(sys.argv) > 4 else 5.6
-F32 = np.float32
+F32 = np.float64 if len(sys.argv) > 5 and sys.argv[5] == "f64" else np.float32
 
 
 def scene(kind, n):
@@ -20,7 +20,7 @@ def scene(kind, n):
     if kind == 2: return (-rng.random((n, 2)) * 1e5).astype(F32)
     if kind == 3: return (10.0 ** rng.uniform(-6, 6, (n, 2))).astype(F32)
     if kind == 4: return (rng.integers(0, 3000, (n, 2)) * 0.5).astype(F32)
-    return nb.scenes.plummer(n, seed=int(rng.integers(1, 1 << 30)))[0]
+    return nb.scenes.plummer(n, seed=int(rng.integers(1, 1 << 30)), dtype=F32)[0]
 
 
 bad = 0
