@@ -107,7 +107,67 @@ def cpu_baseline(pos, w, n_sample_targets):
 
 
 # ---------------------------------------------------------------------------------------------------- legs
-def _direct_leg(nb, name, workload, pos, vel, w, steps, profile_name, executed=None):
+def _host_cores():
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    try:  # a container's CPU share (cgroup v2 quota), when there is one
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            cores = max(1, min(cores, int(float(q) / float(per) + 0.5)))
+    except Exception:
+        pass
+    return cores
+
+
+def _oracle_native():
+    from oracle import oracle as orc
+    try:
+        orc.build(native=True)
+        return orc, True
+    except Exception:
+        return orc, False
+
+
+def _cpu_direct_sample(pos, w, n_targets):
+    """cpu_baseline of a direct-sum leg: the oracle on `n_targets` evenly spaced targets x all sources."""
+    orc, native = _oracle_native()
+    cores = _host_cores()
+    n = pos.shape[0]
+    n_targets = min(n_targets, n)
+    tg = np.arange(0, n, max(1, n // n_targets))[:n_targets]
+    orc.direct_accel(pos[:4096], w[:4096], targets=np.arange(64), nthreads=cores, native_lib=native)  # warm
+    t0 = time.perf_counter()
+    orc.direct_accel(pos, w, targets=tg, nthreads=cores, native_lib=native)
+    dt = time.perf_counter() - t0
+    pairs = float(len(tg)) * n
+    return {"value": pairs / dt, "unit": "pair-interactions/s", "cores": cores, "kind": "port",
+            "sample": f"{len(tg)} targets x {n} sources = {pairs:.3g} pairs in {dt:.2f} s (oracle/nbody_oracle.cpp, "
+                      f"{'-march=native' if native else '-march=x86-64-v3'}, the force law as main.rs:234-253 writes it)",
+            "ms_per_step_extrapolated": 1e3 * float(n) * n / (pairs / dt)}
+
+
+def _cpu_tree_steps(pos, vel, w, kind_name, theta, order_mode, steps):
+    """cpu_baseline of a Barnes-Hut leg: `steps` whole World::update steps of the oracle (build single-threaded as
+    bvh_tree.rs:56-96, force map over all host cores as main.rs:406-416, integrate single-threaded as :419-423)."""
+    orc, native = _oracle_native()
+    cores = _host_cores()
+    t0 = time.perf_counter()
+    if kind_name == "bvh":
+        _, _, _, _, c3 = orc.update_bvh(pos, vel, w, delta=DT, theta=theta, mode=order_mode, nsteps=steps, nthreads=cores,
+                                        native_lib=native)
+    else:
+        _, _, c3 = orc.update_quad(pos, vel, w, delta=DT, theta=theta, nsteps=steps, nthreads=cores, native_lib=native)
+    dt = time.perf_counter() - t0
+    return {"value": 1e3 * dt / steps, "unit": "ms/step", "cores": cores, "kind": "port",
+            "build_ms": 1e3 * c3[0] / steps, "sum_gravity_ms": 1e3 * c3[1] / steps, "post_calculations_ms": 1e3 * c3[2] / steps,
+            "sample": f"{steps} whole step(s) of the oracle's World::update ({kind_name} tree, theta {theta}) on the same bodies in {dt:.2f} s "
+                      f"(oracle/nbody_oracle.cpp, {'-march=native' if native else '-march=x86-64-v3'}; Counting split as main.rs:402/417/424)"}
+
+
+def _direct_leg(nb, name, workload, pos, vel, w, steps, profile_name, executed=None, cpu_targets=8192, kernel="nbody::direct_fast"):
     """A direct-sum leg through the context path (nbody_update_direct_f32), timed like the headline."""
     C = nb._capi
     n = pos.shape[0]
@@ -123,37 +183,45 @@ def _direct_leg(nb, name, workload, pos, vel, w, steps, profile_name, executed=N
         kms, kl = timer.read(reset=True)
         ctx.set_timer(None)
     pairs = float(n) * n
-    ach = FLOPS_PER_PAIR * pairs / (kms * 1e-3) / 1e12 if kms > 0 else 0.0
-    roof = {"bound": "valu_f32", "bound_class": "compute", "kernel": "nbody::direct_fast", "achieved": ach, "peak": PEAK_F32_TFLOPS,
+    kms_per_launch = kms                      # nbody_timer_read: average ms per timed region (one region = one step's main pass)
+    ach = FLOPS_PER_PAIR * pairs / (kms_per_launch * 1e-3) / 1e12 if kms > 0 else 0.0
+    roof = {"bound": "valu_f32", "bound_class": "compute", "kernel": kernel, "achieved": ach, "peak": PEAK_F32_TFLOPS,
             "unit": "TFLOP/s", "frac": ach / PEAK_F32_TFLOPS, "flops_per_pair": FLOPS_PER_PAIR, "pairs_per_launch": pairs,
             "kernel_ms": kms, "launches_timed": kl}
     if executed:
         roof["flops_executed_per_pair"] = executed
         roof["frac_executed"] = roof["frac"] * executed / FLOPS_PER_PAIR
     _traffic(roof, profile_name, 36 * n)
-    return {"leg": name, "workload": workload, "metric": "pair-interactions/s", "value": pairs * steps / dt, "ms_per_step": 1e3 * dt / steps,
-            "steps": steps, "dtype": "f32", "roofline": roof}
+    out = {"leg": name, "workload": workload, "metric": "pair-interactions/s", "value": pairs * steps / dt, "ms_per_step": 1e3 * dt / steps,
+           "steps": steps, "dtype": "f32", "roofline": roof}
+    if cpu_targets:
+        out["cpu_baseline"] = _cpu_direct_sample(pos, w, cpu_targets)
+    return out
 
 
-def _tree_leg(nb, name, workload, pos, vel, w, kind, theta, steps, profile_name):
-    """A Barnes-Hut leg: the step with the reference's arithmetic (bit-identical to the oracle) and with the opt-in FAST
-    pair function; roofline of the walk kernel priced in flops (it is VALU-bound: two IEEE divisions per pair)."""
+def _tree_leg(nb, name, workload, pos, vel, w, kind, theta, steps, profile_names, order=None, cpu_steps=1, default_arith="exact"):
+    """A Barnes-Hut leg: whole steps (build + walk + integrate, Counting split) with the reference's arithmetic
+    (bit-identical to the oracle) and with the tolerance-contract FAST walk; roofline of the walk kernel priced in flops
+    (it is VALU-bound); cpu_baseline = the oracle's World::update on the same bodies, timed in this run."""
     C = nb._capi
+    from oracle import oracle as orc
     f64 = pos.dtype == np.float64
     n = pos.shape[0]
-    out = {"leg": name, "workload": workload, "dtype": "f64" if f64 else "f32", "steps": steps}
+    order = C.ORDER_CONSISTENT if order is None else order
+    kind_name = "quad" if kind == C.TREE_QUAD else "bvh"
+    out = {"leg": name, "workload": workload, "dtype": "f64" if f64 else "f32", "steps": steps,
+           "order": "as written (main.rs:398-423, SURVEY F6)" if order == C.ORDER_AS_WRITTEN else "consistent"}
     with C.Context(0) as ctx:
-        ctx.set_params(theta=theta, order=C.ORDER_CONSISTENT)
-        ctx.upload(pos, vel, w)
-        ctx.walk_stats(True)                   # one untimed walk with the counters on (3 atomics per target)
-        ctx.accel_tree(kind)
-        visits, accepted, leaf_pairs = ctx.walk_stats(False)
-        ctx.upload(pos, vel, w)
+        ctx.set_params(theta=theta, order=order)
         for label, arith in (("exact", C.ARITH_AUTO), ("fast", C.ARITH_FAST)):
             ctx.set_params(arith=arith)
             ctx.upload(pos, vel, w)
+            ctx.walk_stats(True)                   # one untimed walk with the counters on (3 atomics per target)
+            ctx.accel_tree(kind)
+            v0, a0, l0 = ctx.walk_stats(False)
+            ctx.upload(pos, vel, w)
             timer = C.Timer()
-            ctx.update_tree(kind, DT, 1)
+            ctx.update_tree(kind, DT, 2)           # warm-up: allocations, the first build, the walk's history
             ctx.set_timer(timer)
             cnt = C.Counting()
             t0 = time.perf_counter()
@@ -161,58 +229,161 @@ def _tree_leg(nb, name, workload, pos, vel, w, kind, theta, steps, profile_name)
             dt = time.perf_counter() - t0
             kms, kl = timer.read(reset=True)
             ctx.set_timer(None)
+            ctx.walk_stats(True)                   # and the counts of the scene the timed steps ended on
+            ctx.accel_tree(kind)
+            v1, a1, l1 = ctx.walk_stats(False)
+            visits, accepted, leaf_pairs = 0.5 * (v0 + v1), 0.5 * (a0 + a1), 0.5 * (l0 + l1)
             flops = PAIR_FLOPS_AS_WRITTEN * float(leaf_pairs + accepted) + NODE_TEST_FLOPS * float(visits)
             ach = flops / (kms * 1e-3) / 1e12 if kms > 0 else 0.0
             peak = PEAK_F64_TFLOPS if f64 else PEAK_F32_TFLOPS
             roof = {"bound": "valu_f64" if f64 else "valu_f32", "bound_class": "compute",
-                    "kernel": "nbody::tree_walk_small" if kind == C.TREE_QUAD else "nbody::walk_tile", "achieved": ach, "peak": peak,
+                    "kernel": ("nbody::tree_walk_small" if kind == C.TREE_QUAD else "nbody::walk_tile") + ("<FAST>" if label == "fast" else ""),
+                    "achieved": ach, "peak": peak,
                     "unit": "TFLOP/s", "frac": ach / peak, "kernel_ms": kms, "launches_timed": kl,
                     "pair_evaluations_per_launch": float(leaf_pairs + accepted), "node_tests_per_launch": float(visits),
                     "flops_per_pair": PAIR_FLOPS_AS_WRITTEN, "flops_per_node_test": NODE_TEST_FLOPS,
-                    "note": "a division counts as one flop; the as-written pair function does two correctly rounded divisions "
-                            "(~30 VALU instructions each in f64), which is what holds the fraction down"}
+                    "note": "a division counts as one flop; counts are the mean of the walks before and after the timed steps; "
+                            + ("the as-written pair function does two correctly rounded divisions, which is what holds the fraction down"
+                               if label == "exact" else "one reciprocal per pair, terms summed by lane-parallel trees (tolerance contract)")}
             # node records and leaf particles reach a wave by scalar loads, shared by its 64 targets: per-target counts / 64 is
             # the lower bound (every lane on the same path); plus the targets read and the accelerations written
             node_b, pair_b = (144, 24) if f64 else (80, 12)
-            _traffic(roof, profile_name if label == "exact" else "-", int(visits * node_b / 64 + leaf_pairs * pair_b / 64 + n * (32 if f64 else 16)))
+            _traffic(roof, profile_names.get(label, "-"), int(visits * node_b / 64 + leaf_pairs * pair_b / 64 + n * (32 if f64 else 16)))
             roof["algorithmic_bytes_note"] = ("bytes the waves request if all 64 targets of a wave share their path (wave-uniform scalar loads: "
-                                              "per-target node and leaf bytes / 64) plus targets in, accelerations out; the L2 (hit rate 74 % in "
-                                              "the profile) absorbs part of it, so the HBM counter can read lower")
+                                              "per-target node and leaf bytes / 64) plus targets in, accelerations out; the L2 absorbs part of it, "
+                                              "so the HBM counter can read lower")
             out[label] = {"ms_per_step": 1e3 * dt / steps, "bodies_per_s": n * steps / dt, "build_ms": 1e3 * cnt.build_bvh / steps,
                           "walk_phase_ms": 1e3 * cnt.sum_gravity / steps, "integrate_ms": 1e3 * cnt.post_calculations / steps,
                           "interactions_per_s": (leaf_pairs + accepted) / (kms * 1e-3) if kms > 0 else None, "roofline": roof,
-                          "parity": "bit-identical to the oracle" if label == "exact" else "tolerance of the direct kernel (2e-5)"}
+                          "parity": "bit-identical to the oracle" if label == "exact" else "tolerance of the direct kernel (2e-5); tree indexing bit-exact"}
+            if label == "exact":
+                out["walk"] = {"node_visits_per_target": visits / n, "accepted_per_target": accepted / n, "leaf_pairs_per_target": leaf_pairs / n}
     out["metric"] = "ms/step"
-    out["value"] = out["exact"]["ms_per_step"]
+    out["value"] = out[default_arith]["ms_per_step"]
+    out["roofline"] = out[default_arith]["roofline"]
     out["default_arithmetic"] = "exact (the reference's operations; FAST is opt-in, NBODY_ARITH_FAST)"
-    out["walk"] = {"node_visits_per_target": visits / n, "accepted_per_target": accepted / n, "leaf_pairs_per_target": leaf_pairs / n}
+    if cpu_steps:
+        out["cpu_baseline"] = _cpu_tree_steps(pos, vel, w, kind_name, theta,
+                                              orc.AS_WRITTEN if order == C.ORDER_AS_WRITTEN else orc.CONSISTENT, cpu_steps)
     return out
 
 
-LEGS = ("config2", "per_body_masses", "reference_scene_direct", "config4")
+LEGS = ("reference_scene_bvh", "plummer1m_bvh", "config2", "per_body_masses", "reference_scene_direct", "config4")
 
 
-def run_leg(nb, name):
+def run_leg(nb, name, cpu=True):
     C = nb._capi
+    if name == "reference_scene_bvh":
+        # the ONE path the reference really runs: World::update (main.rs:388-425) with the BVH at THETA = 50 (main.rs:35),
+        # leaf 64 (bvh_tree.rs:37), on World::new's scene (main.rs:276-346, seeded here), accelerations applied as written
+        pos, vel, w = nb.scenes.galaxy()
+        return _tree_leg(nb, name, f"the reference's live path: World::update, BVH, theta 50, leaf 64, on World::new's scene ({pos.shape[0]} bodies, "
+                                   "masses 1 but for 75 000 000 and 750 000), f32, NBODY_ORDER_AS_WRITTEN", pos, vel, w, C.TREE_BVH, 50.0, 300,
+                         {"exact": "r03_leg_reference_scene_bvh_pmc.json", "fast": "r03_leg_reference_scene_bvh_fast_pmc.json"},
+                         order=C.ORDER_AS_WRITTEN, cpu_steps=10 if cpu else 0)
+    if name == "plummer1m_bvh":
+        pos, vel, w = nb.scenes.plummer(N_BODIES, seed=SEED)
+        return _tree_leg(nb, name, "World::update, BVH, theta 50, leaf 64, on the headline's bodies (1 048 576, seeded Plummer, masses 1), f32, "
+                                   "NBODY_ORDER_AS_WRITTEN", pos, vel, w, C.TREE_BVH, 50.0, 20,
+                         {"exact": "r03_leg_plummer1m_bvh_pmc.json", "fast": "r03_leg_plummer1m_bvh_fast_pmc.json"},
+                         order=C.ORDER_AS_WRITTEN, cpu_steps=2 if cpu else 0)
     if name == "config2":
         pos, vel, w = nb.scenes.plummer(65536, seed=0x5EED0002)
         return _direct_leg(nb, name, "BASELINE.json configs[1]: 65 536 bodies direct O(N^2) f32, Plummer, masses 1", pos, vel, w, 200,
-                           "r02_leg_config2_pmc.json", executed=14)   # below 2^33 pairs the clamped single pass runs (direct_fast<1,true,false,true>)
+                           "r03_leg_config2_pmc.json", executed=14, cpu_targets=65536 if cpu else 0)   # the CPU leg is one whole step here
     if name == "per_body_masses":
         pos, vel, _ = nb.scenes.plummer(N_BODIES, seed=SEED)
         w = (np.arange(N_BODIES) % 5 + 1).astype(np.uint32)
-        return _direct_leg(nb, name, "1 048 576 bodies direct f32, Plummer, per-body masses 1..5 (direct_fast<1,false,true,true>)", pos, vel, w, 3,
-                           "r02_leg_per_body_masses_pmc.json", executed=14)
+        return _direct_leg(nb, name, "1 048 576 bodies direct f32, Plummer, per-body masses 1..5", pos, vel, w, 3,
+                           "r03_leg_per_body_masses_pmc.json", executed=14, cpu_targets=16384 if cpu else 0)
     if name == "reference_scene_direct":
         pos, vel, w = nb.scenes.galaxy()
         return _direct_leg(nb, name, f"the reference's own scene (World::new, main.rs:276-346, seeded): {pos.shape[0]} bodies, masses 1 but for "
                                      "75 000 000 and 750 000 — the two ride with the near list, the main pass runs at the equal-mass rate",
-                           pos, vel, w, 50, "r02_leg_reference_scene_direct_pmc.json", executed=FLOPS_EXECUTED_PER_PAIR)
+                           pos, vel, w, 50, "r02_leg_reference_scene_direct_pmc.json", executed=FLOPS_EXECUTED_PER_PAIR,
+                           cpu_targets=32768 if cpu else 0)
     if name == "config4":
         pos, vel, w = nb.scenes.plummer(1 << 22, seed=0x5EED0004, dtype=np.float64)
         return _tree_leg(nb, name, "BASELINE.json configs[3]: 4 194 304 bodies Barnes-Hut theta 0.5, linearised quad tree, f64", pos, vel, w,
-                         C.TREE_QUAD, 0.5, 5, "r02_leg_config4_pmc.json")
+                         C.TREE_QUAD, 0.5, 5, {"exact": "r03_leg_config4_pmc.json", "fast": "r03_leg_config4_fast_pmc.json"},
+                         cpu_steps=1 if cpu else 0)
     raise SystemExit(f"bench.py: unknown leg {name!r} (one of {LEGS})")
+
+
+def _headline_roofline(n, n_tgt, kern_ms, kern_launches, steps, single_gpu_full):
+    n_launch = max(1, kern_launches // max(1, steps))      # launches of the dominant kernel per step (= chunks)
+    flops_per_launch = FLOPS_PER_PAIR * float(n) * float(n_tgt) / n_launch
+    achieved = flops_per_launch / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
+    roof = {"bound": "valu_f32", "bound_class": "compute", "kernel": "nbody::direct_fast<1,true,true,true>", "achieved": achieved,
+            "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_TFLOPS,
+            "flops_per_pair": FLOPS_PER_PAIR, "flops_executed_per_pair": FLOPS_EXECUTED_PER_PAIR,
+            "frac_executed": achieved / PEAK_F32_TFLOPS * FLOPS_EXECUTED_PER_PAIR / FLOPS_PER_PAIR,
+            "frac_note": "frac prices the 14 ALGORITHMIC flops of a pair; the timed instantiation executes 13 (mass multiply hoisted "
+                         "for equal masses, clamp dropped for far sources, one bias add extra): frac_executed = frac * 13/14",
+            "pairs_per_launch": float(n) * n_tgt / n_launch, "kernel_ms": kern_ms, "launches_timed": kern_launches,
+            "note": "no MFMA on this path (no dense contraction); peak = f32 vector peak"}
+    if single_gpu_full:
+        _traffic(roof, "r03_direct_pmc.json", 36 * n)
+        if roof["traffic"] is None:
+            _traffic(roof, "r02_direct_pmc.json", 36 * n)
+    else:
+        roof["traffic"] = None
+        roof["traffic_source"] = None
+    return roof
+
+
+def _headline_line(args, n, world, elapsed, roof, config_extra):
+    pairs_per_step = float(n) * float(n)
+    cfg = {"workload": f"direct O(N^2) f32, N={n} bodies, seeded 2-D Plummer sphere, masses 1, "
+                       f"dt={DT}, clamp={CLAMP} (BASELINE.json configs[2])",
+           "n_bodies": n, "arith": "AUTO (FAST kernel; EXACT on hazardous positions)"}
+    cfg.update(config_extra)
+    return {"metric": "pair-interactions/sec + ms/step at N=1M direct O(N^2) (force + integration step)",
+            "value": pairs_per_step * args.steps / elapsed, "unit": "pair-interactions/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": cfg, "roofline": roof}
+
+
+def run_in_library(args):
+    """`--gpus N` without an external launcher (no WORLD_SIZE): ONE process, the product's own multi-GPU path —
+    nbody_create_multi (csrc/multi.hip): one worker thread per device, RCCL by ncclCommInitAll, the reference's single
+    `world.update` call (main.rs:120) sharded inside the library.  What a Rust host would call."""
+    import nbody_simulation_amd as nb
+    C = nb._capi
+    G = args.gpus
+    n = args.n
+    pos, vel, w = nb.scenes.plummer(n, seed=SEED)
+    timer = C.Timer()
+    exchange = C.EXCHANGE_PEER if os.environ.get("NBODY_MULTI_EXCHANGE", "") == "peer" else C.EXCHANGE_RCCL
+    devices = [int(d) for d in args.devices.split(",")] if args.devices else list(range(G))
+    if len(devices) != G:
+        raise SystemExit(f"bench.py: --devices lists {len(devices)} devices, --gpus is {G}")
+    with C.MultiContext(devices, exchange=exchange, chunks=0) as ctx:
+        ctx.upload(pos, vel, w)
+        ctx.set_timer(timer)
+        if args.warmup:
+            ctx.update_direct(DT, args.warmup)
+        timer.read(reset=True)
+        # update_direct returns when every device's stream has drained (hipStreamSynchronize per worker, then the
+        # workers' join): the call itself is the barrier + synchronize bracket, and the wall time is the max over ranks
+        t0 = time.perf_counter()
+        ctx.update_direct(DT, args.steps)
+        elapsed = time.perf_counter() - t0
+        kern_ms, kern_launches = timer.read(reset=True)
+        ctx.set_timer(None)
+        g, xch, chunks, block = ctx.multi_info()
+        n_ranks = ctx.comm_count()
+    # device 0's targets (its kernels are the ones timed): blocks {c*G + 0}
+    n_tgt = sum(max(0, min(block, n - c * g * block)) for c in range(chunks)) if g > 1 else n
+    roof = _headline_roofline(n, n_tgt, kern_ms, kern_launches, args.steps, g == 1 and n == N_BODIES)
+    out = _headline_line(args, n, g, elapsed, roof,
+                         {"targets_per_gpu": n_tgt, "chunks_per_step": chunks, "block": block, "entry": "nbody_create_multi (one process, "
+                          "one worker thread per device)", "n_ranks": n_ranks,
+                          "exchange": ("RCCL in-place ncclAllGather of float2 positions per chunk (xGMI)" if xch == C.EXCHANGE_RCCL
+                                       else "hipMemcpyPeerAsync of every block to every peer")})
+    if g == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(pos, w, args.cpu_sample_targets)
+    print(json.dumps(out), flush=True)
 
 
 def main():
@@ -227,26 +398,38 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
                                                       "several ranks on one GPU)")
     ap.add_argument("--cpu-sample-targets", type=int, default=131072)
+    ap.add_argument("--in-library", action="store_true", help="run the step through nbody_create_multi (one process) even for --gpus 1")
+    ap.add_argument("--devices", default=None, help="in-library path: comma-separated device ids (default 0..gpus-1; one id may "
+                                                    "repeat under NBODY_MULTI_EXCHANGE=peer to rehearse on one GPU)")
     args = ap.parse_args()
+
+    # The launch convention is decided before anything touches a GPU, and nothing is ever re-executed: under an external
+    # launcher (torch.distributed.run sets WORLD_SIZE) this is one rank of N processes; without one, `--gpus N > 1` runs
+    # in this one process through the library's own multi-GPU context.
+    launched = "WORLD_SIZE" in os.environ
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if launched and world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        sys.exit(2)
+    if args.in_library or (not launched and args.gpus > 1):
+        if args.leg:
+            raise SystemExit("bench.py: --leg is a single-GPU run")
+        import nbody_simulation_amd  # noqa: F401  (loads the HIP library; fails loudly when it is missing)
+        return run_in_library(args)
 
     import torch
     import torch.distributed as dist
     import nbody_simulation_amd as nb
     from nbody_simulation_amd.sharding import ShardedDirectStepper
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run",
-                  file=sys.stderr)
-        sys.exit(2)
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; the HIP path has no CPU fallback", file=sys.stderr)
         sys.exit(3)
     if args.leg:
-        print(json.dumps(run_leg(nb, args.leg)), flush=True)
+        print(json.dumps(run_leg(nb, args.leg, cpu=not args.no_cpu_baseline)), flush=True)
         return
     dev_index = local_rank % torch.cuda.device_count()   # one rank per GPU; the modulo only matters in a rehearsal
     torch.cuda.set_device(dev_index)
@@ -288,38 +471,14 @@ def main():
         elapsed = float(tmax.item())
 
     if rank == 0:
-        pairs_per_step = float(n) * float(n)
-        value = pairs_per_step * args.steps / elapsed
         n_tgt = stepper.n_local
-        n_launch = max(1, kern_launches // max(1, args.steps))      # launches of the dominant kernel per step (= chunks)
-        flops_per_launch = FLOPS_PER_PAIR * float(n) * float(n_tgt) / n_launch
-        achieved = flops_per_launch / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
-        roof = {"bound": "valu_f32", "bound_class": "compute", "kernel": "nbody::direct_fast<1,true,true,true>", "achieved": achieved,
-                "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_TFLOPS,
-                "flops_per_pair": FLOPS_PER_PAIR, "flops_executed_per_pair": FLOPS_EXECUTED_PER_PAIR,
-                "frac_executed": achieved / PEAK_F32_TFLOPS * FLOPS_EXECUTED_PER_PAIR / FLOPS_PER_PAIR,
-                "frac_note": "frac prices the 14 ALGORITHMIC flops of a pair; the timed instantiation executes 13 (mass multiply hoisted "
-                             "for equal masses, clamp dropped for far sources, one bias add extra): frac_executed = frac * 13/14",
-                "pairs_per_launch": float(n) * n_tgt / n_launch, "kernel_ms": kern_ms, "launches_timed": kern_launches,
-                "note": "no MFMA on this path (no dense contraction); peak = f32 vector peak"}
-        if world == 1 and n == N_BODIES:
-            _traffic(roof, "r02_direct_pmc.json", 36 * n)
-        else:
-            roof["traffic"] = None
-            roof["traffic_source"] = None
-        out = {
-            "metric": "pair-interactions/sec + ms/step at N=1M direct O(N^2) (force + integration step)",
-            "value": value, "unit": "pair-interactions/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"direct O(N^2) f32, N={n} bodies, seeded 2-D Plummer sphere, masses 1, "
-                                   f"dt={DT}, clamp={CLAMP} (BASELINE.json configs[2])",
-                       "n_bodies": n, "targets_per_gpu": n_tgt, "chunks_per_step": stepper.chunks,
-                       "exchange": "none" if world == 1 else f"{args.backend} in-place all-gather of float2 positions per chunk"
-                                   + (" (RCCL over xGMI)" if args.backend == "nccl" else " (rehearsal)"),
-                       "arith": "AUTO (FAST kernel; EXACT on hazardous positions)"},
-            "roofline": roof,
-        }
+        roof = _headline_roofline(n, n_tgt, kern_ms, kern_launches, args.steps, world == 1 and n == N_BODIES)
+        out = _headline_line(args, n, world, elapsed, roof,
+                             {"targets_per_gpu": n_tgt, "chunks_per_step": stepper.chunks,
+                              "entry": "one process per GPU (sharding.py over nbody_direct_prep_dev / nbody_direct_run_dev)",
+                              "n_ranks": dist.get_world_size() if world > 1 else 1,
+                              "exchange": "none" if world == 1 else f"{args.backend} in-place all-gather of float2 positions per chunk"
+                                          + (" (RCCL over xGMI)" if args.backend == "nccl" else " (rehearsal)")})
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pos, w, args.cpu_sample_targets)
         if world == 1 and not args.no_legs and n == N_BODIES:
@@ -328,7 +487,7 @@ def main():
             legs = []
             for name in LEGS:
                 try:
-                    legs.append(run_leg(nb, name))
+                    legs.append(run_leg(nb, name, cpu=not args.no_cpu_baseline))
                 except Exception as e:  # a leg must not cost the headline line
                     legs.append({"leg": name, "error": repr(e)})
             out["legs"] = legs

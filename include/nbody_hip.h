@@ -34,7 +34,10 @@
 extern "C" {
 #endif
 
-#define NBODY_ABI_VERSION 1
+/* 2: nbody_create_multi*, nbody_multi_info, nbody_direct_prep/run_dev, nbody_update_tree_async_f32, nbody_wait,
+ *    nbody_get_stream, nbody_delta_decoder_set_max_bodies, nbody_selftest_*_f64 (round 2), nbody_multi_comm_count (round 3);
+ *    a binding compares nbody_abi_version() with the value it was written against before it binds anything else. */
+#define NBODY_ABI_VERSION 2
 
 typedef struct nbody_ctx nbody_ctx;
 typedef struct nbody_timer nbody_timer;
@@ -118,6 +121,9 @@ int nbody_create_multi_ex(nbody_ctx** out, int n_devices, const int* device_ids,
 /* Layout of a context: devices, exchange (-1 for a single-GPU context), chunks per direct step and bodies per target
  * block of the current upload.  Any pointer may be NULL. */
 int nbody_multi_info(const nbody_ctx* ctx, int* n_devices, int* exchange, int* chunks, int64_t* block);
+/* Ranks of the context's RCCL communicator as RCCL itself reports them (ncclCommCount); 0 for a single-GPU context or the
+ * peer-copy exchange. */
+int nbody_multi_comm_count(const nbody_ctx* ctx, int* n_ranks);
 void nbody_destroy(nbody_ctx* ctx);
 const char* nbody_last_error(const nbody_ctx* ctx);
 int nbody_default_params(nbody_params* out);
@@ -213,7 +219,7 @@ int nbody_get_counting(const nbody_ctx* ctx, nbody_counting* out);
  *   mass_all  float [n_sources]   weights converted to f32 (u32 -> f32 as `weight as f32`, main.rs:360)
  *   uniform_mass                  > 0 asserts that every entry of mass_all equals this value (the FAST kernel
  *                                 then hoists the multiply out of the sum); < 0 asserts that every entry equals
- *                                 -uniform_mass except a sparse set (at most n/64 bodies: the reference's scene has two
+ *                                 -uniform_mass except a sparse set (at most n/256 bodies: the reference's scene has two
  *                                 heavy bodies among 151 000 of weight 1, main.rs:282-291) — those are found on the
  *                                 device each step and added with their own masses after the equal-mass main pass;
  *                                 0 when masses differ freely or are unknown

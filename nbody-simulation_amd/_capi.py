@@ -16,6 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libnbody_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "nbody_hip.h")
 
+ABI_VERSION = 2   # NBODY_ABI_VERSION of include/nbody_hip.h (tests/test_capi_host.py checks the two agree)
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_DEGENERATE, ERR_NOMEM = 0, -1, -2, -3, -4, -5
 ARITH_AUTO, ARITH_FAST, ARITH_EXACT = 0, 1, 2
 ORDER_AS_WRITTEN, ORDER_CONSISTENT = 0, 1
@@ -53,6 +54,7 @@ _SIGS = {
     "nbody_create_multi": (C.c_int, [C.POINTER(_vp), _i32, _vp]),
     "nbody_create_multi_ex": (C.c_int, [C.POINTER(_vp), _i32, _vp, _i32, _i32]),
     "nbody_multi_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(_i64)]),
+    "nbody_multi_comm_count": (C.c_int, [_vp, C.POINTER(C.c_int)]),
     "nbody_get_stream": (_vp, [_vp]),
     "nbody_direct_prep_dev": (C.c_int, [_vp, _i64, _vp, _vp, _f32, _i64, _i64, _f32, _i32, _vp, _sz]),
     "nbody_direct_run_dev": (C.c_int, [_vp, _i64, _vp, _vp, _f32, _i64, _i64, _vp, _vp, _vp, _f32, _f32, _i32, _i64, _i64, _vp, _sz, _vp]),
@@ -168,12 +170,16 @@ def load() -> C.CDLL:
                                             f"`make -C nbody-simulation_amd/csrc`); there is no CPU fallback")
         _share_hip_runtime_with_torch()
         lib = C.CDLL(LIB_PATH)
+        lib.nbody_abi_version.restype = C.c_int
+        lib.nbody_abi_version.argtypes = []
+        have = lib.nbody_abi_version()
+        if have != ABI_VERSION:  # before anything else is bound: a stale library would fail with an obscure AttributeError
+            raise NBodyError(ERR_INVALID, f"{LIB_PATH} has ABI version {have}, this binding was written against {ABI_VERSION}: "
+                                          f"rebuild it (`make -C nbody-simulation_amd/csrc`)")
         for name, (res, args) in _SIGS.items():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
-        if lib.nbody_abi_version() != 1:
-            raise NBodyError(ERR_INVALID, "libnbody_hip ABI version mismatch")
         _lib = lib
     return _lib
 
@@ -358,6 +364,12 @@ class Context:
         g, x, c, b = C.c_int(0), C.c_int(0), C.c_int(0), _i64(0)
         check(self.h, self.lib.nbody_multi_info(self.h, C.byref(g), C.byref(x), C.byref(c), C.byref(b)))
         return g.value, x.value, c.value, b.value
+
+    def comm_count(self) -> int:
+        """Ranks of the context's RCCL communicator as ncclCommCount reports them (0: none)."""
+        k = C.c_int(0)
+        check(self.h, self.lib.nbody_multi_comm_count(self.h, C.byref(k)))
+        return k.value
 
     def close(self):
         if getattr(self, "h", None):

@@ -169,6 +169,10 @@ DirectConfig choose_direct_config(int64_t n_src, int64_t n_tgt, bool uniform = t
 
 constexpr size_t kFlagBytes = 256;
 
+// The partial-sum area holds gsplit(n) x n entries for every block size n <= n_tgt (a shard's last block may be
+// shorter than the others and then takes a LARGER gsplit: 262080 rows -> 9 where 262144 -> 8).  gsplit(n) =
+// ceil(want_waves / (4 ceil(n/64))) <= 16, so gsplit(n) n < 2097152 + n and <= 16 n; direct_run clamps what an
+// environment override could still push past it.
 size_t direct_partial_bytes(int64_t n_src, int64_t n_tgt) {
   size_t partial = 0;
   for (bool uni : {false, true}) {
@@ -176,6 +180,8 @@ size_t direct_partial_bytes(int64_t n_src, int64_t n_tgt) {
     size_t p = (size_t)c.gsplit * (size_t)n_tgt * sizeof(float2);
     if (p > partial) partial = p;
   }
+  size_t any_block = (size_t)std::min<int64_t>(16 * n_tgt, 2097152 + n_tgt) * sizeof(float2);
+  if (any_block > partial) partial = any_block;
   return (partial + 255) & ~(size_t)255;
 }
 size_t direct_ws_bytes(int64_t n_src, int64_t n_tgt) {
@@ -257,6 +263,7 @@ int direct_run(nbody_ctx* c, hipStream_t stream, int64_t n_src, const void* pos_
 
   DirectConfig cfg = choose_direct_config(n_src, n_tgt, p.uni);
   cfg.nearfar = p.nearfar;
+  while (cfg.gsplit > 1 && (size_t)cfg.gsplit * (size_t)n_tgt * sizeof(float2) > p.partial_bytes) --cfg.gsplit;
   if ((size_t)cfg.gsplit * (size_t)n_tgt * sizeof(float2) > p.partial_bytes)
     return fail(c, NBODY_ERR_INVALID, "direct_step: the partial sums of this block do not fit the workspace's layout");
   int* flags = (int*)ws;

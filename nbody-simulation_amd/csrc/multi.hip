@@ -60,6 +60,7 @@ struct Rccl {
   decltype(&ncclAllGather) AllGather = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
   decltype(&ncclGetVersion) GetVersion = nullptr;
+  decltype(&ncclCommCount) CommCount = nullptr;
   bool load(std::string* err) {
     if (handle) return true;
     // a copy the process already holds (PyTorch-ROCm bundles one) is reused; otherwise the system's
@@ -78,6 +79,7 @@ struct Rccl {
     AllGather = (decltype(AllGather))dlsym(handle, "ncclAllGather");
     GetErrorString = (decltype(GetErrorString))dlsym(handle, "ncclGetErrorString");
     GetVersion = (decltype(GetVersion))dlsym(handle, "ncclGetVersion");
+    CommCount = (decltype(CommCount))dlsym(handle, "ncclCommCount");
     if (!CommInitAll || !CommDestroy || !AllGather || !GetErrorString) {
       *err = "librccl lacks ncclCommInitAll / ncclAllGather";
       handle = nullptr;
@@ -89,14 +91,18 @@ struct Rccl {
 
 // All workers meet here before a collective: either every rank joins it or none does (a rank that failed to enqueue
 // its kernels must not leave the others waiting inside RCCL).
+// A worker that leaves its job with an error (or an exception) BREAKS the barrier: whoever waits, or arrives later in
+// the same job, gets `false` at once instead of waiting for a rank that will never come; Pool::run mends it before
+// the next job.
 struct Barrier {
   std::mutex m;
   std::condition_variable cv;
   int n = 1, waiting = 0;
   uint64_t gen = 0;
-  bool acc = true, result = true;
+  bool acc = true, result = true, broken = false;
   bool arrive(bool ok) {
     std::unique_lock<std::mutex> lk(m);
+    if (broken) return false;
     acc = acc && ok;
     if (++waiting == n) {
       result = acc;
@@ -107,8 +113,19 @@ struct Barrier {
       return result;
     }
     const uint64_t g = gen;
-    cv.wait(lk, [&] { return gen != g; });
-    return result;
+    cv.wait(lk, [&] { return gen != g || broken; });
+    return broken ? false : result;
+  }
+  void break_all() {
+    std::unique_lock<std::mutex> lk(m);
+    broken = true;
+    cv.notify_all();
+  }
+  void mend() {
+    std::unique_lock<std::mutex> lk(m);
+    broken = false;
+    acc = true;
+    waiting = 0;
   }
 };
 
@@ -121,6 +138,7 @@ struct Pool {
   int pending = 0;
   std::vector<int> rc;
   bool stop = false;
+  Barrier* barrier = nullptr;  // broken by a worker that fails, mended before every job
   void start(int n) {
     rc.assign((size_t)n, 0);
     for (int d = 0; d < n; ++d) th.emplace_back([this, d] { loop(d); });
@@ -142,6 +160,7 @@ struct Pool {
       } catch (...) {  // nothing unwinds out of a worker (std::bad_alloc of a host-side builder, say)
         r = NBODY_ERR_NOMEM;
       }
+      if (r != 0 && barrier) barrier->break_all();  // the others must not wait for this rank at a later barrier
       std::unique_lock<std::mutex> lk(m);
       rc[(size_t)d] = r;
       if (--pending == 0) cv_done.notify_all();
@@ -149,6 +168,7 @@ struct Pool {
   }
   // Runs f(d) on every worker; returns the first non-zero result (its device in *who).
   int run(const std::function<int(int)>& f, int* who = nullptr) {
+    if (barrier) barrier->mend();  // (no worker is inside a job here)
     std::unique_lock<std::mutex> lk(m);
     job = f;
     pending = (int)th.size();
@@ -360,11 +380,12 @@ int direct_worker(Multi& M, int d, float delta, int n_steps) {
     if (exch) {
       if (!M.barrier.arrive(ok)) return ok ? NBODY_ERR_HIP : rc;
       rc = M.gather_finish(d, S->stream);  // the next step's preparation needs every position
-      if (rc) return rc;
+      ok = rc == NBODY_OK;                 // a failure here travels to the next barrier: all ranks leave together
     } else if (!ok) {
       return rc;
     }
   }
+  if (!ok) return rc;
   if (par) std::swap(st.pos, s.pos_next);
   hipError_t e = hipStreamSynchronize(S->stream);
   if (e != hipSuccess) return M.hip_fail(d, e, "hipStreamSynchronize");
@@ -407,9 +428,13 @@ int tree_worker(Multi& M, int d, int kind, double delta, int n_steps, nbody_coun
   if (e0 != hipSuccess) return M.hip_fail(d, e0, "hipSetDevice");
   const int G = M.G;
   const int64_t begin = M.slice_begin(d), count = M.slice_count(d);
+  int rc = NBODY_OK;
+  bool ok = true;
   for (int step = 0; step < n_steps; ++step) {
-    int rc = ctx_update_tree_shard(S, M.f64, kind, delta, begin, count, d == 0 ? cnt0 : nullptr);
-    bool ok = rc == NBODY_OK;
+    if (ok) {  // (a failure of the previous step's exchange travels to this step's first barrier: all ranks leave together)
+      rc = ctx_update_tree_shard(S, M.f64, kind, delta, begin, count, d == 0 ? cnt0 : nullptr);
+      ok = rc == NBODY_OK;
+    }
     if (G == 1 && M.exchange != NBODY_EXCHANGE_RCCL) {
       if (!ok) return rc;
       continue;
@@ -425,17 +450,17 @@ int tree_worker(Multi& M, int d, int kind, double delta, int n_steps, nbody_coun
     ok = rc == NBODY_OK;
     if (!M.barrier.arrive(ok)) return ok ? NBODY_ERR_HIP : rc;
     rc = M.gather_finish(d, S->stream);
-    if (rc) return rc;
-    for (int r = 0; r < G; ++r) {
+    ok = rc == NBODY_OK;
+    for (int r = 0; r < G && ok; ++r) {
       const int64_t cr = M.slice_count(r);
       if (r == d || cr == 0) continue;
       const char* sec = M.xbuf[(size_t)d] + (size_t)r * M.xsec;
       rc = ctx_import_rows(S, cr, sec, sec + M.xoff_pos, sec + M.xoff_vel);
-      if (rc) return rc;
+      ok = rc == NBODY_OK;
     }
     if (d == 0 && exchange_s) *exchange_s += now_s() - t0;
   }
-  return NBODY_OK;
+  return ok ? NBODY_OK : rc;
 }
 
 template <class T> int replicate_rows(Multi& M) {
@@ -674,6 +699,7 @@ NB_API int nbody_create_multi_ex(nbody_ctx** out, int n_devices, const int* devi
   M->posbuf[0].assign((size_t)n_devices, nullptr);
   M->posbuf[1].assign((size_t)n_devices, nullptr);
   M->barrier.n = n_devices;
+  M->pool.barrier = &M->barrier;
   auto bail = [&](int rc) {
     multi_destroy(front);
     return rc;
@@ -733,5 +759,18 @@ NB_API int nbody_multi_info(const nbody_ctx* ctx, int* n_devices, int* exchange,
   if (exchange) *exchange = M.exchange;
   if (chunks) *chunks = M.chunks;
   if (block) *block = M.block;
+  return NBODY_OK;
+}
+
+NB_API int nbody_multi_comm_count(const nbody_ctx* ctx, int* n_ranks) {
+  if (!ctx || !n_ranks) return NBODY_ERR_INVALID;
+  *n_ranks = 0;
+  if (!ctx->multi) return NBODY_OK;
+  const Multi& M = *ctx->multi;
+  if (M.exchange != NBODY_EXCHANGE_RCCL || M.comm.empty() || !M.comm[0] || !M.rccl.CommCount) return NBODY_OK;
+  int count = 0;
+  ncclResult_t r = M.rccl.CommCount(M.comm[0], &count);
+  if (r != ncclSuccess) return NBODY_ERR_HIP;
+  *n_ranks = count;
   return NBODY_OK;
 }

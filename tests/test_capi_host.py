@@ -20,7 +20,10 @@ def test_library_exports_every_declared_symbol(nb):
 
 def test_abi_version_and_defaults(nb):
     C = nb._capi
-    assert C.load().nbody_abi_version() == 1
+    import re
+    with open(C.HEADER_PATH) as f:
+        declared = int(re.search(r"#define\s+NBODY_ABI_VERSION\s+(\d+)", f.read()).group(1))
+    assert C.load().nbody_abi_version() == declared == C.ABI_VERSION
     p = C.default_params()
     # the reference's constants: THETA main.rs:35, clamp :247, TARGET_POINTS bvh_tree.rs:37, HEIGHT main.rs:31
     assert (p.theta, p.leaf_size, p.quad_root_h) == (50.0, 64, 100000.0)

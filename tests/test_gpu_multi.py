@@ -217,6 +217,29 @@ def test_config5_shard_layout_rehearsal(nb, orc):
     assert np.all(err <= ACC_RTOL * norm + slack)
 
 
+def test_short_last_block_takes_a_larger_source_split(nb, orc):
+    """a shard's LAST block can be shorter than the others and then wants a larger blockIdx.y source split
+    (262 144 rows -> 8, 261 944 rows -> 9), whose partial sums did not fit an area sized from the full block: the step
+    failed with NBODY_ERR_INVALID for N = 2^21 - 200 on 2 ranks x 4 chunks.  One whole step, sampled targets from every
+    block (the short one included) against the oracle."""
+    C = nb._capi
+    n = (1 << 21) - 200
+    pos, vel, w = nb.scenes.plummer(n, seed=309)
+    vel = np.zeros_like(vel)
+    with _multi(nb, [0, 0], pos, vel, w, C.EXCHANGE_PEER, 4) as m:
+        g, x, c, block = m.multi_info()
+        assert (g, c, block) == (2, 4, 262144) and n - 7 * block == 261944
+        m.update_direct(0.1, 1)
+        p, v, _, ids = m.download()
+    assert np.array_equal(ids, np.arange(n, dtype=np.uint32))
+    tg = np.concatenate([np.arange(77, n, 4099), np.arange(n - 2000, n, 97)])
+    ref64, norm = orc.direct_accel(pos, w, targets=tg, accum="f64", nthreads=16)
+    err = np.abs(v[tg].astype(np.float64) / 0.1 - ref64).sum(axis=1)
+    slack = 4 * np.finfo(F32).eps * np.abs(ref64).sum(axis=1)
+    assert np.all(err - slack <= ACC_RTOL * norm), float(((err - slack) / norm).max())
+    assert np.array_equal(p, (pos + v * F32(0.1)).astype(F32))
+
+
 # ------------------------------------------------------------------ distinct devices under RCCL (needs >= 2 GPUs)
 def test_rccl_between_distinct_devices(nb):
     if _n_gpus() < 2:
