@@ -556,6 +556,293 @@ __global__ __launch_bounds__(256) void walk_tile(const WalkArgs<T> a, const uint
   if (lane == 0) atomicAdd(total_out, sum);
 }
 
+// ---- the one-pass walk under the TOLERANCE contract (nbody_arith FAST) --------------------------------------------------
+// north_star asks bit parity of the tree INDEXING and a tolerance on the forces.  walk_tile above pays for bit parity of the
+// sums as well: a row of LDS per target, a fenced hand-off, 64 dependent adds per target and leaf, two IEEE divisions per
+// pair (76 VALU instructions per (target, leaf) round).  walk_tile_fast keeps the traversal — same node tests, same
+// interaction lists, so nbody_tree_walk_stats and the history are the exact walk's — and spends the freedom:
+//   * a pair costs one v_rcp (pair_term_fast: the direct kernel's arithmetic and tolerance) and lands in an FMA;
+//   * lane = particle rounds keep their 64 terms in registers; eight targets' rows are summed TOGETHER by a transposed
+//     reduction: v_permlane32_swap + add (8 -> 4 values, each half-wave another target), v_permlane16_swap + add (4 -> 2,
+//     each row of 16 lanes another target), a DPP rotate by 8 lanes + add under a bank mask (2 -> 1), three DPP adds inside
+//     8 lanes: 36 instructions per coordinate pair for eight targets, no LDS, no fence, no chain;  each target's lane
+//     fetches its total with one ds_bpermute per coordinate;
+//   * where most of the wave wants the leaf the particles are broadcast instead (lane = target), as before.
+// Any order of additions is inside the tolerance (tests/_tol.py: 2e-5 of sum |term|; a tree of 64 + one add per leaf is
+// a better-conditioned sum than the reference's sequential chain).
+constexpr int kFastRoundCost = 19;  // VALU instructions a target costs at a leaf, lane = particle (round + its share of the reduction)
+constexpr int kFastPairCost = 14;   // ... and a particle costs the wave, lane = target (three broadcasts, the pair, two FMAs)
+
+// v_permlane32_swap / v_permlane16_swap (new in gfx950) through inline asm: this compiler's __builtin_amdgcn_permlane32_swap
+// hands back element 0 of the result pair twice (its lowering extracts value 0 for both halves), so the second register
+// of the swap is lost.  The s_nop covers "VALU writes a VGPR, a permlane swap reads it: two wait states", which the
+// compiler inserts for its own instructions and cannot see inside an asm; what reads the results next is a plain add.
+//   swap_halves: a <- {a.lo, b.lo}, b <- {a.hi, b.hi} (halves of 32 lanes)
+//   swap_rows:   a <- {a.r0, b.r0, a.r2, b.r2}, b <- {a.r1, b.r1, a.r3, b.r3} (rows of 16 lanes)
+__device__ __forceinline__ void swap_halves(float& a, float& b) {
+  asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void swap_rows(float& a, float& b) {
+  asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void swap_halves(double& a, double& b) {
+  unsigned long long ua = __builtin_bit_cast(unsigned long long, a), ub = __builtin_bit_cast(unsigned long long, b);
+  unsigned al = (unsigned)ua, ah = (unsigned)(ua >> 32), bl = (unsigned)ub, bh = (unsigned)(ub >> 32);
+  asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %2\n\tv_permlane32_swap_b32 %1, %3" : "+v"(al), "+v"(ah), "+v"(bl), "+v"(bh));
+  a = __builtin_bit_cast(double, ((unsigned long long)ah << 32) | al);
+  b = __builtin_bit_cast(double, ((unsigned long long)bh << 32) | bl);
+}
+__device__ __forceinline__ void swap_rows(double& a, double& b) {
+  unsigned long long ua = __builtin_bit_cast(unsigned long long, a), ub = __builtin_bit_cast(unsigned long long, b);
+  unsigned al = (unsigned)ua, ah = (unsigned)(ua >> 32), bl = (unsigned)ub, bh = (unsigned)(ub >> 32);
+  asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %2\n\tv_permlane16_swap_b32 %1, %3" : "+v"(al), "+v"(ah), "+v"(bl), "+v"(bh));
+  a = __builtin_bit_cast(double, ((unsigned long long)ah << 32) | al);
+  b = __builtin_bit_cast(double, ((unsigned long long)bh << 32) | bl);
+}
+// v as the DPP control CTRL moves it (every source lane lies inside the row: nothing is out of range)
+template <int CTRL, int BANKS = 0xf> __device__ __forceinline__ float dpp_of(float old, float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL, 0xf, BANKS, BANKS == 0xf));
+}
+template <int CTRL, int BANKS = 0xf> __device__ __forceinline__ double dpp_of(double old, double v) {
+  const unsigned long long uo = __builtin_bit_cast(unsigned long long, old), uv = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)uo, (int)(unsigned)uv, CTRL, 0xf, BANKS, BANKS == 0xf);
+  const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)(uo >> 32), (int)(unsigned)(uv >> 32), CTRL, 0xf, BANKS, BANKS == 0xf);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+constexpr int kDppRor8 = 0x128, kDppHalfMirror = 0x141, kDppQuad1032 = 0xB1, kDppQuad2301 = 0x4E, kDppQuadIdentity = 0xE4;
+// the sum over 8 consecutive lanes, in every one of them
+template <class T> __device__ __forceinline__ T sum_of_8_lanes(T r) {
+  r = r + dpp_of<kDppHalfMirror>((T)0, r);
+  r = r + dpp_of<kDppQuad1032>((T)0, r);
+  r = r + dpp_of<kDppQuad2301>((T)0, r);
+  return r;
+}
+// Eight values per lane -> the 64-lane total of value k in the 8 lanes from kSlotLane8(k) on.
+__device__ __forceinline__ int slot_lane8(int k) { return 16 * (((k & 1) << 1) | ((k >> 1) & 1)) + 8 * (k >> 2); }  // row {0,2,1,3}[k & 3], half-row k >> 2
+template <class T> __device__ __forceinline__ T reduce8(T (&v)[8]) {
+  T p[4], q[2];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {  // half h of p[j]: value 2j + h summed over the two halves
+    swap_halves(v[2 * j], v[2 * j + 1]);
+    p[j] = v[2 * j] + v[2 * j + 1];
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {  // row r of q[i]: value 4i + {0,2,1,3}[r] summed over four rows
+    swap_rows(p[2 * i], p[2 * i + 1]);
+    q[i] = p[2 * i] + p[2 * i + 1];
+  }
+  const T a = q[0] + dpp_of<kDppRor8>((T)0, q[0]);   // lanes i and i ^ 8 of a row added
+  const T b = q[1] + dpp_of<kDppRor8>((T)0, q[1]);
+  const T r = dpp_of<kDppQuadIdentity, 0xc>(a, b);   // lanes 0-7 of every row keep a (values 0-3), lanes 8-15 take b (values 4-7)
+  return sum_of_8_lanes(r);
+}
+// Four values per lane -> the total of value k in the 16 lanes of row {0,2,1,3}[k].
+__device__ __forceinline__ int slot_lane4(int k) { return 16 * (((k & 1) << 1) | ((k >> 1) & 1)); }
+template <class T> __device__ __forceinline__ T reduce4(T (&v)[4]) {
+  swap_halves(v[0], v[1]);
+  swap_halves(v[2], v[3]);
+  T w0 = v[0] + v[1], w1 = v[2] + v[3];
+  swap_rows(w0, w1);
+  T u = w0 + w1;
+  u = u + dpp_of<kDppRor8>((T)0, u);
+  return sum_of_8_lanes(u);
+}
+template <class T> __device__ __forceinline__ T lane_fetch(T v, int src_lane) {  // v of lane src_lane (per-lane index)
+  if constexpr (sizeof(T) == 4) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src_lane << 2, __builtin_bit_cast(int, v)));
+  } else {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)(unsigned)u);
+    const unsigned hi = (unsigned)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)(unsigned)(u >> 32));
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+  }
+}
+// pair_term_fast's scale factor: term = d * scale (force 0 makes the term an exact zero: lanes past a leaf's end)
+__device__ __forceinline__ float fast_scale(float dx, float dy, float force, float clamp) {
+  const float sum = __builtin_fabsf(dx) + __builtin_fabsf(dy);
+  const float d2 = __builtin_fmaxf(__builtin_fmaf(dy, dy, dx * dx), clamp);
+  return force * __builtin_amdgcn_rcpf(__builtin_fmaf(sum, d2, 8.0779356694631609e-28f));  // 2^-90
+}
+__device__ __forceinline__ double fast_scale(double dx, double dy, double force, double clamp) {
+  const double sum = __builtin_fabs(dx) + __builtin_fabs(dy);
+  const double d2 = __builtin_fmax(__builtin_fma(dy, dy, dx * dx), clamp);
+  const double den = __builtin_fma(sum, d2, 0x1p-700);
+  double r = __builtin_amdgcn_rcp(den);
+  r = __builtin_fma(__builtin_fma(-den, r, 1.0), r, r);
+  r = __builtin_fma(__builtin_fma(-den, r, 1.0), r, r);
+  return force * r;
+}
+__device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+template <class T>
+__global__ __launch_bounds__(256) void walk_tile_fast(const WalkArgs<T> a, const uint32_t* __restrict__ off, const int* __restrict__ info,
+                                                      const uint32_t* __restrict__ tgt_ids, uint32_t* __restrict__ hist,
+                                                      unsigned long long* __restrict__ total_out) {
+  using T2 = typename Vec2Of<T>::type;
+  using T4 = typename Vec4Of<T>::type;
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (info[1] != 0) return;  // the estimate's scan wrapped: the caller walks again without one
+  const uint32_t budget = (uint32_t)info[3];
+  int64_t lo = 0, hi = a.n_tgt;
+  while (lo < hi) {  // first t with g(t) >= wave, g(t) = off[t] / budget + t / 64 (see walk_pass)
+    const int64_t mid = (lo + hi) >> 1;
+    if ((int64_t)(off[mid] / budget) + (mid >> 6) < wave) lo = mid + 1; else hi = mid;
+  }
+  const int64_t t0 = lo;
+  hi = t0 + 64 < a.n_tgt ? t0 + 64 : a.n_tgt;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if ((int64_t)(off[mid] / budget) + (mid >> 6) <= wave) lo = mid + 1; else hi = mid;
+  }
+  if (lo == t0) return;
+  const int64_t t = t0 + lane;
+  const bool live = t < lo;
+  const int64_t row = live ? (a.tgt_index ? (int64_t)a.tgt_index[t] : t) : 0;
+  const T2 p = live ? reinterpret_cast<const T2*>(a.tgt_pos)[row] : T2{0, 0};
+  const T4* __restrict__ g0 = reinterpret_cast<const T4*>(a.geom0);
+  const T4* __restrict__ g1 = reinterpret_cast<const T4*>(a.geom1);
+  const int4* __restrict__ lk = reinterpret_cast<const int4*>(a.link);
+  const T2* __restrict__ lpos = reinterpret_cast<const T2*>(a.leaf_pos);
+  const T* __restrict__ lmass = a.leaf_mass;
+  const T theta = a.theta, clamp = a.clamp;
+  const int n_nodes = a.n_nodes_dev ? __builtin_amdgcn_readfirstlane(*a.n_nodes_dev) : a.n_nodes;
+  int resume = live ? 0 : n_nodes;
+  uint32_t n_terms = 0;
+  T ax = 0, ay = 0;
+  int i = 0;
+  while (i < n_nodes) {  // i is wave-uniform
+    const int4 l = lk[i];
+    const T4 b = g0[i];
+    const T4 c = g1[i];
+    asm volatile("" : : "s"(b.x), "s"(c.w));  // the three records together: one latency per step
+    const bool act = resume <= i;
+    int next;
+    if (l.w) {  // Leaf arm, main.rs:351-363: every particle of the slice (any order of additions: tolerance contract)
+      const unsigned long long mask = __builtin_amdgcn_ballot_w64(act);
+      if (mask) {
+        const int takers = __builtin_popcountll(mask);
+        const int rank = act ? (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u)) : -1;
+        for (int k0 = 0; k0 < l.z; k0 += 64) {  // 64 particles at a time
+          const int mine = k0 + lane;
+          const int left = l.z - k0;
+          const int mc = left < 64 ? left : 64;
+          T2 q = T2{0, 0};
+          T m = 0;  // a lane past the leaf's end: force 0, its terms are exact zeros
+          if (mine < l.z) {
+            q = lpos[l.y + mine];
+            m = lmass[l.y + mine];
+          }
+          if (takers * kFastRoundCost > mc * kFastPairCost) {  // most of the wave wants this leaf: lane = target
+            for (int j = 0; j < mc; ++j) {
+              const T qx = lane_t(q.x, j), qy = lane_t(q.y, j), qm = lane_t(m, j);
+              if (act) {
+                const T dx = qx - p.x, dy = qy - p.y;
+                const T sc = fast_scale(dx, dy, qm, clamp);
+                ax = fma_t(dx, sc, ax);
+                ay = fma_t(dy, sc, ay);
+              }
+            }
+            continue;
+          }
+          unsigned long long todo = mask;
+          int batch0 = 0;
+          while (todo) {
+            const int left_t = takers - batch0;
+            if (left_t > 4) {  // eight targets per batch (missing ones contribute zeros)
+              T X[8], Y[8];
+#pragma unroll
+              for (int sl = 0; sl < 8; ++sl) {
+                if (todo) {
+                  const int tl = __builtin_ctzll(todo);
+                  todo &= todo - 1;
+                  const T dx = q.x - lane_t(p.x, tl), dy = q.y - lane_t(p.y, tl);
+                  const T sc = fast_scale(dx, dy, m, clamp);
+                  X[sl] = dx * sc;
+                  Y[sl] = dy * sc;
+                } else {
+                  X[sl] = 0;
+                  Y[sl] = 0;
+                }
+              }
+              const T rx = reduce8(X), ry = reduce8(Y);
+              const int k = rank - batch0;
+              const bool got = k >= 0 && k < 8;
+              const int src = got ? slot_lane8(k) : lane;
+              const T gx = lane_fetch(rx, src), gy = lane_fetch(ry, src);
+              if (got) {
+                ax = ax + gx;
+                ay = ay + gy;
+              }
+              batch0 += 8;
+            } else {
+              T X[4], Y[4];
+#pragma unroll
+              for (int sl = 0; sl < 4; ++sl) {
+                if (todo) {
+                  const int tl = __builtin_ctzll(todo);
+                  todo &= todo - 1;
+                  const T dx = q.x - lane_t(p.x, tl), dy = q.y - lane_t(p.y, tl);
+                  const T sc = fast_scale(dx, dy, m, clamp);
+                  X[sl] = dx * sc;
+                  Y[sl] = dy * sc;
+                } else {
+                  X[sl] = 0;
+                  Y[sl] = 0;
+                }
+              }
+              const T rx = reduce4(X), ry = reduce4(Y);
+              const int k = rank - batch0;
+              const bool got = k >= 0 && k < 4;
+              const int src = got ? slot_lane4(k) : lane;
+              const T gx = lane_fetch(rx, src), gy = lane_fetch(ry, src);
+              if (got) {
+                ax = ax + gx;
+                ay = ay + gy;
+              }
+              batch0 += 4;
+            }
+          }
+        }
+      }
+      if (act) {
+        n_terms += (uint32_t)l.z;
+        resume = l.x;
+      }
+      next = l.x;
+    } else {
+      bool descend = false;
+      if (act) {
+        const bool contains = p.y > b.y && p.x > b.x && p.x < b.z && p.y < b.w;  // bvh_tree.rs:15-20 (all strict)
+        const T ddx = p.x - c.x, ddy = p.y - c.y;                              // dist2(p, cog), main.rs:228-232
+        const T d2 = ddx * ddx + ddy * ddy;
+        if (!contains && c.w < d2 * theta * theta) {                               // :370-372 (the test is the exact walk's, bit for bit)
+          const T dx = c.x - p.x, dy = c.y - p.y;                                  // :374-379
+          const T sc = fast_scale(dx, dy, c.z, clamp);
+          ax = fma_t(dx, sc, ax);
+          ay = fma_t(dy, sc, ay);
+          ++n_terms;
+          resume = l.x;
+        } else {
+          descend = true;                                                          // :381-382
+          resume = i + 1;
+        }
+      }
+      next = __builtin_amdgcn_ballot_w64(descend) != 0 ? i + 1 : l.x;
+    }
+    i = __builtin_amdgcn_readfirstlane(next);
+  }
+  if (live) {
+    reinterpret_cast<T2*>(a.acc)[row] = T2{ax, ay};
+    if (hist) hist[tgt_ids[t]] = n_terms;  // by particle id: the rows are permuted by every build
+  }
+  unsigned long long sum = live ? n_terms : 0ull;  // what this walk cost, for the next estimate's scale
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) sum += (unsigned long long)__shfl_xor((long long)sum, d, 64);
+  if (lane == 0) atomicAdd(total_out, sum);
+}
+
 struct EstimateOf {  // target t's terms in the last walk, scaled
   const uint32_t* hist;
   const uint32_t* ids;
@@ -802,7 +1089,9 @@ hipError_t launch_tree_walk_tile_main(hipStream_t s, const WalkArgs<T>& a, char*
   const int tt = sizeof(T) == 8 ? tile_targets_f64() : tile_targets();
   const dim3 grid((unsigned)((grid_waves + 3) / 4));
 #define NB_TILE(F, R) walk_tile<T, F, R><<<grid, dim3(256), 0, s>>>(a, off, info, tgt_ids, hist, total_out)
-  if (a.fast) { if (tt == 16) NB_TILE(true, 16); else if (tt == 4) NB_TILE(true, 4); else NB_TILE(true, 8); }
+  static const bool fast_rows = getenv("NBODY_WALK_FAST_ROWS") && atoi(getenv("NBODY_WALK_FAST_ROWS")) != 0;  // the round-2 FAST arm (rows + ordered adds), for A/B runs
+  if (a.fast && !fast_rows) walk_tile_fast<T><<<grid, dim3(256), 0, s>>>(a, off, info, tgt_ids, hist, total_out);
+  else if (a.fast) { if (tt == 16) NB_TILE(true, 16); else if (tt == 4) NB_TILE(true, 4); else NB_TILE(true, 8); }
   else { if (tt == 16) NB_TILE(false, 16); else if (tt == 4) NB_TILE(false, 4); else NB_TILE(false, 8); }
 #undef NB_TILE
   return hipGetLastError();

@@ -243,6 +243,25 @@ void bvh_walk(BvhHandle<T>* h, size_t n_tgt, const T* tgt, T theta, T clamp, int
   });
 }
 
+// Tolerance reference of a walk: the same interaction list, every term evaluated in T exactly as main.rs:252 writes it,
+// accumulated in double; norm = sum |term|_1 (the scale of tests/_tol.py).
+template <class T>
+void bvh_walk_ref(BvhHandle<T>* h, size_t n_tgt, const T* tgt, T theta, T clamp, int nthreads, double* acc, double* norm) {
+  parallel_for(n_tgt, nthreads, 256, [&](size_t b, size_t e) {
+    for (size_t i = b; i < e; ++i) {
+      const Vec2<T> p{tgt[2 * i], tgt[2 * i + 1]};
+      double ax = 0, ay = 0, nrm = 0;
+      bvh_visit_terms(p, *h->tree, h->ps.data(), theta, [&](Vec2<T> q, T force) {
+        Vec2<T> term{0, 0};
+        calculate_gravity(p, q, term, force, clamp);
+        ax += (double)term.x; ay += (double)term.y;
+        nrm += std::fabs((double)term.x) + std::fabs((double)term.y);
+      });
+      acc[2 * i] = ax; acc[2 * i + 1] = ay; norm[i] = nrm;
+    }
+  });
+}
+
 template <class T>
 QuadHandle<T>* quad_create(size_t n, const T* pos, const uint32_t* w, T rx, T ry, T rh) {
   auto* h = new QuadHandle<T>();
@@ -271,6 +290,23 @@ void quad_walk(QuadHandle<T>* h, size_t n_tgt, const T* tgt, T theta, T clamp, i
       Vec2<T> a{0, 0};
       quad_sum_gravity(Vec2<T>{tgt[2 * i], tgt[2 * i + 1]}, *h->tree, a, theta, clamp, (WalkStats*)nullptr);
       acc[2 * i] = a.x; acc[2 * i + 1] = a.y;
+    }
+  });
+}
+
+template <class T>
+void quad_walk_ref(QuadHandle<T>* h, size_t n_tgt, const T* tgt, T theta, T clamp, int nthreads, double* acc, double* norm) {
+  parallel_for(n_tgt, nthreads, 256, [&](size_t b, size_t e) {
+    for (size_t i = b; i < e; ++i) {
+      const Vec2<T> p{tgt[2 * i], tgt[2 * i + 1]};
+      double ax = 0, ay = 0, nrm = 0;
+      quad_visit_terms(p, *h->tree, theta, [&](Vec2<T> q, T force) {
+        Vec2<T> term{0, 0};
+        calculate_gravity(p, q, term, force, clamp);
+        ax += (double)term.x; ay += (double)term.y;
+        nrm += std::fabs((double)term.x) + std::fabs((double)term.y);
+      });
+      acc[2 * i] = ax; acc[2 * i + 1] = ay; norm[i] = nrm;
     }
   });
 }
@@ -333,6 +369,14 @@ ORC_API void orc_pair_f64(double p1x, double p1y, double p2x, double p2y, double
   ORC_API void orc_bvh_walk_##SFX(void* h, int64_t n_tgt, const T* tgt, T theta, T clamp, int nthreads, T* acc,     \
                                   uint64_t* stats) {                                                                \
     bvh_walk<T>((BvhHandle<T>*)h, (size_t)n_tgt, tgt, theta, clamp, nthreads, acc, stats);                          \
+  }                                                                                                                 \
+  ORC_API void orc_bvh_walk_ref_##SFX(void* h, int64_t n_tgt, const T* tgt, T theta, T clamp, int nthreads,         \
+                                      double* acc, double* norm) {                                                  \
+    bvh_walk_ref<T>((BvhHandle<T>*)h, (size_t)n_tgt, tgt, theta, clamp, nthreads, acc, norm);                       \
+  }                                                                                                                 \
+  ORC_API void orc_quad_walk_ref_##SFX(void* h, int64_t n_tgt, const T* tgt, T theta, T clamp, int nthreads,        \
+                                       double* acc, double* norm) {                                                 \
+    quad_walk_ref<T>((QuadHandle<T>*)h, (size_t)n_tgt, tgt, theta, clamp, nthreads, acc, norm);                     \
   }                                                                                                                 \
   ORC_API void* orc_quad_create_##SFX(int64_t n, const T* pos, const uint32_t* w, T rx, T ry, T rh) {               \
     return quad_create<T>((size_t)n, pos, w, rx, ry, rh);                                                           \

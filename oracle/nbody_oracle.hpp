@@ -212,6 +212,25 @@ void bvh_sum_gravity(Vec2<T> p, const BVHNode<T>& tree, const Particle<T>* base,
   }
 }
 
+// The interaction list of main.rs:348-386 as a visitor: on_term(source position, force) for every leaf particle and every
+// accepted node, in the recursion's order.  Same tests as bvh_sum_gravity above; used by the tolerance reference
+// (terms evaluated as written, accumulated in double, with sum |term|: what a FAST walk is measured against).
+template <class T, class F>
+void bvh_visit_terms(Vec2<T> p, const BVHNode<T>& tree, const Particle<T>* base, T theta, F&& on_term) {
+  if (tree.is_leaf) {
+    for (size_t i = 0; i < tree.count; ++i) on_term(base[tree.first + i].position, (T)base[tree.first + i].weight);
+    return;
+  }
+  const Rect<T>& b = tree.boundary;
+  Vec2<T> tmp = vmax(b.size, Vec2<T>{b.size.y, b.size.x});
+  if (!b.contains(p) && tmp.x * tmp.y < dist2(p, tree.center_of_gravity) * theta * theta) {
+    on_term(tree.center_of_gravity, (T)tree.total_mass);
+  } else {
+    bvh_visit_terms(p, *tree.children[0], base, theta, on_term);
+    bvh_visit_terms(p, *tree.children[1], base, theta, on_term);
+  }
+}
+
 // Pre-order flattening used by the tests to compare with the product's linearised tree.
 template <class T> struct FlatNode {
   T off_x, off_y, size_x, size_y, cog_x, cog_y;
@@ -366,6 +385,20 @@ void quad_sum_gravity(Vec2<T> p, const QuadNode<T>& tree, Vec2<T>& accel, T thet
   } else {
     for (auto& c : tree.children)
       if (c) quad_sum_gravity(p, *c, accel, theta, clamp, st);
+  }
+}
+
+template <class T, class F>
+void quad_visit_terms(Vec2<T> p, const QuadNode<T>& tree, T theta, F&& on_term) {  // quad_sum_gravity's interaction list
+  if (tree.is_leaf) {
+    for (int i = 0; i < tree.count; ++i) on_term(tree.pts[i].position, (T)tree.pts[i].weight);
+    return;
+  }
+  if (!tree.boundary.contains(p) && tree.boundary.height2 < dist2(p, tree.center_of_gravity) * theta * theta) {
+    on_term(tree.center_of_gravity, (T)tree.total_mass);
+  } else {
+    for (auto& c : tree.children)
+      if (c) quad_visit_terms(p, *c, theta, on_term);
   }
 }
 

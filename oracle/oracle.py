@@ -258,6 +258,20 @@ class BVH:
           _p(st, C.c_uint64))
         return (acc, st) if stats else acc
 
+    def walk_ref(self, targets, theta=50.0, clamp=0.001, nthreads=1):
+        """The tolerance reference of the walk: the same interaction list, every term as main.rs:252 writes it in the tree's
+        precision, accumulated in double -> (acc64[n,2], norm[n] = sum |term|_1)."""
+        ct = self.ct
+        tg = _prep(targets, self.nt)
+        acc = np.zeros(tg.shape, np.float64)
+        norm = np.zeros(tg.shape[0], np.float64)
+        f = getattr(self._L, f"orc_bvh_walk_ref_{self.sfx}")
+        f.restype = None
+        f.argtypes = [C.c_void_p, C.c_int64, C.POINTER(ct), ct, ct, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        f(self.h, tg.shape[0], _p(tg, ct), ct(self.nt(theta)), ct(self.nt(np.float32(clamp))), int(nthreads),
+          _p(acc, C.c_double), _p(norm, C.c_double))
+        return acc, norm
+
 
 @dataclass
 class FlatQuad:
@@ -342,3 +356,17 @@ class Quad:
         f(self.h, tg.shape[0], _p(tg, ct), ct(self.nt(theta)), ct(self.nt(np.float32(clamp))), int(nthreads), _p(acc, ct),
           _p(st, C.c_uint64))
         return (acc, st) if stats else acc
+
+    def walk_ref(self, targets, theta=50.0, clamp=0.001, nthreads=1):
+        """The tolerance reference of the walk: the same interaction list, every term as main.rs:252 writes it in the tree's
+        precision, accumulated in double -> (acc64[n,2], norm[n] = sum |term|_1)."""
+        ct = self.ct
+        tg = _prep(targets, self.nt)
+        acc = np.zeros(tg.shape, np.float64)
+        norm = np.zeros(tg.shape[0], np.float64)
+        f = getattr(self._L, f"orc_quad_walk_ref_{self.sfx}")
+        f.restype = None
+        f.argtypes = [C.c_void_p, C.c_int64, C.POINTER(ct), ct, ct, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        f(self.h, tg.shape[0], _p(tg, ct), ct(self.nt(theta)), ct(self.nt(np.float32(clamp))), int(nthreads),
+          _p(acc, C.c_double), _p(norm, C.c_double))
+        return acc, norm

@@ -1,0 +1,156 @@
+"""The tolerance-contract Barnes-Hut walk (nbody_arith FAST: walk_tile_fast / the FAST arms of the fused walks) against the
+CPU oracle.  Needs an MI355X.
+
+north_star: tree node indexing bit-exact, forces to a stated tolerance.  FAST keeps the exact walk's node tests and
+interaction lists (so the walk statistics and the tree are the oracle's, bit for bit) and evaluates a pair with one
+reciprocal, sums a leaf's terms by a lane-parallel tree instead of the reference's sequential chain.  The bound is the
+direct kernel's (tests/_tol.py): |a_gpu - a_ref64|_1 <= 2e-5 * sum |term|_1 per target, a_ref64 = the walk's own terms
+evaluated as main.rs:252 writes them and accumulated in double (oracle: BVH.walk_ref / Quad.walk_ref)."""
+import numpy as np
+import pytest
+
+from tests._tol import check_fast
+
+pytestmark = pytest.mark.gpu
+F32 = np.float32
+F64_RTOL = 1e-12     # f64 FAST: a twice-refined reciprocal (~2^-52), the sum in double — far inside this
+
+
+@pytest.fixture(scope="module")
+def ctx(nb):
+    c = nb._capi.Context(0)
+    yield c
+    c.close()
+
+
+def _scene(nb, name, n, dtype):
+    rng = np.random.default_rng(71)
+    if name == "plummer":
+        pos, vel, _ = nb.scenes.plummer(n, seed=711)
+    elif name == "galaxy":
+        pos, vel, _ = nb.scenes.galaxy()
+        sel = rng.choice(pos.shape[0], n, replace=False)
+        sel.sort()
+        sel[:2] = (0, 1)                                   # keep the two heavy bodies
+        pos, vel = pos[sel], vel[sel]
+    else:  # clumps: tight groups far apart -> waves in which a handful of lanes want a leaf
+        centres = rng.random((n // 50, 2)) * 9e4 + 5e3
+        pos = (np.repeat(centres, 50, axis=0) + rng.standard_normal((n // 50 * 50, 2)) * 3.0).astype(F32)
+        vel = np.zeros_like(pos)
+    n = pos.shape[0]
+    w = (np.arange(n) % 5 + 1).astype(np.uint32)
+    if name == "galaxy":
+        w[0], w[1] = 75_000_000, 750_000
+    return pos.astype(dtype), vel.astype(dtype), w
+
+
+def _check(acc, ref64, norm, dtype, label):
+    if dtype == np.float32:
+        check_fast(acc, ref64, norm, label=label)
+    else:
+        err = np.abs(acc.astype(np.float64) - ref64).sum(axis=1)
+        assert np.all(np.isfinite(acc)) and np.all(err <= F64_RTOL * norm), float((err / norm).max())
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("scene,n,theta,leaf", [
+    ("plummer", 30000, 50.0, 64),     # the reference's theta: few takers per leaf (batches of 4 and 8)
+    ("plummer", 30000, 0.5, 64),      # needle boxes, nearly the direct sum: lane = target arm
+    ("plummer", 9000, 5.0, 16),       # small big-leaves
+    ("plummer", 9000, 50.0, 200),     # leaves longer than a wave: 64 particles at a time
+    ("galaxy", 40000, 50.0, 64),      # masses 1..5 and the two heavy bodies
+    ("clumps", 20000, 50.0, 64),
+])
+def test_fast_bvh_walk_within_tolerance(nb, orc, ctx, monkeypatch, dtype, scene, n, theta, leaf):
+    C = nb._capi
+    monkeypatch.setenv("NBODY_WALK_SPLIT", "3")            # the one-pass walk whatever the size
+    pos, vel, w = _scene(nb, scene, n, dtype)
+    pos[10] = pos[11]                                      # a coincident pair inside one leaf: contributes exactly nothing
+    bvh = orc.BVH(pos, w, leaf_size=leaf)
+    flat = bvh.flat()
+    ctx.set_params(theta=theta, leaf_size=leaf, order=C.ORDER_CONSISTENT, arith=C.ARITH_FAST)
+    ctx.upload(pos, vel, w)
+    acc = ctx.accel_tree(C.TREE_BVH)                       # the particles themselves, in tree order
+    # tree indexing stays bit-exact under FAST: the build does not depend on the arithmetic of the walk
+    t = ctx.tree_export()
+    for k in ("mass", "is_leaf", "first", "count", "skip"):
+        assert np.array_equal(t[k], getattr(flat, k)), k
+    assert np.array_equal(t["geom"], flat.geom, equal_nan=True) and np.array_equal(ctx.download()[3], flat.ids)
+    ref64, norm = bvh.walk_ref(flat.pos_perm, theta=theta, nthreads=16)
+    _check(acc, ref64, norm, dtype, f" bvh {scene} theta {theta} leaf {leaf}")
+    # arbitrary targets: fewer than a wave, not a multiple of 64, far outside every box
+    far = np.array([[1e7, -1e7], [0, 0], [5e4, 5e4]], dtype)
+    for tg in (pos[:37], np.concatenate([pos[5::11], far])):
+        ctx.upload(pos, vel, w)
+        acc = ctx.accel_tree(C.TREE_BVH, tg)
+        ref64, norm = bvh.walk_ref(tg, theta=theta, nthreads=16)
+        _check(acc, ref64, np.maximum(norm, 1e-300), dtype, " targets")
+    ctx.set_params(arith=C.ARITH_AUTO, leaf_size=64)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("n,theta", [(20000, 0.5), (20000, 50.0), (3000, 0.0)])
+def test_fast_quad_walk_within_tolerance(nb, orc, ctx, dtype, n, theta):
+    C = nb._capi
+    pos, vel, w = _scene(nb, "plummer", n, dtype)
+    pos[10] = pos[11]
+    quad = orc.Quad(pos, w)
+    ctx.set_params(theta=theta, order=C.ORDER_CONSISTENT, arith=C.ARITH_FAST)
+    ctx.upload(pos, vel, w)
+    acc = ctx.accel_tree(C.TREE_QUAD)
+    ref64, norm = quad.walk_ref(pos, theta=theta, nthreads=16)
+    _check(acc, ref64, norm, dtype, f" quad theta {theta}")
+    acc = ctx.accel_tree(C.TREE_QUAD, pos[3::7])
+    _check(acc, ref64[3::7], norm[3::7], dtype, " quad targets")
+    ctx.set_params(arith=C.ARITH_AUTO)
+
+
+@pytest.mark.parametrize("kind_name,dtype", [("bvh", np.float32), ("quad", np.float32), ("quad", np.float64), ("bvh", np.float64)])
+def test_fast_walk_statistics_are_the_oracles(nb, orc, ctx, kind_name, dtype):
+    """Node visits, accepted nodes and leaf pairs of a FAST walk equal the oracle's recursion: the interaction lists do not
+    depend on the arithmetic of the pair function."""
+    C = nb._capi
+    n = 6000
+    pos, vel, w = _scene(nb, "plummer", n, dtype)
+    kind = C.TREE_BVH if kind_name == "bvh" else C.TREE_QUAD
+    tree = orc.BVH(pos, w) if kind_name == "bvh" else orc.Quad(pos, w)
+    for theta in (50.0, 0.7):
+        ctx.set_params(theta=theta, order=C.ORDER_CONSISTENT, arith=C.ARITH_FAST)
+        ctx.upload(pos, vel, w)
+        ctx.walk_stats(True)
+        ctx.accel_tree(kind, pos)
+        got = ctx.walk_stats(False)
+        _, st = tree.walk(pos, theta=theta, stats=True)
+        assert tuple(int(x) for x in st) == got
+    ctx.set_params(arith=C.ARITH_AUTO)
+
+
+@pytest.mark.parametrize("order", ["as_written", "consistent"])
+def test_fast_bvh_steps_follow_the_exact_trajectory(nb, orc, ctx, order):
+    """Whole World::update steps under FAST (the walk's history estimate, steps enqueued ahead of the host, the walk's
+    counts by id): after 10 steps the positions are the exact trajectory's to a few ulps of the box, particle by particle
+    (by id: a last-bit difference may send a particle to the other side of a split plane and permute the rows)."""
+    C = nb._capi
+    pos, vel, w = nb.scenes.galaxy()
+    pos, vel, w = pos[::2].copy(), vel[::2].copy(), w[::2].copy()
+    ordc = C.ORDER_AS_WRITTEN if order == "as_written" else C.ORDER_CONSISTENT
+    out = {}
+    for arith in (C.ARITH_AUTO, C.ARITH_FAST):
+        ctx.set_params(theta=50.0, leaf_size=64, order=ordc, arith=arith)
+        ctx.upload(pos, vel, w)
+        ctx.update_tree(C.TREE_BVH, 0.1, 10)
+        p, v, _, ids = ctx.download()
+        inv = np.argsort(ids)
+        out[arith] = (p[inv], v[inv])
+    ctx.set_params(arith=C.ARITH_AUTO)
+    if order == "consistent":
+        # velocities change by dt * a per step: |dv| <= 10 * dt * 2e-5 * sum|term|; positions by dt * that
+        dv = np.abs(out[C.ARITH_FAST][1].astype(np.float64) - out[C.ARITH_AUTO][1]).max()
+        dp = np.abs(out[C.ARITH_FAST][0].astype(np.float64) - out[C.ARITH_AUTO][0]).max()
+        scale = np.abs(out[C.ARITH_AUTO][1]).max()
+        assert dv <= 1e-3 * max(scale, 1.0) and dp <= 0.05, (dv, dp, scale)
+    else:
+        # as written the acceleration of row i goes to whoever sits in row i after the build: a permuted row
+        # changes WHO gets an acceleration, so only the bulk is comparable: nearly every particle agrees closely
+        dp = np.abs(out[C.ARITH_FAST][0].astype(np.float64) - out[C.ARITH_AUTO][0]).max(axis=1)
+        assert np.mean(dp <= 0.05) > 0.99, float(np.mean(dp <= 0.05))
