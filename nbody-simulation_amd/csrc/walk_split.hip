@@ -20,6 +20,9 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <cstdio>
+#include <vector>
+
 #include "bvh_build.h"
 #include "walk_split.h"
 
@@ -387,22 +390,26 @@ __global__ __launch_bounds__(256) void walk_tile(const WalkArgs<T> a, const uint
   __shared__ T2 tile_all[4][TT * kStride];
   const int lane = threadIdx.x & 63;
   T2* __restrict__ tile = tile_all[threadIdx.x >> 6];
-  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
   if (info[1] != 0) return;  // the estimate's scan wrapped: the caller takes the fused walk
-  const uint32_t budget = (uint32_t)info[3];
-  int64_t lo = 0, hi = a.n_tgt;
-  while (lo < hi) {  // first t with g(t) >= wave, g(t) = off[t] / budget + t / 64 (see walk_pass)
-    const int64_t mid = (lo + hi) >> 1;
-    if ((int64_t)(off[mid] / budget) + (mid >> 6) < wave) lo = mid + 1; else hi = mid;
-  }
-  const int64_t t0 = lo;
-  hi = t0 + 64 < a.n_tgt ? t0 + 64 : a.n_tgt;
+  // first t with g(t) >= wave, g(t) = off[t] / budget + t / 64 (see walk_pass), then the first with g(t) > wave: all on the
+  // scalar side (`off` through the constant address space; the budget is a power of two, tile_total)
+  const int bshift = 31 - __builtin_clz((unsigned)__builtin_amdgcn_readfirstlane(info[3]));
+  const uint32_t __attribute__((address_space(4)))* offc = (const uint32_t __attribute__((address_space(4)))*)off;
+  const int n_tgt = (int)a.n_tgt;  // (the scan is 32 bits wide)
+  int lo = 0, hi = n_tgt;
   while (lo < hi) {
-    const int64_t mid = (lo + hi) >> 1;
-    if ((int64_t)(off[mid] / budget) + (mid >> 6) <= wave) lo = mid + 1; else hi = mid;
+    const int mid = (int)(((unsigned)lo + (unsigned)hi) >> 1);
+    if ((int)(offc[mid] >> bshift) + (mid >> 6) < wave) lo = mid + 1; else hi = mid;
+  }
+  const int t0 = lo;
+  hi = t0 + 64 < n_tgt ? t0 + 64 : n_tgt;
+  while (lo < hi) {
+    const int mid = (int)(((unsigned)lo + (unsigned)hi) >> 1);
+    if ((int)(offc[mid] >> bshift) + (mid >> 6) <= wave) lo = mid + 1; else hi = mid;
   }
   if (lo == t0) return;
-  const int64_t t = t0 + lane;
+  const int64_t t = (int64_t)t0 + lane;
   const bool live = t < lo;
   const int64_t row = live ? (a.tgt_index ? (int64_t)a.tgt_index[t] : t) : 0;
   const T2 p = live ? reinterpret_cast<const T2*>(a.tgt_pos)[row] : T2{0, 0};
@@ -417,29 +424,20 @@ __global__ __launch_bounds__(256) void walk_tile(const WalkArgs<T> a, const uint
   uint32_t n_terms = 0;
   T ax = 0, ay = 0;  // Vec2::zero(), main.rs:409
   int i = 0;
-  while (i < n_nodes) {  // i is wave-uniform
-    const int4 l = lk[i];
-    const T4 b = g0[i];
-    const T4 c = g1[i];
-#ifndef NB_TILE_LATE_GEOM
-    asm volatile("" : : "s"(b.x), "s"(c.w));  // the three records together: one latency per step (the compiler sinks the two
-                                              // it needs in the node arm only into that arm, behind the first one's wait)
-#endif
-    const bool act = resume <= i;
-    int next;
-    if (l.w) {  // Leaf arm, main.rs:351-363
-      const unsigned long long mask = __builtin_amdgcn_ballot_w64(act);
-      if (mask) {
+  // The particles [first, first + count), in order, for the lanes of `mask` (`act`: this lane is one of them): main.rs:351-363.
+  auto leaf_rows = [&](const unsigned long long mask, const bool act, const int first, const int count) {
+    {
+      {
         const int takers = __builtin_popcountll(mask);
-        for (int k0 = 0; k0 < l.z; k0 += 64) {  // 64 particles at a time
+        for (int k0 = 0; k0 < count; k0 += 64) {  // 64 particles at a time
           const int mine = k0 + lane;
-          const int left = l.z - k0;
+          const int left = count - k0;
           const int rounds8 = ((left < 64 ? left : 64) + 7) >> 3;
           T2 q = T2{0, 0};
           T m = 0;
-          if (mine < l.z) {
-            q = lpos[l.y + mine];
-            m = lmass[l.y + mine];
+          if (mine < count) {
+            q = lpos[first + mine];
+            m = lmass[first + mine];
           }
           if (takers * kTileRoundCost > (left < 64 ? left : 64) * kFusedPairCost) {
             // most of the wave wants this leaf: lane = target, the particles one after the other (the fused walk's
@@ -456,7 +454,7 @@ __global__ __launch_bounds__(256) void walk_tile(const WalkArgs<T> a, const uint
             continue;
           }
           unsigned long long todo = mask;
-          const bool valid = mine < l.z;
+          const bool valid = mine < count;
           // the acting targets take the rows in lane order, TT per batch: a target's row is its rank among the acting lanes
           const int rank = act ? (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u)) : -1;
           int batch0 = 0;
@@ -520,6 +518,21 @@ __global__ __launch_bounds__(256) void walk_tile(const WalkArgs<T> a, const uint
           }
         }
       }
+    }
+  };
+  while (i < n_nodes) {  // i is wave-uniform
+    const int4 l = lk[i];
+    const T4 b = g0[i];
+    const T4 c = g1[i];
+#ifndef NB_TILE_LATE_GEOM
+    asm volatile("" : : "s"(b.x), "s"(c.w));  // the three records together: one latency per step (the compiler sinks the two
+                                              // it needs in the node arm only into that arm, behind the first one's wait)
+#endif
+    const bool act = resume <= i;
+    int next;
+    if (l.w) {  // Leaf arm
+      const unsigned long long mask = __builtin_amdgcn_ballot_w64(act);
+      if (mask) leaf_rows(mask, act, l.y, l.z);
       if (act) {
         n_terms += (uint32_t)l.z;
         resume = l.x;
@@ -542,7 +555,22 @@ __global__ __launch_bounds__(256) void walk_tile(const WalkArgs<T> a, const uint
           resume = i + 1;
         }
       }
-      next = __builtin_amdgcn_ballot_w64(descend) != 0 ? i + 1 : l.x;
+      const unsigned long long dmask = __builtin_amdgcn_ballot_w64(descend);
+      if (l.x - i == 3) {
+        // A subtree of three nodes: both children are leaves and a lane that descends takes both, whole (main.rs:381-382:
+        // children[0] then children[1]) — their slices, one after the other, ARE this node's own range [first, first +
+        // count) (the partition keeps a node's particles together, left child first; the record of an inner node carries
+        // its range too).  So the two leaf steps happen here: the same pairs for the same lanes in the same order, two
+        // records and one round trip to the particles fewer per pair of leaves.
+        if (dmask) leaf_rows(dmask, descend, l.y, l.z);
+        if (descend) {
+          n_terms += (uint32_t)l.z;
+          resume = l.x;
+        }
+        next = l.x;
+      } else {
+        next = dmask != 0 ? i + 1 : l.x;
+      }
     }
     i = __builtin_amdgcn_readfirstlane(next);
   }
@@ -637,7 +665,6 @@ template <class T> __device__ __forceinline__ T reduce8(T (&v)[8]) {
   return sum_of_8_lanes(r);
 }
 // Four values per lane -> the total of value k in the 16 lanes of row {0,2,1,3}[k].
-__device__ __forceinline__ int slot_lane4(int k) { return 16 * (((k & 1) << 1) | ((k >> 1) & 1)); }
 template <class T> __device__ __forceinline__ T reduce4(T (&v)[4]) {
   swap_halves(v[0], v[1]);
   swap_halves(v[2], v[3]);
@@ -646,6 +673,26 @@ template <class T> __device__ __forceinline__ T reduce4(T (&v)[4]) {
   T u = w0 + w1;
   u = u + dpp_of<kDppRor8>((T)0, u);
   return sum_of_8_lanes(u);
+}
+// Two values per lane (a target's x and y terms) -> the 64-lane total of x in lanes 16-31, of y in lanes 48-63: one swap of
+// halves, four DPP adds inside the rows, one row broadcast (lane 15 of rows 0 and 2 into rows 1 and 3).
+constexpr int kDppRowBcast15 = 0x142;
+template <class T> __device__ __forceinline__ T row_bcast15_odd_rows(T v) {  // rows 1 and 3: lane 15 of the row before; rows 0 and 2: zero
+  if constexpr (sizeof(T) == 4) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), kDppRowBcast15, 0xa, 0xf, false));
+  } else {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, kDppRowBcast15, 0xa, 0xf, false);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), kDppRowBcast15, 0xa, 0xf, false);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+  }
+}
+template <class T> __device__ __forceinline__ T reduce2(T x, T y) {
+  swap_halves(x, y);
+  T s = x + y;  // lanes 0-31: x.lo + x.hi, lanes 32-63: y.lo + y.hi
+  s = s + dpp_of<kDppRor8>((T)0, s);
+  s = sum_of_8_lanes(s);
+  return s + row_bcast15_odd_rows(s);
 }
 template <class T> __device__ __forceinline__ T lane_fetch(T v, int src_lane) {  // v of lane src_lane (per-lane index)
   if constexpr (sizeof(T) == 4) {
@@ -675,29 +722,36 @@ __device__ __forceinline__ double fast_scale(double dx, double dy, double force,
 __device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
 
-template <class T>
+template <class T, int REC, bool LOG>  // REC: how the node records are fetched (0 plain loads: the compiler picks scalar loads; 1 vector loads); LOG: per-wave log (development)
 __global__ __launch_bounds__(256) void walk_tile_fast(const WalkArgs<T> a, const uint32_t* __restrict__ off, const int* __restrict__ info,
                                                       const uint32_t* __restrict__ tgt_ids, uint32_t* __restrict__ hist,
                                                       unsigned long long* __restrict__ total_out) {
   using T2 = typename Vec2Of<T>::type;
   using T4 = typename Vec4Of<T>::type;
   const int lane = threadIdx.x & 63;
-  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
   if (info[1] != 0) return;  // the estimate's scan wrapped: the caller walks again without one
-  const uint32_t budget = (uint32_t)info[3];
-  int64_t lo = 0, hi = a.n_tgt;
-  while (lo < hi) {  // first t with g(t) >= wave, g(t) = off[t] / budget + t / 64 (see walk_pass)
-    const int64_t mid = (lo + hi) >> 1;
-    if ((int64_t)(off[mid] / budget) + (mid >> 6) < wave) lo = mid + 1; else hi = mid;
+  // Which targets are this wave's: those with g(t) = off[t] / budget + t / 64 == wave (see walk_pass), by two binary searches.
+  // Everything in them is wave-uniform, and kept on the scalar side on purpose: `off` is read through the constant address
+  // space (s_load: it was written by kernels before this one) and the budget is a power of two (tile_total), so the
+  // quotient is a shift — forty dependent steps that cost a wave 125 us as vector loads and a 32-bit division each, on
+  // SIMDs whose vector pipes the other waves keep busy (profiles/r03_walk_wave_log.txt).
+  const int bshift = 31 - __builtin_clz((unsigned)__builtin_amdgcn_readfirstlane(info[3]));
+  const uint32_t __attribute__((address_space(4)))* offc = (const uint32_t __attribute__((address_space(4)))*)off;
+  const int n_tgt = (int)a.n_tgt;  // (the scan, hence the walk, is 32 bits wide)
+  int lo = 0, hi = n_tgt;
+  while (lo < hi) {  // first t with g(t) >= wave
+    const int mid = (int)(((unsigned)lo + (unsigned)hi) >> 1);
+    if ((int)(offc[mid] >> bshift) + (mid >> 6) < wave) lo = mid + 1; else hi = mid;
   }
-  const int64_t t0 = lo;
-  hi = t0 + 64 < a.n_tgt ? t0 + 64 : a.n_tgt;
-  while (lo < hi) {
-    const int64_t mid = (lo + hi) >> 1;
-    if ((int64_t)(off[mid] / budget) + (mid >> 6) <= wave) lo = mid + 1; else hi = mid;
+  const int t0 = lo;
+  hi = t0 + 64 < n_tgt ? t0 + 64 : n_tgt;
+  while (lo < hi) {  // first t with g(t) > wave
+    const int mid = (int)(((unsigned)lo + (unsigned)hi) >> 1);
+    if ((int)(offc[mid] >> bshift) + (mid >> 6) <= wave) lo = mid + 1; else hi = mid;
   }
   if (lo == t0) return;
-  const int64_t t = t0 + lane;
+  const int64_t t = (int64_t)t0 + lane;
   const bool live = t < lo;
   const int64_t row = live ? (a.tgt_index ? (int64_t)a.tgt_index[t] : t) : 0;
   const T2 p = live ? reinterpret_cast<const T2*>(a.tgt_pos)[row] : T2{0, 0};
@@ -712,27 +766,44 @@ __global__ __launch_bounds__(256) void walk_tile_fast(const WalkArgs<T> a, const
   uint32_t n_terms = 0;
   T ax = 0, ay = 0;
   int i = 0;
-  while (i < n_nodes) {  // i is wave-uniform
-    const int4 l = lk[i];
-    const T4 b = g0[i];
-    const T4 c = g1[i];
-    asm volatile("" : : "s"(b.x), "s"(c.w));  // the three records together: one latency per step
-    const bool act = resume <= i;
-    int next;
-    if (l.w) {  // Leaf arm, main.rs:351-363: every particle of the slice (any order of additions: tolerance contract)
-      const unsigned long long mask = __builtin_amdgcn_ballot_w64(act);
-      if (mask) {
+  const long long log_t0 = LOG ? wall_clock64() : 0;
+  unsigned log_nodes = 0, log_leaves = 0, log_rounds = 0;
+  // A node's three records (link, box, centre of gravity | mass | s^2), fetched together: one latency per step.  REC = 1
+  // fetches them by VECTOR loads of one address (the offset passes through a register the compiler cannot see through, or
+  // it would pick scalar loads): the records then sit in VGPRs, where the node test's operands cost half of what SGPR
+  // operands cost (measured cost model).  Measured equal within 2 % (profiles/r03_walk_fast_variants.txt);
+  // fetching one node AHEAD into a second register set made both scenes 12-15 % slower (the compiler copies the set at the
+  // loop's back edge behind a full wait).
+  struct Rec { int4 l; T4 b; T4 c; };
+  const int last = n_nodes - 1;
+  unsigned lane_zero;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(lane_zero));
+  auto fetch = [&](int k) -> Rec {
+    k = k < last ? k : last;
+    if constexpr (REC == 0) return Rec{lk[k], g0[k], g1[k]};
+    const unsigned o16 = (unsigned)k * 16u + lane_zero;
+    const unsigned ot = (unsigned)k * (unsigned)sizeof(T4) + lane_zero;
+    return Rec{*reinterpret_cast<const int4*>(reinterpret_cast<const char*>(lk) + o16), *reinterpret_cast<const T4*>(reinterpret_cast<const char*>(g0) + ot),
+               *reinterpret_cast<const T4*>(reinterpret_cast<const char*>(g1) + ot)};
+  };
+  // The particles [first, first + count) for the lanes of `mask` (`taker`: this lane is one of them), main.rs:351-363;
+  // any order of additions (tolerance contract).
+  auto rounds = [&](const unsigned long long mask, const bool taker, const int first, const int count) {
+    {
+      {
+        const bool act = taker;
         const int takers = __builtin_popcountll(mask);
+        if constexpr (LOG) { ++log_leaves; log_rounds += (unsigned)takers; }
         const int rank = act ? (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u)) : -1;
-        for (int k0 = 0; k0 < l.z; k0 += 64) {  // 64 particles at a time
+        for (int k0 = 0; k0 < count; k0 += 64) {  // 64 particles at a time
           const int mine = k0 + lane;
-          const int left = l.z - k0;
+          const int left = count - k0;
           const int mc = left < 64 ? left : 64;
           T2 q = T2{0, 0};
-          T m = 0;  // a lane past the leaf's end: force 0, its terms are exact zeros
-          if (mine < l.z) {
-            q = lpos[l.y + mine];
-            m = lmass[l.y + mine];
+          T m = 0;  // a lane past the end: force 0, its terms are exact zeros
+          if (mine < count) {
+            q = lpos[first + mine];
+            m = lmass[first + mine];
           }
           if (takers * kFastRoundCost > mc * kFastPairCost) {  // most of the wave wants this leaf: lane = target
             for (int j = 0; j < mc; ++j) {
@@ -748,64 +819,84 @@ __global__ __launch_bounds__(256) void walk_tile_fast(const WalkArgs<T> a, const
           }
           unsigned long long todo = mask;
           int batch0 = 0;
+          // one acting target's terms against the 64 particles, lane = particle
+#define NB_FAST_ROUND(XV, YV)                                             \
+  {                                                                       \
+    const int tl = __builtin_ctzll(todo);                                 \
+    todo &= todo - 1;                                                     \
+    const T dx = q.x - lane_t(p.x, tl), dy = q.y - lane_t(p.y, tl);       \
+    const T sc = fast_scale(dx, dy, m, clamp);                            \
+    XV = dx * sc;                                                         \
+    YV = dy * sc;                                                         \
+  }
           while (todo) {
             const int left_t = takers - batch0;
-            if (left_t > 4) {  // eight targets per batch (missing ones contribute zeros)
+            const int k = rank - batch0;  // this lane's place in the batch, if it is an acting target
+            T gx, gy;
+            int took;
+            if (left_t > 4) {  // eight targets (missing ones contribute zeros): x and y reduced side by side
               T X[8], Y[8];
 #pragma unroll
               for (int sl = 0; sl < 8; ++sl) {
-                if (todo) {
-                  const int tl = __builtin_ctzll(todo);
-                  todo &= todo - 1;
-                  const T dx = q.x - lane_t(p.x, tl), dy = q.y - lane_t(p.y, tl);
-                  const T sc = fast_scale(dx, dy, m, clamp);
-                  X[sl] = dx * sc;
-                  Y[sl] = dy * sc;
-                } else {
-                  X[sl] = 0;
-                  Y[sl] = 0;
-                }
+                X[sl] = 0;
+                Y[sl] = 0;
+                if (todo) NB_FAST_ROUND(X[sl], Y[sl])
               }
               const T rx = reduce8(X), ry = reduce8(Y);
-              const int k = rank - batch0;
-              const bool got = k >= 0 && k < 8;
-              const int src = got ? slot_lane8(k) : lane;
-              const T gx = lane_fetch(rx, src), gy = lane_fetch(ry, src);
-              if (got) {
-                ax = ax + gx;
-                ay = ay + gy;
-              }
-              batch0 += 8;
-            } else {
-              T X[4], Y[4];
+              const int src = slot_lane8(k & 7);
+              gx = lane_fetch(rx, src);
+              gy = lane_fetch(ry, src);
+              took = 8;
+            } else if (left_t > 2) {  // three or four targets: their x and y are the eight values of ONE reduction
+              T V[8];
 #pragma unroll
               for (int sl = 0; sl < 4; ++sl) {
-                if (todo) {
-                  const int tl = __builtin_ctzll(todo);
-                  todo &= todo - 1;
-                  const T dx = q.x - lane_t(p.x, tl), dy = q.y - lane_t(p.y, tl);
-                  const T sc = fast_scale(dx, dy, m, clamp);
-                  X[sl] = dx * sc;
-                  Y[sl] = dy * sc;
-                } else {
-                  X[sl] = 0;
-                  Y[sl] = 0;
-                }
+                V[2 * sl] = 0;
+                V[2 * sl + 1] = 0;
+                if (todo) NB_FAST_ROUND(V[2 * sl], V[2 * sl + 1])
               }
-              const T rx = reduce4(X), ry = reduce4(Y);
-              const int k = rank - batch0;
-              const bool got = k >= 0 && k < 4;
-              const int src = got ? slot_lane4(k) : lane;
-              const T gx = lane_fetch(rx, src), gy = lane_fetch(ry, src);
-              if (got) {
-                ax = ax + gx;
-                ay = ay + gy;
-              }
-              batch0 += 4;
+              const T r = reduce8(V);
+              const int src = 16 * (k & 1) + 8 * ((k >> 1) & 1);  // slot_lane8(2k); y sits 32 lanes on (slot_lane8(2k + 1))
+              gx = lane_fetch(r, src);
+              gy = lane_fetch(r, src + 32);
+              took = 4;
+            } else if (left_t == 2) {  // two targets: four values
+              T V[4];
+              NB_FAST_ROUND(V[0], V[1])
+              NB_FAST_ROUND(V[2], V[3])
+              const T r = reduce4(V);  // x0 row 0, y0 row 2, x1 row 1, y1 row 3
+              const int src = 16 * (k & 1);
+              gx = lane_fetch(r, src);
+              gy = lane_fetch(r, src + 32);
+              took = 2;
+            } else {  // one target
+              T x, y;
+              NB_FAST_ROUND(x, y)
+              const T r = reduce2(x, y);
+              gx = lane_t(r, 16);
+              gy = lane_t(r, 48);
+              took = 1;
             }
+            if (k >= 0 && k < took) {
+              ax = ax + gx;
+              ay = ay + gy;
+            }
+            batch0 += took;
           }
+#undef NB_FAST_ROUND
         }
       }
+    }
+  };
+  auto step = [&](const Rec& rec, const int i) -> int {
+    const int4 l = rec.l;
+    const T4 b = rec.b;
+    const T4 c = rec.c;
+    const bool act = resume <= i;
+    int next;
+    if (l.w) {  // Leaf arm
+      const unsigned long long mask = __builtin_amdgcn_ballot_w64(act);
+      if (mask) rounds(mask, act, l.y, l.z);
       if (act) {
         n_terms += (uint32_t)l.z;
         resume = l.x;
@@ -813,6 +904,7 @@ __global__ __launch_bounds__(256) void walk_tile_fast(const WalkArgs<T> a, const
       next = l.x;
     } else {
       bool descend = false;
+      if constexpr (LOG) ++log_nodes;
       if (act) {
         const bool contains = p.y > b.y && p.x > b.x && p.x < b.z && p.y < b.w;  // bvh_tree.rs:15-20 (all strict)
         const T ddx = p.x - c.x, ddy = p.y - c.y;                              // dist2(p, cog), main.rs:228-232
@@ -829,9 +921,27 @@ __global__ __launch_bounds__(256) void walk_tile_fast(const WalkArgs<T> a, const
           resume = i + 1;
         }
       }
-      next = __builtin_amdgcn_ballot_w64(descend) != 0 ? i + 1 : l.x;
+      const unsigned long long dmask = __builtin_amdgcn_ballot_w64(descend);
+      if (l.x - i == 3) {
+        // A subtree of three nodes: both children are leaves, and a lane that descends here takes both, whole — their
+        // particles are this node's own range [first, first + count) (a node's record carries its range too).  So the two
+        // leaf steps happen HERE: two records and one round trip for the particles fewer per pair of leaves, which is most of
+        // what a wave waits for (the records of three leaves in four are never fetched).  Same pairs, same lanes.
+        if (dmask) rounds(dmask, descend, l.y, l.z);
+        if (descend) {
+          n_terms += (uint32_t)l.z;
+          resume = l.x;
+        }
+        next = l.x;
+      } else {
+        next = dmask != 0 ? i + 1 : l.x;
+      }
     }
-    i = __builtin_amdgcn_readfirstlane(next);
+    return __builtin_amdgcn_readfirstlane(next);
+  };
+  while (i < n_nodes) {
+    const Rec r = fetch(i);
+    i = step(r, i);
   }
   if (live) {
     reinterpret_cast<T2*>(a.acc)[row] = T2{ax, ay};
@@ -841,6 +951,13 @@ __global__ __launch_bounds__(256) void walk_tile_fast(const WalkArgs<T> a, const
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) sum += (unsigned long long)__shfl_xor((long long)sum, d, 64);
   if (lane == 0) atomicAdd(total_out, sum);
+  if (LOG && lane == 0) {
+    unsigned long long* o = a.wave_log + 4 * wave;
+    o[0] = (unsigned long long)(wall_clock64() - log_t0);
+    o[1] = log_nodes;
+    o[2] = log_leaves;
+    o[3] = ((unsigned long long)(unsigned)(lo - t0) << 32) | log_rounds;
+  }
 }
 
 struct EstimateOf {  // target t's terms in the last walk, scaled
@@ -1080,9 +1197,9 @@ hipError_t launch_tree_walk_tile_prep(hipStream_t s, const WalkArgs<T>& a, char*
 }
 
 template <class T>
-hipError_t launch_tree_walk_tile_main(hipStream_t s, const WalkArgs<T>& a, char* scratch, const WalkSplitLayout& L, const uint32_t* tgt_ids,
+hipError_t launch_tree_walk_tile_main(hipStream_t s, const WalkArgs<T>& a_in, char* scratch, const WalkSplitLayout& L, const uint32_t* tgt_ids,
                                       uint32_t* hist, int64_t grid_waves) {
-  if (a.n_tgt <= 0 || grid_waves <= 0) return hipSuccess;
+  if (a_in.n_tgt <= 0 || grid_waves <= 0) return hipSuccess;
   const uint32_t* off = (const uint32_t*)(scratch + L.off);
   int* info = (int*)(scratch + L.info);
   unsigned long long* total_out = (unsigned long long*)(info + 6);
@@ -1090,10 +1207,35 @@ hipError_t launch_tree_walk_tile_main(hipStream_t s, const WalkArgs<T>& a, char*
   const dim3 grid((unsigned)((grid_waves + 3) / 4));
 #define NB_TILE(F, R) walk_tile<T, F, R><<<grid, dim3(256), 0, s>>>(a, off, info, tgt_ids, hist, total_out)
   static const bool fast_rows = getenv("NBODY_WALK_FAST_ROWS") && atoi(getenv("NBODY_WALK_FAST_ROWS")) != 0;  // the round-2 FAST arm (rows + ordered adds), for A/B runs
-  if (a.fast && !fast_rows) walk_tile_fast<T><<<grid, dim3(256), 0, s>>>(a, off, info, tgt_ids, hist, total_out);
+  unsigned long long* wave_log = nullptr;
+  WalkArgs<T> a_log = a_in;
+  if (a_in.fast && getenv("NBODY_WALK_WAVE_LOG") && atoi(getenv("NBODY_WALK_WAVE_LOG")) != 0) {  // development: per-wave time and step counts
+    if (hipMalloc((void**)&wave_log, (size_t)grid.x * 4 * 4 * sizeof(unsigned long long)) != hipSuccess) return hipErrorOutOfMemory;
+    (void)hipMemsetAsync(wave_log, 0, (size_t)grid.x * 4 * 4 * sizeof(unsigned long long), s);
+    a_log.wave_log = wave_log;
+  }
+  const WalkArgs<T>& a = a_log;
+  static const int rec_mode = getenv("NBODY_WALK_FAST_REC") ? atoi(getenv("NBODY_WALK_FAST_REC")) : 0;
+  if (a.fast && !fast_rows) {
+    if (wave_log) walk_tile_fast<T, 0, true><<<grid, dim3(256), 0, s>>>(a, off, info, tgt_ids, hist, total_out);
+    else if (rec_mode == 1) walk_tile_fast<T, 1, false><<<grid, dim3(256), 0, s>>>(a, off, info, tgt_ids, hist, total_out);
+    else walk_tile_fast<T, 0, false><<<grid, dim3(256), 0, s>>>(a, off, info, tgt_ids, hist, total_out);
+  }
   else if (a.fast) { if (tt == 16) NB_TILE(true, 16); else if (tt == 4) NB_TILE(true, 4); else NB_TILE(true, 8); }
   else { if (tt == 16) NB_TILE(false, 16); else if (tt == 4) NB_TILE(false, 4); else NB_TILE(false, 8); }
 #undef NB_TILE
+  if (wave_log) {
+    const size_t nw = (size_t)grid.x * 4;
+    std::vector<unsigned long long> h(nw * 4);
+    (void)hipMemcpyAsync(h.data(), wave_log, nw * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s);
+    (void)hipStreamSynchronize(s);
+    (void)hipFree(wave_log);
+    FILE* f = fopen(getenv("NBODY_WALK_WAVE_LOG_FILE") ? getenv("NBODY_WALK_WAVE_LOG_FILE") : "/tmp/nbody_wave_log.bin", "wb");
+    if (f) {
+      fwrite(h.data(), sizeof(unsigned long long), h.size(), f);
+      fclose(f);
+    }
+  }
   return hipGetLastError();
 }
 

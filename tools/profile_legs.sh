@@ -1,14 +1,14 @@
 #!/bin/bash
 # rocprofv3 passes of bench.py's headline and legs (run on the GPU box from the repo root):
-#   tools/profile_legs.sh <leg: headline|config2|per_body_masses|reference_scene_direct|config4> <kernel regex> <out json>
-# writes gpurun_out/prof_r02/<leg>/{stats,pmc1,pmc2,pmc3} and the summary json; the --stats csv is copied beside it.
+#   tools/profile_legs.sh <leg: headline | any name of bench.py LEGS> <kernel regex> <out json>
+# writes gpurun_out/prof_r03/<leg>/{stats,pmc1,pmc2,pmc3} and the summary json; the --stats csv is copied beside it.
 set -o pipefail
 leg=$1; rx=$2; out=$3
 root=$PWD
-d=$root/gpurun_out/prof_r02/$leg
+d=$root/gpurun_out/prof_r03/$leg
 mkdir -p $d
 cd /tmp && export TMPDIR=/tmp && cd $root
-if [ "$leg" = headline ]; then cmd="bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-legs"; else cmd="bench.py --leg $leg"; fi
+if [ "$leg" = headline ]; then cmd="bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-legs"; else cmd="bench.py --leg $leg --no-cpu-baseline"; fi
 rocprofv3 --kernel-trace --stats --output-format csv -d $d/stats -o p -- python3 $cmd > $d/stats.log 2>&1 || { tail -5 $d/stats.log; exit 1; }
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $d/pmc1 -o p -- python3 $cmd > $d/pmc1.log 2>&1 || { tail -5 $d/pmc1.log; exit 1; }
 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $d/pmc2 -o p -- python3 $cmd > $d/pmc2.log 2>&1 || { tail -5 $d/pmc2.log; exit 1; }

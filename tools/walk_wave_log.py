@@ -1,0 +1,35 @@
+"""NBODY_WALK_WAVE_LOG=1: per-wave clock ticks (100 MHz) and step counts of the FAST one-pass BVH walk (walk_tile_fast).
+    python tools/walk_wave_log.py [galaxy|plummer]"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["NBODY_WALK_WAVE_LOG"] = "1"
+os.environ["NBODY_STEP_AHEAD"] = "0"
+import nbody_simulation_amd as nb
+C = nb._capi
+scene = sys.argv[1] if len(sys.argv) > 1 else "galaxy"
+pos, vel, w = nb.scenes.galaxy() if scene == "galaxy" else nb.scenes.plummer(1 << 20, seed=0x5EED0003)
+with C.Context(0) as ctx:
+    ctx.set_params(theta=50.0, order=C.ORDER_AS_WRITTEN, arith=C.ARITH_FAST)
+    ctx.upload(pos, vel, w)
+    t = C.Timer()
+    ctx.update_tree(C.TREE_BVH, 0.1, 2)
+    ctx.set_timer(t)
+    ctx.update_tree(C.TREE_BVH, 0.1, 1)
+    ms, _ = t.read()
+log = np.fromfile("/tmp/nbody_wave_log.bin", dtype=np.uint64).reshape(-1, 4)
+us = log[:, 0] * 0.01
+nodes, leaves = log[:, 1].astype(np.int64), log[:, 2].astype(np.int64)
+targets, rounds = (log[:, 3] >> np.uint64(32)).astype(np.int64), (log[:, 3] & np.uint64(0xFFFFFFFF)).astype(np.int64)
+live = targets > 0
+print(f"{scene}: walk kernel {ms:.3f} ms (with the log's overhead); {live.sum()} of {len(us)} waves have targets")
+print(f"per live wave: {us[live].mean():.1f} us mean, {np.percentile(us[live], 99):.1f} p99, {us[live].max():.1f} max; steps {nodes[live].mean():.0f} node + "
+      f"{leaves[live].mean():.0f} leaf, {rounds[live].mean():.0f} rounds, {targets[live].mean():.1f} targets")
+steps = nodes + leaves
+ok = live & (steps > 0)
+print(f"us per step (node + leaf): mean {(us[ok] / steps[ok]).mean():.2f}; sum of wave times {us[live].sum() / 1e3:.1f} ms")
+A = np.stack([nodes[ok], leaves[ok], rounds[ok], np.ones(ok.sum())], axis=1).astype(np.float64)
+coef, *_ = np.linalg.lstsq(A, us[ok], rcond=None)
+print("least squares: %.3f us per node step + %.3f us per leaf step + %.3f us per round + %.1f us per wave" % tuple(coef))
+for k in np.argsort(-us)[:8]:
+    print(f"  wave {k}: {us[k]:.1f} us, {targets[k]} targets, {nodes[k]} node steps, {leaves[k]} leaf steps, {rounds[k]} rounds")
