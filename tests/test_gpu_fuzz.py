@@ -1,0 +1,112 @@
+"""A bounded, fixed-seed subset of tools/bvh_fuzz.py / tools/quad_fuzz.py inside the driver-run suite, against the ORACLE
+(tools/*_fuzz.py compare the device builds with the product's own host builders over much larger sizes; here the checker is
+the CPU restatement of bvh_tree.rs:56-158 / quad_tree.rs:153-270).  Needs an MI355X.
+
+Every case: a random size (1 ... 2e5), leaf size and distribution; the device-built tree equals the oracle's node for node
+(ranges, skip links, u32 masses, boxes and centres of gravity bit for bit, NaN for empty leaves) and so does the row
+permutation; then two whole steps equal the oracle's World::update, row for row."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+F32 = np.float32
+
+
+def _scene(rng, kind, n, dtype, nb):
+    if kind == 0:
+        return (rng.random((n, 2)) * 1e5).astype(dtype)
+    if kind == 1:
+        return (rng.standard_normal((n, 2)) * 3e4).astype(dtype)          # both signs: sums wander through zero
+    if kind == 2:
+        return (-rng.random((n, 2)) * 1e5).astype(dtype)                   # all negative: the max fold starts from 0.0
+    if kind == 3:
+        return (10.0 ** rng.uniform(-6, 6, (n, 2))).astype(dtype)          # twelve decades
+    if kind == 4:
+        return (rng.integers(0, 3000, (n, 2)) * 0.5).astype(dtype)         # half-integer lattice: ties, coincident points
+    return nb.scenes.plummer(n, seed=int(rng.integers(1, 1 << 30)), dtype=dtype)[0]
+
+
+@pytest.fixture(scope="module")
+def ctx(nb):
+    c = nb._capi.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_bvh_builds_equal_the_oracle_on_random_cases(nb, orc, ctx, dtype):
+    C = nb._capi
+    rng = np.random.default_rng(20261004 + (1 if dtype == np.float64 else 0))
+    done = on_device = 0
+    for case in range(16 if dtype == np.float32 else 10):
+        n = int(10 ** rng.uniform(0.0, 5.3))
+        leaf = int(rng.choice([1, 4, 16, 64, 64, 64, 200, 1000]))
+        kind = int(rng.integers(0, 6))
+        if leaf < 16:
+            n = min(n, 30000)
+        pos = _scene(rng, kind, n, dtype, nb)
+        w = rng.integers(1, 9, n).astype(np.uint32)
+        vel = (rng.standard_normal((n, 2)) * 10).astype(dtype)
+        tag = f"case {case}: n {n} leaf {leaf} kind {kind} {np.dtype(dtype).name}"
+        bvh = orc.BVH(pos, w, leaf_size=leaf)
+        o = bvh.flat()
+        if o.overflow:                                                      # > leaf coincident points: the reference recurses without end
+            continue
+        ctx.set_params(theta=50.0, leaf_size=leaf, order=C.ORDER_AS_WRITTEN, arith=C.ARITH_AUTO)
+        ctx.upload(pos, vel, w)
+        ctx.accel_tree(C.TREE_BVH, pos[:1])
+        on_device += int(ctx.last_build_on_device())
+        t = ctx.tree_export()
+        for k in ("mass", "is_leaf", "first", "count", "skip"):
+            assert np.array_equal(t[k], getattr(o, k)), f"{tag}: {k}"
+        assert np.array_equal(t["geom"], o.geom, equal_nan=True), f"{tag}: geom"
+        assert np.array_equal(t["order"], o.ids), f"{tag}: permutation"
+        try:
+            rp, rv, rw, rids, _ = orc.update_bvh(pos, vel, w, delta=0.05, theta=50.0, leaf_size=leaf, mode=orc.AS_WRITTEN, nsteps=2, nthreads=16)
+        except RuntimeError:                                                # points that come to coincide during the steps
+            continue
+        ctx.upload(pos, vel, w)
+        ctx.update_tree(C.TREE_BVH, 0.05, 2)
+        p, v, w2, ids = ctx.download()
+        assert np.array_equal(ids, rids) and np.array_equal(p, rp, equal_nan=True) and np.array_equal(v, rv, equal_nan=True) and np.array_equal(w2, rw), tag
+        done += 1
+    assert done >= 6 and on_device >= done // 2, (done, on_device)
+    ctx.set_params(leaf_size=64)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_quad_builds_equal_the_oracle_on_random_cases(nb, orc, ctx, dtype):
+    C = nb._capi
+    rng = np.random.default_rng(20261005 + (1 if dtype == np.float64 else 0))
+    done = 0
+    for case in range(14 if dtype == np.float32 else 8):
+        n = int(10 ** rng.uniform(0.0, 5.3))
+        kind = int(rng.choice([0, 1, 3, 4, 5, 5]))                          # (kind 1 and 3 put points outside the root cell too)
+        pos = _scene(rng, kind, n, dtype, nb)
+        if kind == 4:
+            pos = pos + dtype(0.25) * rng.integers(0, 3, pos.shape).astype(dtype)   # fewer than nine coincident points per site
+        w = rng.integers(1, 9, n).astype(np.uint32)
+        vel = (rng.standard_normal((n, 2)) * 10).astype(dtype)
+        tag = f"case {case}: n {n} kind {kind} {np.dtype(dtype).name}"
+        quad = orc.Quad(pos, w)
+        o = quad.flat()
+        if o.overflow:
+            continue
+        ctx.set_params(theta=0.7, order=C.ORDER_CONSISTENT, arith=C.ARITH_AUTO)
+        ctx.upload(pos, vel, w)
+        ctx.accel_tree(C.TREE_QUAD, pos[:1])
+        t = ctx.tree_export()
+        for k in ("mass", "is_leaf", "first", "count", "skip"):
+            assert np.array_equal(t[k], getattr(o, k)), f"{tag}: {k}"
+        assert np.array_equal(t["geom"], o.geom, equal_nan=True), f"{tag}: geom"
+        assert np.array_equal(t["order"], o.order), f"{tag}: leaf order"
+        try:
+            rp, rv, _ = orc.update_quad(pos, vel, w, delta=0.05, theta=0.7, nsteps=2, nthreads=16)
+        except RuntimeError:
+            continue
+        ctx.upload(pos, vel, w)
+        ctx.update_tree(C.TREE_QUAD, 0.05, 2)
+        p, v, _, ids = ctx.download()
+        assert np.array_equal(ids, np.arange(n)) and np.array_equal(p, rp, equal_nan=True) and np.array_equal(v, rv, equal_nan=True), tag
+        done += 1
+    assert done >= 5, done
