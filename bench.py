@@ -290,7 +290,8 @@ def run_leg(nb, name, cpu=True):
     if name == "config2":
         pos, vel, w = nb.scenes.plummer(65536, seed=0x5EED0002)
         return _direct_leg(nb, name, "BASELINE.json configs[1]: 65 536 bodies direct O(N^2) f32, Plummer, masses 1", pos, vel, w, 200,
-                           "r03_leg_config2_pmc.json", executed=14, cpu_targets=65536 if cpu else 0)   # the CPU leg is one whole step here
+                           "r03_leg_config2_pmc.json", executed=FLOPS_EXECUTED_PER_PAIR, cpu_targets=65536 if cpu else 0)   # (from 2^32 pairs on the
+                                                                                   # near/far split runs: the same instantiation as the headline; the CPU leg is one whole step)
     if name == "per_body_masses":
         pos, vel, _ = nb.scenes.plummer(N_BODIES, seed=SEED)
         w = (np.arange(N_BODIES) % 5 + 1).astype(np.uint32)

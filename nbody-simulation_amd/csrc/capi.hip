@@ -142,10 +142,11 @@ int env_int(const char* name, int dflt) {
 DirectConfig choose_direct_config(int64_t n_src, int64_t n_tgt, bool uniform = true) {
   DirectConfig c;
   c.use_asm = env_int("NBODY_DIRECT_ASM", 1) != 0;
-  // near/far split: ~0.1-0.3 ms of preparation per step against 10 % of the pair work, break-even measured at
-  // 65536 x 65536 pairs (profiles/r01_small_n_steps.txt).  NBODY_DIRECT_NEARFAR: 0 never, 1 by size (default), 2 always.
+  // near/far split: 0.05 ms (65 536 bodies) to 0.16 ms (1 M) of preparation per step against 10 % of the pair work: it pays
+  // from 65 536 x 65 536 pairs on (profiles/r03_nearfar_hash_grid.txt; the sort-based split of rounds 1-2 broke even at
+  // twice that).  NBODY_DIRECT_NEARFAR: 0 never, 1 by size (default), 2 always.
   const int nf = env_int("NBODY_DIRECT_NEARFAR", 1);
-  c.nearfar = nf == 2 || (nf == 1 && (double)n_src * (double)n_tgt >= 8589934592.0);
+  c.nearfar = nf == 2 || (nf == 1 && (double)n_src * (double)n_tgt >= 4294967296.0);
   // measured at N = 1M (profiles/r01_direct_mass_variants.txt): 1 target/thread with the hand-ordered block wins for
   // equal masses (44.0 %) and for per-body masses (39.8 % vs 36.1 % for 2 targets/thread)
   (void)uniform;

@@ -38,7 +38,7 @@ struct DirectConfig {
 };
 
 struct NearFarLayout {
-  size_t keys0, keys1, idx0, idx1, is_near, scan, near_list, pos_far, cub_temp, cub_temp_bytes, total;
+  size_t table_keys, table_bytes, is_near, scan, near_list, pos_far, cub_temp, cub_temp_bytes, total;
 };
 NearFarLayout nearfar_layout(int64_t n_src);
 // heavy_base > 0: bodies whose mass differs from it join the near list (sparse-heavy scenes; `mass` is then read)

@@ -12,9 +12,15 @@
 //          to +inf, 1/inf = 0, the pair contributes exactly 0) and added by `direct_finish` with the clamp.
 // Only the order of summation changes (near sources last), which FAST arithmetic does not promise anyway.
 //
-// Steps, all on the stream, no host round trip: cell keys -> radix sort (hipCUB) -> neighbour test (own cell: the
-// adjacent sorted entries; (cx, cy+-1): adjacent in key order; (cx+-1, cy-1..cy+1): one binary search each) ->
-// exclusive scan -> compacted ascending index list + far copy of the positions -> decision word.
+// Steps, all on the stream, no host round trip (round 3: a hash grid instead of a sort — the question "is any other body in
+// my 3 x 3 cells" needs no order, and the sort was two thirds of the split's 0.33 ms: hipCUB picks a merge sort for 64-bit keys
+// at these sizes, profiles/r02_direct_kernel_stats.csv):
+//   one memset (the table: every slot empty) -> nf_insert: each body enters its cell in the slot of its 2 x 2 super-cell (open
+//   addressing, atomicCAS on 32-bit slots, linear probing, load factor <= 1/4) -> nf_mark: four lookups per body, their first
+//   probes side by side; near iff the 3 x 3 cells around it hold anyone else -> exclusive scan -> compacted ascending index
+//   list + far copy of the positions -> decision word.
+// Which bodies are near is a function of the positions alone, whatever order the inserts land in; the list is compacted in
+// ascending body index: the step stays bitwise reproducible.
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 #include <stdint.h>
@@ -25,74 +31,110 @@ namespace nbody {
 
 namespace {
 
-constexpr int kCellBias = 1 << 30;  // cell indices are stored biased, valid while |x / h| < 2^30
+constexpr int kCellBias = 1 << 29;  // cell indices are stored biased, valid while |x / h| < 2^29
+// The table holds SUPER-cells of 2 x 2 cells, 32 bits each: a 27-bit fingerprint of the super-cell's coordinates, a "more than
+// one body" bit and four occupancy bits (one per cell).  A body's 3 x 3 cells lie in 2 x 2 super-cells: four lookups instead
+// of nine, in a table an eighth the size of one with 64-bit keys per cell — the lookups are random accesses, and what they
+// cost is the lines they pull through the L2s (191 us for nine 8-byte probes per body at N = 1 M).  Two super-cells whose
+// fingerprints collide in one probe chain are merged: that can only turn a far body into a near one (which is always
+// correct: near bodies are summed with the clamp), deterministically, with probability ~2^-27 per lookup.
+constexpr uint32_t kEmptySlot = ~0u;  // the memset's 0xFF bytes; fingerprints never have all 27 bits set
+constexpr uint32_t kMultiBit = 16u;
 
-__global__ __launch_bounds__(256) void nf_cell_keys(const float2* __restrict__ pos, int n, double inv_h,
-                                                    uint64_t* __restrict__ keys, uint32_t* __restrict__ idx,
-                                                    int* __restrict__ flags) {
-  int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  float2 p = pos[i];
+struct SuperCell {
+  uint32_t slot, fp;
+};
+__device__ __forceinline__ SuperCell super_of(uint32_t sx, uint32_t sy, uint32_t tmask) {
+  uint64_t k = ((uint64_t)sx << 32) | sy;  // splitmix64's finaliser: neighbouring super-cells land far apart
+  k ^= k >> 30;
+  k *= 0xBF58476D1CE4E5B9ull;
+  k ^= k >> 27;
+  k *= 0x94D049BB133111EBull;
+  k ^= k >> 31;
+  uint32_t fp = (uint32_t)(k >> 37);
+  if (fp == 0x7FFFFFFu) fp = 0x7FFFFFEu;
+  return SuperCell{(uint32_t)k & tmask, fp};
+}
+__device__ __forceinline__ bool cell_of(float2 p, double inv_h, uint32_t* cx, uint32_t* cy) {  // false: outside the grid's range (or NaN)
   double fx = floor((double)p.x * inv_h), fy = floor((double)p.y * inv_h);
-  bool bad = !(fx > -(double)kCellBias + 2 && fx < (double)kCellBias - 2 && fy > -(double)kCellBias + 2 &&
-               fy < (double)kCellBias - 2);  // also catches NaN
-  if (bad) {
-    atomicOr(&flags[kFlagFallback], 1);
-    fx = fy = 0;
-  }
-  uint32_t cx = (uint32_t)((long)fx + kCellBias), cy = (uint32_t)((long)fy + kCellBias);
-  keys[i] = ((uint64_t)cx << 32) | cy;
-  idx[i] = (uint32_t)i;
+  const bool ok = fx > -(double)kCellBias + 2 && fx < (double)kCellBias - 2 && fy > -(double)kCellBias + 2 && fy < (double)kCellBias - 2;
+  if (!ok) fx = fy = 0;
+  *cx = (uint32_t)((long)fx + kCellBias);
+  *cy = (uint32_t)((long)fy + kCellBias);
+  return ok;
 }
 
-__device__ __forceinline__ int lower_bound_u64(const uint64_t* __restrict__ a, int n, uint64_t v) {
-  int lo = 0, hi = n;
-  while (lo < hi) {
-    int mid = (lo + hi) >> 1;
-    if (a[mid] < v) lo = mid + 1; else hi = mid;
+// Every body enters its cell's bit in its super-cell's slot; the second body to arrive in a super-cell sets the "multi" bit.
+__global__ __launch_bounds__(256) void nf_insert(const float2* __restrict__ pos, int n, double inv_h, uint32_t* __restrict__ table,
+                                                 uint32_t tmask, int* __restrict__ flags) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  uint32_t cx, cy;
+  if (!cell_of(pos[i], inv_h, &cx, &cy)) atomicOr(&flags[kFlagFallback], 1);
+  const SuperCell sc = super_of(cx >> 1, cy >> 1, tmask);
+  const uint32_t bit = 1u << ((cx & 1) * 2 + (cy & 1));
+  uint32_t h = sc.slot;
+  for (uint32_t probe = 0; probe <= tmask; ++probe) {  // (load factor <= 1/4: a free slot is a probe or two away)
+    const uint32_t old = atomicCAS(&table[h], kEmptySlot, (sc.fp << 5) | bit);
+    if (old == kEmptySlot) return;
+    if ((old >> 5) == sc.fp) {
+      if ((old & (bit | kMultiBit)) != (bit | kMultiBit)) atomicOr(&table[h], bit | kMultiBit);
+      return;
+    }
+    h = (h + 1) & tmask;
   }
-  return lo;
+  atomicOr(&flags[kFlagFallback], 1);  // never expected: the table is larger than the number of bodies
 }
 
 // is_near[i] = 1 when another body shares body i's cell or one of the 8 cells around it.
 // `heavy_base` > 0: a body whose mass differs from it is listed as near too — the main pass then runs with the one mass
 // hoisted out of the sum, and direct_finish adds the few odd bodies with their own masses (the reference's scene: two
 // heavy bodies among 151 000 of weight 1, main.rs:282-291).
-__global__ __launch_bounds__(256) void nf_mark(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ idx,
-                                               int n, const float* __restrict__ mass, float heavy_base,
+__global__ __launch_bounds__(256) void nf_mark(const float2* __restrict__ pos, int n, double inv_h, const uint32_t* __restrict__ table,
+                                               uint32_t tmask, const float* __restrict__ mass, float heavy_base,
                                                uint32_t* __restrict__ is_near) {
-  int r = blockIdx.x * 256 + threadIdx.x;
-  if (r >= n) return;
-  const uint64_t k = keys[r];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  uint32_t cx, cy;
+  (void)cell_of(pos[i], inv_h, &cx, &cy);
+  const uint32_t sx = cx >> 1, sy = cy >> 1;
+  // the 3 x 3 cells around (cx, cy) reach one super-cell further on the side of the body's cell: -1 from an even cell, +1 from an odd one
+  const uint32_t ox = sx + ((cx & 1) ? 1u : ~0u), oy = sy + ((cy & 1) ? 1u : ~0u);
+  // which cells of each of the four super-cells belong to the 3 x 3 block (the body's own cell left out): bit = x parity * 2 + y parity
+  const uint32_t own_bit = 1u << ((cx & 1) * 2 + (cy & 1));
+  const uint32_t far_x = (cx & 1) ? 0u : 1u, far_y = (cy & 1) ? 0u : 1u;  // parity of the one column / row the block has in the other super-cell
+  uint32_t need[4];
+  need[0] = 15u & ~own_bit;                                       // (sx, sy): its other three cells
+  need[1] = (1u << (far_x * 2)) | (1u << (far_x * 2 + 1));        // (ox, sy): one column, both rows
+  need[2] = (1u << far_y) | (1u << (2 + far_y));                  // (sx, oy): one row, both columns
+  need[3] = 1u << (far_x * 2 + far_y);                            // (ox, oy): the corner cell
+  SuperCell sc[4] = {super_of(sx, sy, tmask), super_of(ox, sy, tmask), super_of(sx, oy, tmask), super_of(ox, oy, tmask)};
+  uint32_t got[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) got[c] = table[sc[c].slot];  // the four first probes side by side: one round trip
   bool near = false;
-  // same cell, or (cx, cy-1) / (cx, cy+1): those are the entries next to r in key order
-  if (r > 0) near |= (k - keys[r - 1]) <= 1;
-  if (r + 1 < n) near |= (keys[r + 1] - k) <= 1;
-  if (!near) {
-    // columns cx-1 and cx+1, rows cy-1 .. cy+1: three consecutive keys each
-    const uint64_t col = (uint64_t)1 << 32;
-    uint64_t lo = k - col - 1;
-    int p = lower_bound_u64(keys, n, lo);
-    near |= (p < n && keys[p] <= lo + 2);
-    if (!near) {
-      lo = k + col - 1;
-      p = lower_bound_u64(keys, n, lo);
-      near |= (p < n && keys[p] <= lo + 2);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    uint32_t at = got[c], hh = sc[c].slot;
+    for (uint32_t probe = 0; at != kEmptySlot && (at >> 5) != sc[c].fp && probe <= tmask; ++probe) {
+      hh = (hh + 1) & tmask;
+      at = table[hh];
     }
+    if (at != kEmptySlot) near |= (at & need[c]) != 0 || (c == 0 && (at & kMultiBit) != 0);
   }
-  const uint32_t body = idx[r];
-  if (heavy_base > 0.f) near |= mass[body] != heavy_base;
-  is_near[body] = near ? 1u : 0u;
+  if (heavy_base > 0.f) near |= mass[i] != heavy_base;
+  is_near[i] = near ? 1u : 0u;
 }
 
+// The near list (ascending body index: the near sum has a fixed order) and the far copy of the positions.
 __global__ __launch_bounds__(256) void nf_compact(const float2* __restrict__ pos, const uint32_t* __restrict__ is_near,
                                                   const uint32_t* __restrict__ scan, int n, float2* __restrict__ pos_far,
                                                   uint32_t* __restrict__ near_list) {
-  int i = blockIdx.x * 256 + threadIdx.x;
+  const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   float2 p = pos[i];
   if (is_near[i]) {
-    near_list[scan[i]] = (uint32_t)i;  // ascending body index: the near sum has a fixed order
+    near_list[scan[i]] = (uint32_t)i;
     p = make_float2(1e30f, 1e30f);
   }
   pos_far[i] = p;
@@ -120,20 +162,26 @@ size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 }  // namespace
 
 // Layout of the near/far scratch inside the caller's workspace (all 256-B aligned).
+static uint32_t table_slots(int64_t n_src) {  // a power of two, at least four times the bodies (a probe is an atomic's round trip)
+  uint32_t m = 1024;
+  while ((int64_t)m < 4 * n_src && m < (1u << 31)) m <<= 1;
+  return m;
+}
 NearFarLayout nearfar_layout(int64_t n_src) {
   NearFarLayout L{};
   size_t n = (size_t)(n_src > 0 ? n_src : 1);
+  const size_t slots = table_slots(n_src);
   size_t off = 0;
-  L.keys0 = off; off += align_up(n * 8);
-  L.keys1 = off; off += align_up(n * 8);
-  L.idx0 = off; off += align_up(n * 4);
-  L.idx1 = off; off += align_up(n * 4);
+  L.table_keys = off; off += align_up(slots * 4);
+  L.table_bytes = slots * 4;
   L.is_near = off; off += align_up(n * 4);
   L.scan = off; off += align_up(n * 4);
   L.near_list = off; off += align_up(n * 4);
   L.pos_far = off; off += align_up(n * 8);
   L.cub_temp = off;
-  L.cub_temp_bytes = align_up((size_t)8 << 20);  // radix sort with double buffers + scan need far less
+  size_t need_scan = 0;
+  (void)hipcub::DeviceScan::ExclusiveSum(nullptr, need_scan, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)n, (hipStream_t) nullptr);
+  L.cub_temp_bytes = align_up(need_scan + 256);
   off += L.cub_temp_bytes;
   L.total = off;
   return L;
@@ -142,10 +190,7 @@ NearFarLayout nearfar_layout(int64_t n_src) {
 // Enqueues the split.  On return flags[kFlagState] is (will be) valid on the stream.
 hipError_t launch_nearfar(hipStream_t s, const float2* pos, const float* mass, float heavy_base, int n, float clamp, int use_hazard,
                           int* flags, char* scratch, const NearFarLayout& L, const float2** pos_far, const uint32_t** near_list) {
-  uint64_t* k0 = (uint64_t*)(scratch + L.keys0);
-  uint64_t* k1 = (uint64_t*)(scratch + L.keys1);
-  uint32_t* i0 = (uint32_t*)(scratch + L.idx0);
-  uint32_t* i1 = (uint32_t*)(scratch + L.idx1);
+  uint32_t* table = (uint32_t*)(scratch + L.table_keys);
   uint32_t* is_near = (uint32_t*)(scratch + L.is_near);
   uint32_t* scan = (uint32_t*)(scratch + L.scan);
   uint32_t* list = (uint32_t*)(scratch + L.near_list);
@@ -154,34 +199,17 @@ hipError_t launch_nearfar(hipStream_t s, const float2* pos, const float* mass, f
   *near_list = list;
   const double h = sqrt((double)clamp) * 1.001;  // pitch strictly above sqrt(clamp), margin >> f32 rounding of d2
   const unsigned blocks = (unsigned)((n + 255) / 256);
-  hipLaunchKernelGGL(nf_cell_keys, dim3(blocks), dim3(256), 0, s, pos, n, 1.0 / h, k0, i0, flags);
-  hipError_t e = hipGetLastError();
+  const uint32_t tmask = table_slots(n) - 1;
+  hipError_t e = hipMemsetAsync(table, 0xFF, L.table_bytes, s);
   if (e != hipSuccess) return e;
-  hipcub::DoubleBuffer<uint64_t> dk(k0, k1);
-  hipcub::DoubleBuffer<uint32_t> dv(i0, i1);
-  size_t need = 0;
-  e = hipcub::DeviceRadixSort::SortPairs(nullptr, need, dk, dv, n, 0, 64, s);
-  if (e != hipSuccess) return e;
-  size_t need_scan = 0;
-  e = hipcub::DeviceScan::ExclusiveSum(nullptr, need_scan, is_near, scan, n, s);
-  if (e != hipSuccess) return e;
-  if (need > L.cub_temp_bytes || need_scan > L.cub_temp_bytes) {
-    // never expected; stay correct by taking the single clamped pass
-    hipLaunchKernelGGL(nf_decide_simple, dim3(1), dim3(1), 0, s, use_hazard, flags);
-    return hipGetLastError();
-  }
-  size_t tb = L.cub_temp_bytes;
-  e = hipcub::DeviceRadixSort::SortPairs(scratch + L.cub_temp, tb, dk, dv, n, 0, 64, s);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(nf_mark, dim3(blocks), dim3(256), 0, s, dk.Current(), dv.Current(), n, mass, heavy_base, is_near);
+  hipLaunchKernelGGL(nf_insert, dim3(blocks), dim3(256), 0, s, pos, n, 1.0 / h, table, tmask, flags);
+  hipLaunchKernelGGL(nf_mark, dim3(blocks), dim3(256), 0, s, pos, n, 1.0 / h, (const uint32_t*)table, tmask, mass, heavy_base, is_near);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
-  tb = L.cub_temp_bytes;
+  size_t tb = L.cub_temp_bytes;
   e = hipcub::DeviceScan::ExclusiveSum(scratch + L.cub_temp, tb, is_near, scan, n, s);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(nf_compact, dim3(blocks), dim3(256), 0, s, pos, is_near, scan, n, far, list);
-  e = hipGetLastError();
-  if (e != hipSuccess) return e;
   hipLaunchKernelGGL(nf_decide, dim3(1), dim3(1), 0, s, is_near, scan, n, n / 64, use_hazard, flags);
   return hipGetLastError();
 }
