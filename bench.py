@@ -295,8 +295,9 @@ def run_leg(nb, name, cpu=True):
     if name == "per_body_masses":
         pos, vel, _ = nb.scenes.plummer(N_BODIES, seed=SEED)
         w = (np.arange(N_BODIES) % 5 + 1).astype(np.uint32)
-        return _direct_leg(nb, name, "1 048 576 bodies direct f32, Plummer, per-body masses 1..5", pos, vel, w, 3,
-                           "r03_leg_per_body_masses_pmc.json", executed=14, cpu_targets=16384 if cpu else 0)
+        return _direct_leg(nb, name, "1 048 576 bodies direct f32, Plummer, per-body masses 1..5 (five mass classes: sources in class order, "
+                                     "the equal-mass kernel tile by tile)", pos, vel, w, 3,
+                           "r03_leg_per_body_masses_pmc.json", executed=FLOPS_EXECUTED_PER_PAIR, cpu_targets=16384 if cpu else 0)
     if name == "reference_scene_direct":
         pos, vel, w = nb.scenes.galaxy()
         return _direct_leg(nb, name, f"the reference's own scene (World::new, main.rs:276-346, seeded): {pos.shape[0]} bodies, masses 1 but for "

@@ -222,7 +222,10 @@ int nbody_get_counting(const nbody_ctx* ctx, nbody_counting* out);
  *                                 -uniform_mass except a sparse set (at most n/256 bodies: the reference's scene has two
  *                                 heavy bodies among 151 000 of weight 1, main.rs:282-291) — those are found on the
  *                                 device each step and added with their own masses after the equal-mass main pass;
- *                                 0 when masses differ freely or are unknown
+ *                                 0 when masses differ freely or are unknown.  (A context — nbody_upload_* + nbody_update_direct_f32,
+ *                                 single- or multi-GPU — goes further by itself: masses that take at most 32 distinct values
+ *                                 are handled as mass classes at the equal-mass rate; this device-pointer call has no
+ *                                 place to keep the class order and runs the per-body-mass kernel for them.)
  *   vel       float2[n_targets]   this shard's velocities, updated in place
  *   pos_out   float2[n_targets]   this shard's new positions (must not alias pos_all)
  *   acc_out   float2[n_targets]   or NULL

@@ -123,6 +123,8 @@ template <class T> void free_state(State<T>& s) {
   s.tree_host_stale = false; s.n_nodes = 0;
   s.node_cap = 0; s.n = 0; s.tree_valid = false; s.tree.clear();
   s.h_pos.clear(); s.h_weight.clear();
+  free_dev(s.classes.rank); free_dev(s.classes.pad_slots); free_dev(s.classes.tile_mass);
+  s.classes = typename State<T>::MassClasses{};
 }
 
 template <class T> State<T>& state_of(nbody_ctx* c);
@@ -189,6 +191,89 @@ size_t direct_ws_bytes(int64_t n_src, int64_t n_tgt) {
   return kFlagBytes + direct_partial_bytes(n_src, n_tgt) + nearfar_layout(n_src).total;
 }
 
+// Mass classes of the context's f32 rows in their current order (ctx.h, State::MassClasses): built on the host from the
+// weights (static between uploads; only the row order moves, with the tree builds), cached until the rows are permuted.
+// Classes are taken in ascending weight, bodies inside a class in ascending row: everything downstream stays a function
+// of the inputs alone (bitwise reproducible).  Not used for equal masses, for "one mass but for a few bodies" (the near
+// list carries those) or for more than 32 distinct masses (the per-body kernel runs then).
+int ensure_mass_classes(nbody_ctx* c) {
+  State<float>& s = c->sf;
+  auto& mc = s.classes;
+  if (mc.epoch == s.row_epoch) return NBODY_OK;
+  mc.epoch = s.row_epoch;
+  mc.usable = false;
+  const int64_t n = s.n;
+  if (env_int("NBODY_DIRECT_NO_CLASSES", 0) != 0 || s.uniform_mass > 0.f || s.sparse_base > 0.f || n < 32768) return NBODY_OK;
+  if (s.h_weight_stale) {
+    s.h_weight.resize((size_t)n);
+    HIPCHK(c, hipMemcpyAsync(s.h_weight.data(), s.set[s.cur].weight, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    s.h_weight_stale = false;
+  }
+  uint32_t vals[kMaxMassClasses];
+  int64_t counts[kMaxMassClasses];
+  int k = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    const uint32_t w = s.h_weight[(size_t)i];
+    int j = 0;
+    while (j < k && vals[j] != w) ++j;
+    if (j == k) {
+      if (k == (int)kMaxMassClasses) return NBODY_OK;  // too many distinct masses
+      vals[k] = w;
+      counts[k] = 0;
+      ++k;
+    }
+    ++counts[j];
+  }
+  if (k < 2) return NBODY_OK;
+  int order[kMaxMassClasses];
+  for (int j = 0; j < k; ++j) order[j] = j;
+  std::sort(order, order + k, [&](int a, int b) { return vals[a] < vals[b]; });
+  int64_t start[kMaxMassClasses], fill[kMaxMassClasses];
+  int64_t slots = 0;
+  std::vector<float> tile_mass;
+  std::vector<uint32_t> pads;
+  for (int r = 0; r < k; ++r) {
+    const int j = order[r];
+    start[j] = slots;
+    fill[j] = 0;
+    const int64_t padded = (counts[j] + kDirectTile - 1) / kDirectTile * kDirectTile;
+    for (int64_t t = 0; t < padded / kDirectTile; ++t) tile_mass.push_back((float)vals[j]);  // `weight as f32`, main.rs:360
+    for (int64_t q = slots + counts[j]; q < slots + padded; ++q) pads.push_back((uint32_t)q);
+    slots += padded;
+  }
+  std::vector<uint32_t> rank((size_t)n);
+  for (int64_t i = 0; i < n; ++i) {
+    const uint32_t w = s.h_weight[(size_t)i];
+    int j = 0;
+    while (vals[j] != w) ++j;
+    rank[(size_t)i] = (uint32_t)(start[j] + fill[j]++);
+  }
+  free_dev(mc.rank); free_dev(mc.pad_slots); free_dev(mc.tile_mass);
+  HIPCHK(c, hipMalloc((void**)&mc.rank, (size_t)n * 4));
+  HIPCHK(c, hipMalloc((void**)&mc.pad_slots, (pads.size() + 1) * 4));
+  HIPCHK(c, hipMalloc((void**)&mc.tile_mass, (tile_mass.size() + 1) * 4));
+  HIPCHK(c, hipMemcpyAsync(mc.rank, rank.data(), (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+  if (!pads.empty()) HIPCHK(c, hipMemcpyAsync(mc.pad_slots, pads.data(), pads.size() * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(mc.tile_mass, tile_mass.data(), tile_mass.size() * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  mc.n_classes = k;
+  mc.n_slots = slots;
+  mc.n_pad_slots = (int)pads.size();
+  mc.usable = true;
+  if (env_int("NBODY_TRACE", 0) != 0)
+    std::fprintf(stderr, "[nbody] direct: %d mass classes, %lld bodies in %lld slots\n", k, (long long)n, (long long)slots);
+  return NBODY_OK;
+}
+// the classes of `c` if they describe exactly these sources in their current row order
+const State<float>::MassClasses* classes_for(const nbody_ctx* c, int64_t n_src, const void* mass_all) {
+  if (!c || !c->has_f32) return nullptr;
+  const State<float>& s = c->sf;
+  const auto& mc = s.classes;
+  if (!mc.usable || mc.epoch != s.row_epoch || n_src != s.n || mass_all != (const void*)s.set[s.cur].mass) return nullptr;
+  return &mc;
+}
+
 // A direct step = one preparation over ALL positions (hazard scan, near/far split, the decision word) followed by one
 // or more runs, each over a block of targets.  `n_tgt_total` (all targets this device computes in the step) decides
 // whether the near/far split pays; `n_tgt_max` (the largest block of one run) sizes the partial-sum area, so that
@@ -197,12 +282,13 @@ struct DirectPlan {
   int arith = 0;
   bool uni = false;
   float sparse_base = 0.f;  // > 0: all masses equal this but a few bodies', which travel with the near list
+  const State<float>::MassClasses* classes = nullptr;  // masses in a few classes: the far copy in class order, equal-mass arithmetic per tile
   bool nearfar = false;
   int use_hazard = 0;
   size_t partial_bytes = 0;
 };
-int direct_plan(nbody_ctx* c, int64_t n_src, float uniform_mass, int64_t n_tgt_total, int64_t n_tgt_max, float clamp, int arith,
-                const void* ws, size_t ws_bytes, DirectPlan* out) {
+int direct_plan(nbody_ctx* c, int64_t n_src, const void* mass_all, float uniform_mass, int64_t n_tgt_total, int64_t n_tgt_max, float clamp,
+                int arith, const void* ws, size_t ws_bytes, DirectPlan* out) {
   if (n_src < 0 || n_tgt_total < 0 || n_tgt_max < 0 || n_tgt_max > n_tgt_total || n_tgt_total > n_src || n_src > 0x7fffffffLL)
     return fail(c, NBODY_ERR_INVALID, "direct_step: bad target/source counts");
   if (arith < NBODY_ARITH_AUTO || arith > NBODY_ARITH_EXACT) return fail(c, NBODY_ERR_INVALID, "direct_step: bad arith");
@@ -217,6 +303,7 @@ int direct_plan(nbody_ctx* c, int64_t n_src, float uniform_mass, int64_t n_tgt_t
   // main pass runs at the equal-mass rate.  Without the split (small problems) the per-body-mass kernel is used.
   if (uniform_mass < 0.f && p.nearfar && env_int("NBODY_DIRECT_NO_UNIFORM", 0) == 0 && env_int("NBODY_DIRECT_NO_SPARSE", 0) == 0)
     p.sparse_base = -uniform_mass;
+  if (!p.uni && p.sparse_base == 0.f && p.nearfar) p.classes = classes_for(c, n_src, mass_all);
   p.use_hazard = arith == NBODY_ARITH_AUTO;
   p.partial_bytes = direct_partial_bytes(n_src, n_tgt_max);
   *out = p;
@@ -227,7 +314,7 @@ int direct_plan(nbody_ctx* c, int64_t n_src, float uniform_mass, int64_t n_tgt_t
 int direct_prep(nbody_ctx* c, hipStream_t stream, int64_t n_src, const void* pos_all, const void* mass_all, float uniform_mass,
                 int64_t n_tgt_total, int64_t n_tgt_max, float clamp, int arith, void* ws, size_t ws_bytes) {
   DirectPlan p;
-  int rc = direct_plan(c, n_src, uniform_mass, n_tgt_total, n_tgt_max, clamp, arith, ws, ws_bytes, &p);
+  int rc = direct_plan(c, n_src, mass_all, uniform_mass, n_tgt_total, n_tgt_max, clamp, arith, ws, ws_bytes, &p);
   if (rc) return rc;
   if (n_tgt_total == 0 || p.arith == NBODY_ARITH_EXACT) return NBODY_OK;
   if (!pos_all || !mass_all) return fail(c, NBODY_ERR_INVALID, "direct_step: null pos_all/mass_all");
@@ -240,7 +327,8 @@ int direct_prep(nbody_ctx* c, hipStream_t stream, int64_t n_src, const void* pos
     const float2* pos_far = nullptr;
     const uint32_t* near_list = nullptr;
     HIPCHK(c, launch_nearfar(stream, (const float2*)pos_all, (const float*)mass_all, p.sparse_base, (int)n_src, clamp, p.use_hazard, flags,
-                             nf_scratch, L, &pos_far, &near_list));
+                             nf_scratch, L, &pos_far, &near_list, p.classes ? p.classes->rank : nullptr,
+                             p.classes ? p.classes->pad_slots : nullptr, p.classes ? p.classes->n_pad_slots : 0));
   } else {
     HIPCHK(c, launch_decide_simple(stream, p.use_hazard, flags));
   }
@@ -254,7 +342,7 @@ int direct_run(nbody_ctx* c, hipStream_t stream, int64_t n_src, const void* pos_
   if (n_tgt < 0 || tgt_begin < 0 || tgt_begin + n_tgt > n_src || n_tgt > n_tgt_max)
     return fail(c, NBODY_ERR_INVALID, "direct_step: bad target/source range");
   DirectPlan p;
-  int rc = direct_plan(c, n_src, uniform_mass, n_tgt_total, n_tgt_max, clamp, arith, ws, ws_bytes, &p);
+  int rc = direct_plan(c, n_src, mass_all, uniform_mass, n_tgt_total, n_tgt_max, clamp, arith, ws, ws_bytes, &p);
   if (rc) return rc;
   if (n_tgt == 0) return NBODY_OK;
   if (!pos_all || !mass_all) return fail(c, NBODY_ERR_INVALID, "direct_step: null pos_all/mass_all");
@@ -307,6 +395,11 @@ int direct_run(nbody_ctx* c, hipStream_t stream, int64_t n_src, const void* pos_
       a0.to_partial = 1;
       a0.run_state = 0;
       if (p.sparse_base > 0.f) a0.uniform_mass = p.sparse_base;  // the odd masses sit in the near list (state 1 reads them all)
+      if (p.classes) {  // the far copy is in class order, padded: the equal-mass instantiation, a tile's mass in its closing FMA
+        a0.n_src = (int)p.classes->n_slots;
+        a0.uniform_mass = 1.0f;
+        a0.tile_mass = p.classes->tile_mass;
+      }
       HIPCHK(c, launch_direct_fast(stream, a0, cfg, true));
     }
     DirectArgs a1 = a;  // state 1: one clamped pass over every source
@@ -404,6 +497,7 @@ template <class T> int upload(nbody_ctx* c, int64_t n, const T* pos, const T* ve
     HIPCHK(c, hipStreamSynchronize(c->stream));
   }
   s.h_weight_stale = false;
+  ++s.row_epoch;
   s.uniform_mass = (uniform && s.h_weight[0] > 0) ? (float)s.h_weight[0] : 0.f;
   s.sparse_base = 0.f;
   if (!uniform && n > 0) {  // one mass but for a few bodies?  (majority vote, then a count)
@@ -541,6 +635,7 @@ int bvh_build_device64(nbody_ctx* c, State<double>& s) {
   g.ids_in = in.ids; g.ids_out = out.ids;
   HIPCHK(c, launch_gather<double>(c->stream, g));
   s.cur = 1 - s.cur;
+    ++s.row_epoch;
   s.h_weight_stale = true;
   s.n_nodes = m;
   s.tree_kind = NBODY_TREE_BVH;
@@ -642,6 +737,7 @@ template <class T> int bvh_build_device(nbody_ctx* c, State<T>& s) {
       s.bvh_levels_hint = used;
     }
     s.cur = 1 - s.cur;
+    ++s.row_epoch;
     s.h_weight_stale = true;
     s.n_nodes = m;
     s.tree_kind = NBODY_TREE_BVH;
@@ -862,6 +958,7 @@ template <class T> int tree_build_phase(nbody_ctx* c, State<T>& s, int kind) {
     g.ids_in = in.ids; g.ids_out = out.ids;
     HIPCHK(c, launch_gather<T>(c->stream, g));
     s.cur = 1 - s.cur;
+    ++s.row_epoch;
     // host mirror of the row order
     s.h_tmp.resize((size_t)n);
     for (int64_t i = 0; i < n; ++i) s.h_tmp[(size_t)i] = s.h_weight[s.tree.order[(size_t)i]];
@@ -1174,6 +1271,7 @@ template <class T> int bvh_step_ahead(nbody_ctx* c, State<T>& s, T delta, PhaseE
     while (used < kBvhLevels - 1 && bigcount[used] != 0) ++used;
     s.bvh_levels_hint = used;
     s.cur = 1 - s.cur;
+    ++s.row_epoch;
     s.h_weight_stale = true;
     s.n_nodes = flags[kBvhNodes];
     s.tree_kind = NBODY_TREE_BVH;
@@ -1828,6 +1926,8 @@ NB_API int nbody_update_direct_f32(nbody_ctx* c, float delta, int n_steps, nbody
   int step = 0;
   // ---- graph replay of step pairs (no timer attached: event records do not belong in a captured graph)
   const bool want_graph = n_steps >= 4 && s.n > 0 && s.n <= (1 << 17) && !c->timer && env_int("NBODY_DIRECT_GRAPH", 1) != 0;
+  rc = ensure_mass_classes(c);  // (host work and copies: before any capture)
+  if (rc) return rc;
   if (want_graph) {
     auto& st = s.set[s.cur];
     DirectGraph& g = c->direct_graph;
@@ -1888,6 +1988,8 @@ NB_API int nbody_accel_direct_f32(nbody_ctx* c, float* acc_xy) {
   HIPCHK(c, hipSetDevice(c->device));
   State<float>& s = c->sf;
   int rc = ensure_workspace(c, direct_ws_bytes(s.n, s.n));
+  if (rc) return rc;
+  rc = ensure_mass_classes(c);
   if (rc) return rc;
   auto& st = s.set[s.cur];
   rc = direct_step_dev(c, c->stream, s.n, st.pos, st.mass, direct_mass_hint(s), 0, s.n, nullptr, nullptr, s.acc, 0.f, c->params.clamp,
@@ -2159,6 +2261,7 @@ int ctx_import_rows(nbody_ctx* c, int64_t n_rows, const void* rows, const void* 
 }
 size_t ctx_direct_ws_bytes(int64_t n_src, int64_t n_tgt) { return direct_ws_bytes(n_src, n_tgt); }
 int ctx_ensure_workspace(nbody_ctx* c, size_t bytes) { return ensure_workspace(c, bytes); }
+int ctx_ensure_mass_classes(nbody_ctx* c) { return c && c->has_f32 ? ensure_mass_classes(c) : NBODY_OK; }
 int ctx_direct_prep(nbody_ctx* c, hipStream_t stream, int64_t n_src, const void* pos_all, const void* mass_all, float uniform_mass,
                     int64_t n_tgt_total, int64_t n_tgt_max, float clamp, int arith, void* ws, size_t ws_bytes) {
   return direct_prep(c, stream, n_src, pos_all, mass_all, uniform_mass, n_tgt_total, n_tgt_max, clamp, arith, ws, ws_bytes);

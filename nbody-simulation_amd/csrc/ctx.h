@@ -29,6 +29,20 @@ template <class T> struct State {
   T2* pos_next = nullptr;  // direct step output, swapped with set[cur].pos
   float uniform_mass = 0.f;  // > 0 when every weight is the same value (checked on upload)
   float sparse_base = 0.f;   // > 0 when every weight is this value but for at most n/256 bodies (the reference's scene)
+  // Mass classes (direct step, masses that differ freely but take at most 32 values): the far copy of the positions is
+  // written in class order, every class padded to whole 1024-source tiles, so the main pass runs the equal-mass arithmetic
+  // tile by tile.  Built lazily for the current row order (row_epoch moves whenever a build permutes the rows).
+  struct MassClasses {
+    uint64_t epoch = ~0ull;        // row_epoch these arrays were built for
+    bool usable = false;           // 2 .. 32 distinct masses, none of the cheaper cases
+    int n_classes = 0;
+    int64_t n_slots = 0;           // bodies + padding
+    int n_pad_slots = 0;
+    uint32_t* rank = nullptr;      // [n] device: body -> slot
+    uint32_t* pad_slots = nullptr; // [n_pad_slots] device
+    float* tile_mass = nullptr;    // [n_slots / 1024] device
+  } classes;
+  uint64_t row_epoch = 0;
   T2* acc = nullptr;
   // tree
   void* geom0 = nullptr;
@@ -49,7 +63,7 @@ template <class T> struct State {
   size_t qb_scratch_bytes = 0;
   char* bb_scratch = nullptr;    // device BVH build
   size_t bb_scratch_bytes = 0;
-  bool h_weight_stale = false;   // a device BVH build permuted the rows without touching h_weight
+  bool h_weight_stale = false;   // a device BVH build permuted the rows without touching h_weight (row_epoch moves with it)
   int quad_depth_hint = 0;       // depth of the last device-built quad tree (how many levels the next build sorts by)
   int bvh_levels_hint = 0;       // long-node levels the last device-built BVH had (how many the next step enqueues blind)
   bool bb_flags_clean = false;   // the BVH build's flags and level counters are zero (the step enqueued ahead left them so)
@@ -184,6 +198,7 @@ int ctx_export_slice(nbody_ctx* c, int64_t begin, int64_t count, void* rows, voi
 int ctx_import_rows(nbody_ctx* c, int64_t n_rows, const void* rows, const void* pos, const void* vel);
 size_t ctx_direct_ws_bytes(int64_t n_src, int64_t n_tgt);
 int ctx_ensure_workspace(nbody_ctx* c, size_t bytes);
+int ctx_ensure_mass_classes(nbody_ctx* c);  // State::MassClasses of the f32 rows, for the direct steps that follow
 int ctx_direct_prep(nbody_ctx* c, hipStream_t stream, int64_t n_src, const void* pos_all, const void* mass_all, float uniform_mass,
                     int64_t n_tgt_total, int64_t n_tgt_max, float clamp, int arith, void* ws, size_t ws_bytes);
 int ctx_direct_run(nbody_ctx* c, hipStream_t stream, int64_t n_src, const void* pos_all, const void* mass_all, float uniform_mass,

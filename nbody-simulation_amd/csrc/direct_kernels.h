@@ -28,6 +28,8 @@ struct DirectArgs {
   const int* flags;    // decision words
   int run_state;       // the kernel runs only when flags[kFlagState] == run_state; < 0: always
   const uint32_t* near_list;  // near sources (ascending body index), count in flags[kFlagNearCount]
+  const float* tile_mass;     // mass classes (capi.hip): src_pos is ordered by mass class, every 1024-source tile holds ONE class
+                              // (classes padded with far-away points) and tile_mass[tile] is its mass; null otherwise
 };
 
 struct DirectConfig {
@@ -42,8 +44,13 @@ struct NearFarLayout {
 };
 NearFarLayout nearfar_layout(int64_t n_src);
 // heavy_base > 0: bodies whose mass differs from it join the near list (sparse-heavy scenes; `mass` is then read)
+// rank (optional, mass classes): body i's slot in the far copy (class order, classes padded to whole tiles); the n_pad_slots
+// slots of pad_slots hold no body and receive the far-away point.  The far copy then has n + n_pad_slots entries.
+constexpr int64_t kMaxMassClasses = 32;
+constexpr int64_t kDirectTile = 1024;
 hipError_t launch_nearfar(hipStream_t s, const float2* pos, const float* mass, float heavy_base, int n, float clamp, int use_hazard,
-                          int* flags, char* scratch, const NearFarLayout& L, const float2** pos_far, const uint32_t** near_list);
+                          int* flags, char* scratch, const NearFarLayout& L, const float2** pos_far, const uint32_t** near_list,
+                          const uint32_t* rank = nullptr, const uint32_t* pad_slots = nullptr, int n_pad_slots = 0);
 hipError_t launch_decide_simple(hipStream_t s, int use_hazard, int* flags);
 
 hipError_t launch_direct_fast(hipStream_t s, const DirectArgs& a, const DirectConfig& c, bool noclamp);

@@ -223,6 +223,11 @@ __global__ __launch_bounds__(256) void direct_fast(const DirectArgs a) {
   // sources of this grid split: [g0, g1)
   int gchunk = (a.n_src + (int)gridDim.y - 1) / (int)gridDim.y;
   gchunk = (gchunk + 31) & ~31;
+  // Mass classes: the sources come ordered by class, each class padded to whole tiles, so a tile has ONE mass and the
+  // equal-mass arithmetic applies: the class's mass rides in the add that joins a tile's partial sum to the running total
+  // (an FMA instead of an add, once per 256 pairs: nothing per pair).  The splits then start on tile boundaries.
+  const float* __restrict__ class_mass = UNIFORM ? a.tile_mass : nullptr;
+  if (class_mass) gchunk = (gchunk + TILE - 1) & ~(TILE - 1);
   long g0l = (long)blockIdx.y * gchunk;
   const int g0 = g0l < a.n_src ? (int)g0l : a.n_src;
   const int g1 = (g0 + gchunk < a.n_src) ? g0 + gchunk : a.n_src;
@@ -230,6 +235,7 @@ __global__ __launch_bounds__(256) void direct_fast(const DirectArgs a) {
 
   for (int base = g0; base < g1; base += TILE) {
     const int cnt = (g1 - base < TILE) ? g1 - base : TILE;
+    const float tm = class_mass ? class_mass[base / TILE] : 1.0f;  // (1.0: fma(b, 1, a) is a + b, bit for bit)
 #pragma unroll
     for (int r = 0; r < TILE / 256; ++r) {
       int s = r * 256 + (int)threadIdx.x;
@@ -272,8 +278,8 @@ __global__ __launch_bounds__(256) void direct_fast(const DirectArgs a) {
         float m = UNIFORM ? 1.0f : tile_mass[u];
         fast_pair<UNIFORM, NOCLAMP>(xi[0], yi[0], p.x, p.y, m, clamp, bx, by);
       }
-      ax[0] += bx;
-      ay[0] += by;
+      ax[0] = __builtin_fmaf(bx, tm, ax[0]);
+      ay[0] = __builtin_fmaf(by, tm, ay[0]);
     } else {
       float bx[TPT], by[TPT];
 #pragma unroll
@@ -307,8 +313,8 @@ __global__ __launch_bounds__(256) void direct_fast(const DirectArgs a) {
       }
 #pragma unroll
       for (int k = 0; k < TPT; ++k) {
-        ax[k] += bx[k];
-        ay[k] += by[k];
+        ax[k] = __builtin_fmaf(bx[k], tm, ax[k]);
+        ay[k] = __builtin_fmaf(by[k], tm, ay[k]);
       }
     }
     __syncthreads();

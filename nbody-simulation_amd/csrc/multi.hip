@@ -343,6 +343,7 @@ int direct_worker(Multi& M, int d, float delta, int n_steps) {
   const int G = M.G, C = M.chunks;
   const size_t rowb = sizeof(float2);
   int rc = ctx_ensure_workspace(S, ctx_direct_ws_bytes(n, std::min<int64_t>(M.block, n)));
+  if (rc == NBODY_OK) rc = ctx_ensure_mass_classes(S);
   bool ok = rc == NBODY_OK;
   const int64_t total = M.local_total(d);
   int64_t tmax = 0;  // this device's largest block
@@ -493,6 +494,7 @@ template <class T> int replicate_rows(Multi& M) {
       if (e != hipSuccess) return M.hip_fail(0, e, "replicate rows");
     }
     s.h_weight_stale = true;  // the host mirror of the weights is in another row order now
+    ++s.row_epoch;
     s.tree_valid = false;
     s.wt_hist_n = -1;
   }

@@ -127,17 +127,22 @@ __global__ __launch_bounds__(256) void nf_mark(const float2* __restrict__ pos, i
 }
 
 // The near list (ascending body index: the near sum has a fixed order) and the far copy of the positions.
+// With mass classes the far copy is written in class order (rank[i]) and the threads past n fill the padding slots.
 __global__ __launch_bounds__(256) void nf_compact(const float2* __restrict__ pos, const uint32_t* __restrict__ is_near,
                                                   const uint32_t* __restrict__ scan, int n, float2* __restrict__ pos_far,
-                                                  uint32_t* __restrict__ near_list) {
+                                                  uint32_t* __restrict__ near_list, const uint32_t* __restrict__ rank,
+                                                  const uint32_t* __restrict__ pad_slots, int n_pad_slots) {
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
+  if (i >= n) {
+    if (i - n < n_pad_slots) pos_far[pad_slots[i - n]] = make_float2(1e30f, 1e30f);
+    return;
+  }
   float2 p = pos[i];
   if (is_near[i]) {
     near_list[scan[i]] = (uint32_t)i;
     p = make_float2(1e30f, 1e30f);
   }
-  pos_far[i] = p;
+  pos_far[rank ? rank[i] : (uint32_t)i] = p;
 }
 
 // state: 0 = near/far split (no clamp in the main pass), 1 = single clamped pass, 2 = EXACT kernel.
@@ -177,7 +182,7 @@ NearFarLayout nearfar_layout(int64_t n_src) {
   L.is_near = off; off += align_up(n * 4);
   L.scan = off; off += align_up(n * 4);
   L.near_list = off; off += align_up(n * 4);
-  L.pos_far = off; off += align_up(n * 8);
+  L.pos_far = off; off += align_up((n + (size_t)(kMaxMassClasses + 1) * (size_t)kDirectTile) * 8);  // (room for the mass classes' padding)
   L.cub_temp = off;
   size_t need_scan = 0;
   (void)hipcub::DeviceScan::ExclusiveSum(nullptr, need_scan, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)n, (hipStream_t) nullptr);
@@ -189,7 +194,8 @@ NearFarLayout nearfar_layout(int64_t n_src) {
 
 // Enqueues the split.  On return flags[kFlagState] is (will be) valid on the stream.
 hipError_t launch_nearfar(hipStream_t s, const float2* pos, const float* mass, float heavy_base, int n, float clamp, int use_hazard,
-                          int* flags, char* scratch, const NearFarLayout& L, const float2** pos_far, const uint32_t** near_list) {
+                          int* flags, char* scratch, const NearFarLayout& L, const float2** pos_far, const uint32_t** near_list,
+                          const uint32_t* rank, const uint32_t* pad_slots, int n_pad_slots) {
   uint32_t* table = (uint32_t*)(scratch + L.table_keys);
   uint32_t* is_near = (uint32_t*)(scratch + L.is_near);
   uint32_t* scan = (uint32_t*)(scratch + L.scan);
@@ -209,7 +215,9 @@ hipError_t launch_nearfar(hipStream_t s, const float2* pos, const float* mass, f
   size_t tb = L.cub_temp_bytes;
   e = hipcub::DeviceScan::ExclusiveSum(scratch + L.cub_temp, tb, is_near, scan, n, s);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(nf_compact, dim3(blocks), dim3(256), 0, s, pos, is_near, scan, n, far, list);
+  if ((int64_t)n_pad_slots > (kMaxMassClasses + 1) * kDirectTile) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(nf_compact, dim3((unsigned)((n + (rank ? n_pad_slots : 0) + 255) / 256)), dim3(256), 0, s, pos, is_near, scan, n, far, list,
+                     rank, pad_slots, rank ? n_pad_slots : 0);
   hipLaunchKernelGGL(nf_decide, dim3(1), dim3(1), 0, s, is_near, scan, n, n / 64, use_hazard, flags);
   return hipGetLastError();
 }

@@ -412,3 +412,64 @@ def test_reference_scene_takes_the_sparse_path(nb, orc, monkeypatch):
     check_fast(accs["0"][tg], ref64, norm, label=" galaxy sparse")
     check_fast(accs["1"][tg], ref64, norm, label=" galaxy per-body")
     assert not np.array_equal(accs["0"], accs["1"])              # i.e. another kernel really ran
+
+
+# ------------------------------------------------------------------ mass classes (round 3)
+@pytest.mark.parametrize("n_classes", [2, 5, 32, 33])
+def test_mass_classes_within_tolerance(nb, orc, ctx, monkeypatch, capfd, n_classes):
+    """Masses that differ freely but take few values: the sources are ordered by mass class (every class padded to whole
+    1 024-source tiles) and the equal-mass kernel runs tile by tile, the class's mass in the FMA that closes a tile.  1 .. 32
+    classes take that path (NBODY_TRACE says so), 33 fall back to the per-body-mass kernel; both inside the frozen tolerance,
+    near bodies (clamped pairs, a coincident pair) included, and bitwise reproducible from one upload to the next."""
+    C = nb._capi
+    n = 98304 + 777                                          # >= 65 536: the near/far split (and with it the classes) is on
+    pos, vel, _ = nb.scenes.plummer(n, seed=47)
+    rng = np.random.default_rng(n_classes)
+    masses = np.unique(np.concatenate([[1, 7], rng.integers(1, 1 << 20, 64)]))[:n_classes].astype(np.uint32)
+    assert len(masses) == n_classes
+    w = masses[rng.integers(0, n_classes, n)]
+    w[:n_classes] = masses                                   # every class occurs
+    pos[100] = pos[200]                                      # coincident: contributes nothing
+    pos[300] = pos[400] + F32(0.0078125)                     # inside the clamp radius: both are near bodies
+    tg = np.arange(0, n, 37)
+    ref64, norm, cpu32 = _refs(orc, pos, w, targets=tg)
+    monkeypatch.setenv("NBODY_TRACE", "1")
+    ctx.set_params(arith=C.ARITH_AUTO, clamp=0.001)
+    ctx.upload(pos, vel, w)
+    capfd.readouterr()
+    a1 = ctx.accel_direct()
+    err = capfd.readouterr().err
+    assert (f"{n_classes} mass classes" in err) == (n_classes <= 32), err[-400:]
+    check_fast(a1[tg], ref64, norm, cpu32, label=f" {n_classes} classes")
+    ctx.upload(pos, vel, w)
+    assert np.array_equal(ctx.accel_direct(), a1)            # reproducible
+    monkeypatch.setenv("NBODY_DIRECT_NO_CLASSES", "1")       # the per-body kernel on the same input
+    ctx.upload(pos, vel, w)
+    a0 = ctx.accel_direct()
+    check_fast(a0[tg], ref64, norm, cpu32, label=" per-body kernel")
+    assert (n_classes > 32) == np.array_equal(a0, a1)
+
+
+def test_mass_classes_follow_the_rows_through_a_tree_build(nb, orc, ctx, monkeypatch):
+    """A BVH step permutes the rows (BVHTree::from partitions in place): the class order is rebuilt for the new row order
+    before the next direct step, and whole direct steps follow the per-body kernel's trajectory to rounding."""
+    C = nb._capi
+    n = 70000
+    pos, vel, _ = nb.scenes.plummer(n, seed=48)
+    w = (np.arange(n) % 4 * 3 + 1).astype(np.uint32)
+    ctx.set_params(arith=C.ARITH_AUTO, theta=50.0, order=C.ORDER_CONSISTENT)
+    ctx.upload(pos, vel, w)
+    ctx.update_direct(0.1, 1)
+    ctx.update_tree(C.TREE_BVH, 0.1, 1)                      # rows permuted
+    p, v, w2, ids = ctx.download()
+    assert not np.array_equal(ids, np.arange(n))
+    acc = ctx.accel_direct()                                 # classes of the permuted rows
+    tg = np.arange(0, n, 29)
+    check_fast(acc[tg], *_refs(orc, p, w2, targets=tg)[:2], label=" after a build")
+    ctx.update_direct(0.1, 3)
+    pa = ctx.download()
+    monkeypatch.setenv("NBODY_DIRECT_NO_CLASSES", "1")
+    ctx.upload(p, v, w2)
+    ctx.update_direct(0.1, 3)
+    pb = ctx.download()
+    assert np.abs(pa[0].astype(np.float64) - pb[0]).max() <= 1e-3 and np.abs(pa[1].astype(np.float64) - pb[1]).max() <= 1e-3
