@@ -731,6 +731,7 @@ __global__ __launch_bounds__(256) void walk_tile_fast(const WalkArgs<T> a, const
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
   if (info[1] != 0) return;  // the estimate's scan wrapped: the caller walks again without one
+  const long long log_t0 = LOG ? wall_clock64() : 0;
   // Which targets are this wave's: those with g(t) = off[t] / budget + t / 64 == wave (see walk_pass), by two binary searches.
   // Everything in them is wave-uniform, and kept on the scalar side on purpose: `off` is read through the constant address
   // space (s_load: it was written by kernels before this one) and the budget is a power of two (tile_total), so the
@@ -766,7 +767,6 @@ __global__ __launch_bounds__(256) void walk_tile_fast(const WalkArgs<T> a, const
   uint32_t n_terms = 0;
   T ax = 0, ay = 0;
   int i = 0;
-  const long long log_t0 = LOG ? wall_clock64() : 0;
   unsigned log_nodes = 0, log_leaves = 0, log_rounds = 0;
   // A node's three records (link, box, centre of gravity | mass | s^2), fetched together: one latency per step.  REC = 1
   // fetches them by VECTOR loads of one address (the offset passes through a register the compiler cannot see through, or
@@ -953,7 +953,7 @@ __global__ __launch_bounds__(256) void walk_tile_fast(const WalkArgs<T> a, const
   if (lane == 0) atomicAdd(total_out, sum);
   if (LOG && lane == 0) {
     unsigned long long* o = a.wave_log + 4 * wave;
-    o[0] = (unsigned long long)(wall_clock64() - log_t0);
+    o[0] = (((unsigned long long)log_t0 & 0xFFFFFFFFFFull) << 24) | ((unsigned long long)(wall_clock64() - log_t0) & 0xFFFFFFull);  // start (absolute, 40 bits) | duration
     o[1] = log_nodes;
     o[2] = log_leaves;
     o[3] = ((unsigned long long)(unsigned)(lo - t0) << 32) | log_rounds;

@@ -18,7 +18,8 @@ with C.Context(0) as ctx:
     ctx.update_tree(C.TREE_BVH, 0.1, 1)
     ms, _ = t.read()
 log = np.fromfile("/tmp/nbody_wave_log.bin", dtype=np.uint64).reshape(-1, 4)
-us = log[:, 0] * 0.01
+start = (log[:, 0] >> np.uint64(24)).astype(np.int64)
+us = (log[:, 0] & np.uint64(0xFFFFFF)) * 0.01
 nodes, leaves = log[:, 1].astype(np.int64), log[:, 2].astype(np.int64)
 targets, rounds = (log[:, 3] >> np.uint64(32)).astype(np.int64), (log[:, 3] & np.uint64(0xFFFFFFFF)).astype(np.int64)
 live = targets > 0
@@ -31,5 +32,10 @@ print(f"us per step (node + leaf): mean {(us[ok] / steps[ok]).mean():.2f}; sum o
 A = np.stack([nodes[ok], leaves[ok], rounds[ok], np.ones(ok.sum())], axis=1).astype(np.float64)
 coef, *_ = np.linalg.lstsq(A, us[ok], rcond=None)
 print("least squares: %.3f us per node step + %.3f us per leaf step + %.3f us per round + %.1f us per wave" % tuple(coef))
+t_first = start[live].min()
+end = start + (us * 100).astype(np.int64)
+print(f"waves start between 0 and {(start[live].max() - t_first) * 0.01:.1f} us after the first; the last one ends at {(end[live].max() - t_first) * 0.01:.1f} us")
+for k in np.argsort(-end * live)[:5]:
+    print(f"  ends last: wave {k}: starts at {(start[k] - t_first) * 0.01:.1f} us, runs {us[k]:.1f} us, {targets[k]} targets, {nodes[k]} node steps, {leaves[k]} leaf steps")
 for k in np.argsort(-us)[:8]:
     print(f"  wave {k}: {us[k]:.1f} us, {targets[k]} targets, {nodes[k]} node steps, {leaves[k]} leaf steps, {rounds[k]} rounds")
