@@ -27,7 +27,7 @@ enum : int {
 
 struct BvhBuildLayout {
   int node_cap, big_cap, chunk_cap;
-  size_t flags, bigcount, chunkcount, zero_end, bigq, subq, topq, ch_rec, ch_sum, ch_box, ch_run, ch_cx, ch_cy, ch_before, pts, ids, lidx, ridx;
+  size_t flags, bigcount, chunkcount, zero_end, bigq, subq, topq, ch_rec, ch_sum, ch_box, ch_run, ch_cx, ch_cy, ch_before, pts, ids, lidx, ridx, pred, pair;
   size_t nbegin, nlen, nparent, nchild, ndepth, nleaf, nsize, npre, nbox, ncog, nmass, narrive, nmean, nsplit, nchunk0, ndone, nbad;
   size_t total;
 };

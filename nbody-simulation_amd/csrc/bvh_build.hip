@@ -16,7 +16,8 @@
 // Two phases.  Nodes longer than kSub points are processed breadth-first, a level at a time, with the node's points
 // spread over many work-groups: bvh_big_fold (the chain: one 1024-thread group per node, the only serial part),
 // bvh_big_count (per-chunk counts; the last chunk to finish picks the axis, the split and creates the children),
-// bvh_big_ranks (rank lists), bvh_big_swap.  Every node of at most kSub points is the root of a subtree that ONE
+// bvh_big_ranks (ranks from the predicate bits bvh_big_count left; the two halves of a pair meet in a 64-bit slot and whoever
+// arrives second swaps: round 3, one launch per level fewer).  Every node of at most kSub points is the root of a subtree that ONE
 // work-group builds completely out of LDS (bvh_subtrees): long nodes by the whole group, short ones a wave each.
 //
 // Nodes get breadth-first ids while they are made.  The upward pass (:133-158; leaves: unweighted mean in slice order,
@@ -54,6 +55,7 @@ constexpr int kChunk = 2048;     // points per work-group in the multi-group pas
 #ifndef NB_RUN_LEN
 #define NB_RUN_LEN 16384
 #endif
+constexpr int kFusedPartitionMax = 400000;  // points up to which a level's rank pass also swaps (bvh_big_ranks); beyond: lists + bvh_big_swap
 constexpr int kRunLen = NB_RUN_LEN;   // nodes longer than this have their chain prepared chunk by chunk (bvh_chunk_runs)
 constexpr float kMaxF = 3.402823466e+38f;
 
@@ -76,6 +78,8 @@ struct BvhPtrs {
   uint32_t* ID;
   int* lidx;
   int* ridx;
+  uint8_t* pred;             // long nodes: bit 0 = x > mean.x, bit 1 = y > mean.y of every point (bvh_big_count), read by bvh_big_ranks
+  unsigned long long* pair;  // long nodes: one slot per pair of misplaced points (low word: the left one's index + 1, high word: the right one's)
   int* nbegin;
   int* nlen;
   int* nparent;
@@ -115,6 +119,8 @@ BvhPtrs make_ptrs(char* s, const BvhBuildLayout& L) {
   a.ID = (uint32_t*)(s + L.ids);
   a.lidx = (int*)(s + L.lidx);
   a.ridx = (int*)(s + L.ridx);
+  a.pred = (uint8_t*)(s + L.pred);
+  a.pair = (unsigned long long*)(s + L.pair);
   a.nbegin = (int*)(s + L.nbegin);
   a.nlen = (int*)(s + L.nlen);
   a.nparent = (int*)(s + L.nparent);
@@ -625,6 +631,7 @@ __global__ __launch_bounds__(256) void bvh_init(BvhPtrs a, const float2* __restr
     const float2 p = pos[i];
     a.P[i] = p;
     a.ID[i] = (uint32_t)i;
+    a.pair[i] = 0ull;  // (the pair slots clean themselves; a build that was abandoned half-way may have left some)
     if (p.x != p.x || p.y != p.y) a.flags[kBvhFallback] = 1;
   }
   for (int j = i + 1; j < a.cap; j += gridDim.x * 256) a.ndepth[j] = -1;  // not a node (yet): ids are handed out in ranges
@@ -1102,8 +1109,10 @@ __global__ __launch_bounds__(256) void bvh_big_count(BvhPtrs a, int level, int l
     unsigned cx = 0u, cy = 0u;
     for (int i = lo + tid; i < hi; i += 256) {
       const float2 q = a.P[b + i];
-      cx += q.x > h.x;
-      cy += q.y > h.y;
+      const unsigned px = q.x > h.x, py = q.y > h.y;
+      cx += px;
+      cy += py;
+      a.pred[b + i] = (uint8_t)(px | (py << 1));  // both axes: which one splits is known only when every chunk has counted
     }
     cx = group_sum<4>(cx, red[0], tid);
     cy = group_sum<4>(cy, red[1], tid);
@@ -1220,8 +1229,79 @@ __global__ __launch_bounds__(256) void bvh_big_count(BvhPtrs a, int level, int l
   }
 }
 
-// ---- long nodes: the two rank lists of the partition ---------------------------------------------------------------
+// ---- long nodes: the partition ---------------------------------------------------------------------------------------
+// The crate's two pointers meet the k-th misplaced point going up from the left and the k-th going down from the right, so
+// the swaps are known from ranks alone: a point's rank follows from the chunk prefixes of bvh_big_count.  Rounds 1-2 wrote
+// two rank lists here and swapped in a kernel of its own; now each misplaced point posts its index in the slot of its pair
+// (one atomicOr on a 64-bit word: low half the left point, high half the right one) and whichever of the two arrives second
+// swaps the points and clears the slot.  The ranks are computed from the predicate BITS bvh_big_count left, not from the
+// points: those are being swapped by other work-groups meanwhile.  One launch per level fewer, and no list is written or read.
 __global__ __launch_bounds__(256) void bvh_big_ranks(BvhPtrs a, int level) {
+  __shared__ unsigned wcnt[4];
+  constexpr int PER = kChunk / 256;  // consecutive points per thread
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nc = a.chunkcount[level];
+  const int4* ch_rec = a.ch_rec + (size_t)(level & 1) * a.cap_chunk;
+  for (int c = blockIdx.x; c < nc; c += gridDim.x) {
+    const int4 cr = ch_rec[c];
+    const int node = cr.x, ci = cr.y, b = cr.z, len = cr.w;
+    const int sp = a.nsplit[node];
+    const int shift = sp < 0 ? 0 : 1;  // on x: bit 0, on y: bit 1
+    const int m = sp & 0x7fffffff;
+    const int base = ci * kChunk + tid * PER;
+    bool pr[PER];
+    unsigned mine = 0u;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      pr[j] = false;
+      if (base + j < len) {
+        pr[j] = ((a.pred[b + base + j] >> shift) & 1) != 0;
+        mine += pr[j];
+      }
+    }
+    unsigned inc = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const unsigned o = (unsigned)__shfl_up((int)inc, d, 64);
+      if (lane >= d) inc += o;
+    }
+    if (lane == 63) wcnt[wave] = inc;
+    __syncthreads();
+    unsigned t = (unsigned)a.ch_before[c] + inc - mine;  // predicate-true points of the node before my first one
+    for (int w = 0; w < wave; ++w) t += wcnt[w];
+    float2* P = a.P + b;
+    uint32_t* ID = a.ID + b;
+    unsigned long long* pair = a.pair + b;  // pair k of this node: k < min(m, len - m) <= len / 2, inside the node's own range
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const int i = base + j;
+      if (i < len) {
+        const bool left = i < m && !pr[j];    // the k-th misplaced point from the left, k = i - t
+        const bool right = i >= m && pr[j];   // the k-th misplaced point from the right, k = m - t - 1
+        if (left || right) {
+          const int k = left ? i - (int)t : m - (int)t - 1;
+          const unsigned long long old = atomicOr(&pair[k], left ? (unsigned long long)(unsigned)(i + 1) : (unsigned long long)(unsigned)(i + 1) << 32);
+          const unsigned other = left ? (unsigned)(old >> 32) : (unsigned)old;
+          if (other != 0u) {  // the partner was here first: swap, and leave the slot clean for the next level
+            const int l = left ? i : (int)other - 1, r = left ? (int)other - 1 : i;
+            const float2 pl = P[l], pq = P[r];
+            P[l] = pq; P[r] = pl;
+            const uint32_t il = ID[l], ir = ID[r];
+            ID[l] = ir; ID[r] = il;
+            pair[k] = 0ull;
+          }
+        }
+        t += pr[j];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ---- long nodes, many points (a million and more): rank lists, then the swaps in a kernel of their own --------------------
+// (the fused pass above spends an atomic with a return value and four scattered accesses per misplaced point inside ONE
+// kernel: at N = 1 M 24.6 us per level against 6.7 + 6.4 us for the two below; at 151 405 it is 8.6 us against 9.4)
+__global__ __launch_bounds__(256) void bvh_big_ranks_lists(BvhPtrs a, int level) {
   __shared__ unsigned wcnt[4];
   __shared__ unsigned red[4];
   constexpr int PER = kChunk / 256;  // consecutive points per thread
@@ -1875,6 +1955,8 @@ BvhBuildLayout bvh_build_layout(int64_t n, int leaf_size) {
   L.ids = take(4 * N);
   L.lidx = take(4 * N);
   L.ridx = take(4 * N);
+  L.pred = take(N);
+  L.pair = take(8 * N);
   L.nbegin = take(4 * C);
   L.nlen = take(4 * C);
   L.nparent = take(4 * C);
@@ -1921,7 +2003,10 @@ hipError_t bvh_build_levels(hipStream_t s, int n, int leaf_size, int level_begin
     int64_t gb = L.big_cap < width ? L.big_cap : width;
     int64_t gc = L.chunk_cap;
     if (gc > 1024) gc = 1024;
-    const int use_runs = (n >> level) > kRunLen / 2 ? 1 : 0;  // could a node of this level be longer than kRunLen?
+    // could a node of this level be longer than kRunLen?  (A performance choice only: a chain without prepared runs is
+    // scanned.  Three quarters of kRunLen as the level's average: the level whose nodes average 9 462 of the reference scene's
+    // points spent two launches preparing runs nobody used.)
+    const int use_runs = (n >> level) > kRunLen * 3 / 4 ? 1 : 0;
     if (use_runs) {
       bvh_chunk_sums<<<dim3((unsigned)gc), dim3(256), 0, s>>>(a, level);
       bvh_chunk_runs<<<dim3((unsigned)gc), dim3(256), 0, s>>>(a, level);
@@ -1932,8 +2017,12 @@ hipError_t bvh_build_levels(hipStream_t s, int n, int leaf_size, int level_begin
     bvh_debug_fold_times(s);
 #endif
     bvh_big_count<<<dim3((unsigned)gc), dim3(256), 0, s>>>(a, level, leaf_size);
-    bvh_big_ranks<<<dim3((unsigned)gc), dim3(256), 0, s>>>(a, level);
-    bvh_big_swap<<<dim3((unsigned)gc), dim3(256), 0, s>>>(a, level);
+    if (n <= kFusedPartitionMax) {
+      bvh_big_ranks<<<dim3((unsigned)gc), dim3(256), 0, s>>>(a, level);
+    } else {
+      bvh_big_ranks_lists<<<dim3((unsigned)gc), dim3(256), 0, s>>>(a, level);
+      bvh_big_swap<<<dim3((unsigned)gc), dim3(256), 0, s>>>(a, level);
+    }
   }
   return hipGetLastError();
 }

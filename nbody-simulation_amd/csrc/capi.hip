@@ -119,7 +119,7 @@ template <class T> void free_state(State<T>& s) {
   free_dev(s.pos_next); free_dev(s.acc); free_dev(s.geom0); free_dev(s.geom1); free_dev(s.link); free_dev(s.order_dev);
   free_dev(s.node_depth); free_dev(s.node_mass); free_dev(s.node_size); free_dev(s.qb_scratch); free_dev(s.bb_scratch); free_dev(s.ws_scratch); free_dev(s.ws_terms); free_dev(s.wt_hist);
   s.node_aux_cap = 0; s.qb_scratch_bytes = 0; s.bb_scratch_bytes = 0; s.h_weight_stale = false;
-  s.ws_scratch_bytes = 0; s.ws_capacity = 0; s.ws_backoff = 0; s.quad_depth_hint = 0; s.wt_hist_n = -1; s.bvh_levels_hint = 0; s.ahead_total_due = false;
+  s.ws_scratch_bytes = 0; s.ws_capacity = 0; s.ws_backoff = 0; s.quad_depth_hint = 0; s.wt_hist_n = -1; s.bvh_levels_hint = 0; s.bvh_levels_stable = 0; s.ahead_total_due = false;
   s.tree_host_stale = false; s.n_nodes = 0;
   s.node_cap = 0; s.n = 0; s.tree_valid = false; s.tree.clear();
   s.h_pos.clear(); s.h_weight.clear();
@@ -735,6 +735,7 @@ template <class T> int bvh_build_device(nbody_ctx* c, State<T>& s) {
       int used = 0;
       while (used < kBvhLevels - 1 && hostf[kBvhFlagWords + used] != 0) ++used;
       s.bvh_levels_hint = used;
+      s.bvh_levels_stable = 0;
     }
     s.cur = 1 - s.cur;
     ++s.row_epoch;
@@ -1024,6 +1025,7 @@ int tree_walk_phase(nbody_ctx* c, State<T>& s, int kind, const void* tgt_pos, in
         s.wt_hist_n = -1;
         HIPCHK(c, hipMalloc((void**)&s.ws_scratch, L.total));
         s.ws_scratch_bytes = L.total;
+        HIPCHK(c, hipMemsetAsync(s.ws_scratch + L.scan_state, 0, L.scan_state_bytes, c->stream));  // walk_scan_est_tail keeps its books there
       }
       const bool self = tgt_pos == nullptr;
       if (self && !s.wt_hist) {
@@ -1073,6 +1075,7 @@ int tree_walk_phase(nbody_ctx* c, State<T>& s, int kind, const void* tgt_pos, in
         s.ws_scratch_bytes = 0;
         HIPCHK(c, hipMalloc((void**)&s.ws_scratch, L.total));
         s.ws_scratch_bytes = L.total;
+        HIPCHK(c, hipMemsetAsync(s.ws_scratch + L.scan_state, 0, L.scan_state_bytes, c->stream));
       }
       for (int attempt = 0; attempt < 2 && !done; ++attempt) {
         int info[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1177,7 +1180,11 @@ template <class T> int bvh_step_ahead(nbody_ctx* c, State<T>& s, T delta, PhaseE
     // ---- build: as many long-node levels as the last tree had, plus one (a balanced tree's, plus two, the first time)
     const int first_levels = bvh_build_first_levels(n);
     int lv_end = first_levels > 0 ? first_levels + 2 : 0;
-    if (lv_end > 0 && s.bvh_levels_hint > 0) lv_end = s.bvh_levels_hint + 1;  // (a lopsided tree has more than a balanced one + 2)
+    // (a lopsided tree has more than a balanced one + 2).  The spare level is four launches that find nothing to do (19 us of a
+    // 1.1 ms step): once the count has stood for eight builds it is dropped — the verdict still checks that no long node is
+    // left (bigcount[lv_end] == 0), and a tree that grows a level then costs ONE repeated step and brings the spare back.
+    if (lv_end > 0 && s.bvh_levels_hint > 0)
+      lv_end = s.bvh_levels_hint + ((s.bvh_levels_stable >= 8 && env_int("NBODY_BVH_SPARE_LEVEL", 0) == 0) ? 0 : 1);
     if (lv_end > 0) lv_end = std::max(1, env_int("NBODY_BVH_BLIND_LEVELS", lv_end));  // tests: too few levels, the verdict fails
     if (lv_end > kBvhKeyDepth + 1) lv_end = kBvhKeyDepth + 1;
     const bool flags_clean = s.bb_flags_clean;
@@ -1235,6 +1242,8 @@ template <class T> int bvh_step_ahead(nbody_ctx* c, State<T>& s, T delta, PhaseE
     tail.clear = (int*)(s.bb_scratch + L.flags);
     tail.clear_words = (int)((L.zero_end - L.flags) / sizeof(int));
     tail.info_zeroed = true;
+    // (one kernel instead of three: 17 us against 32 at 151 405 targets, 31 against 67 at a million; NBODY_WALK_FUSED_SCAN_MAX=0: the three)
+    tail.fused_scan = n <= std::min<int64_t>(kWalkFusedScanMaxTargets, env_int("NBODY_WALK_FUSED_SCAN_MAX", (int)kWalkFusedScanMaxTargets));
     HIPCHK(c, launch_tree_walk_tile_prep<T>(c->stream, w, s.ws_scratch, WL, tgt_ids, s.wt_hist, 1, shift, &waves, &tail));
     s.bb_flags_clean = true;
     int* h = c->spec_host;
@@ -1263,12 +1272,14 @@ template <class T> int bvh_step_ahead(nbody_ctx* c, State<T>& s, T delta, PhaseE
     if (h[1] == 0) {  // the build needs more levels or the host builder: nothing was integrated, `in` is intact
       s.wt_hist_n = -1;  // (the walk returned at once and left zeros in the history)
       s.bvh_levels_hint = 0;
+      s.bvh_levels_stable = 0;
       (void)phase_mark(c, ph, 3);
       return 1;
     }
     // the build stands: what bvh_build_device records
     int used = 0;
     while (used < kBvhLevels - 1 && bigcount[used] != 0) ++used;
+    s.bvh_levels_stable = used == s.bvh_levels_hint ? s.bvh_levels_stable + 1 : 0;
     s.bvh_levels_hint = used;
     s.cur = 1 - s.cur;
     ++s.row_epoch;

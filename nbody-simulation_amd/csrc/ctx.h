@@ -66,6 +66,7 @@ template <class T> struct State {
   bool h_weight_stale = false;   // a device BVH build permuted the rows without touching h_weight (row_epoch moves with it)
   int quad_depth_hint = 0;       // depth of the last device-built quad tree (how many levels the next build sorts by)
   int bvh_levels_hint = 0;       // long-node levels the last device-built BVH had (how many the next step enqueues blind)
+  int bvh_levels_stable = 0;     // consecutive step-ahead builds that had exactly that many: after eight the spare blind level is dropped
   bool bb_flags_clean = false;   // the BVH build's flags and level counters are zero (the step enqueued ahead left them so)
   bool ahead_total_due = false;  // the last ahead-step's exact term count has not been read back yet
   // split walk (walk_split.hip): counts/offsets scratch and the term array

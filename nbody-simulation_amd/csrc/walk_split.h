@@ -10,8 +10,10 @@ namespace nbody {
 
 struct WalkSplitLayout {
   size_t cnt, off, info, cub_temp, cub_temp_bytes, total;  // bytes from the start of the scratch block
+  size_t scan_state, scan_state_bytes;  // walk_scan_est_tail: a ticket and one 64-bit state per work-group (zeroed once, by the caller)
 };
 WalkSplitLayout walk_split_layout(int64_t n_tgt);
+constexpr int64_t kWalkFusedScanMaxTargets = (int64_t)1 << 24;  // TileTail::fused_scan: at most this many targets
 
 // info (int[8] at scratch + L.info) afterwards: {total terms, term array too small, 32-bit offsets wrapped, terms per wave
 // of the term pass, ...}.
@@ -47,6 +49,10 @@ struct TileTail {
   int* clear = nullptr;           // zeroed once packed
   int clear_words = 0;
   bool info_zeroed = false;       // info is zero already (an earlier kernel of the stream did it)
+  // The estimate's scan, its overflow check and the duties above as ONE kernel (walk_scan_est_tail: a single-pass scan with
+  // decoupled look-back) instead of the library scan's two launches + the check's.  The caller has zeroed
+  // scratch + L.scan_state (L.scan_state_bytes) once, when it allocated the scratch; the kernel keeps its own books there.
+  bool fused_scan = false;
 };
 template <class T>
 hipError_t launch_tree_walk_tile_prep(hipStream_t s, const WalkArgs<T>& a, char* scratch, const WalkSplitLayout& L, const uint32_t* tgt_ids,

@@ -1000,6 +1000,47 @@ __global__ void walk_tile_total(const uint32_t* __restrict__ cnt, const uint32_t
                                 int* __restrict__ info) {
   tile_total(cnt, off, n, tgt_ids, hist, shift, extra_waves, grid_waves, info);
 }
+// The TileTail duties (walk_split.h), by the one work-group that knows the estimate's total: the walk's budget and flags
+// (info[0..7] final), the verdict on the build, the record packed for the host, the build's counters cleared.
+__device__ __forceinline__ void tile_tail_duties(unsigned long long total, int wrapped, int wrapped2, int shift, int64_t n, int64_t extra_waves,
+                                                 int64_t grid_waves, int groups, int* __restrict__ info, const TileTail& tail, int tid) {
+  const int my_flag = tail.pack && tid < tail.flag_words ? tail.flags[tid] : 0;  // (on its way while thread 0 works)
+  if (tid == 0) {
+    int out[8] = {0, wrapped, wrapped2, 0, 0, 0, 0, 0};
+    out[0] = (int)(total > 0x7fffffffull ? 0x7fffffffull : total);
+    // walk_tile_total's arithmetic (a total clipped to 2^31 - 1 has raised the flag already)
+    unsigned long long want = (total + (unsigned long long)extra_waves - 1) / (unsigned long long)extra_waves;
+    uint32_t budget = kTileBudget >> shift;
+    if (budget < 64) budget = 64;
+    while (budget < want && budget < (1u << 30)) budget <<= 1;
+    out[3] = (int)budget;
+    if (total / budget + (unsigned long long)(n / 64) + 1 >= (unsigned long long)grid_waves) out[1] = 1;
+    out[4] = groups;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) info[k] = out[k];
+    int v0 = 0, v1 = 0;
+    if (tail.verdict) {
+      const int m = tail.flags[kBvhNodes];
+      const bool ok = tail.flags[kBvhFallback] == 0 && tail.flags[kBvhBadIndex] == 0 && m > 0 && m <= tail.node_cap &&
+                      tail.flags[kBvhNodeCount] <= tail.node_cap &&
+                      (tail.level_end <= 0 || tail.bigcount[tail.level_end] == 0);
+      v0 = ok ? m : 0;
+      v1 = ok ? 1 : 0;
+      tail.verdict[0] = v0;
+      tail.verdict[1] = v1;
+    }
+    if (tail.pack) {
+      tail.pack[0] = v0;
+      tail.pack[1] = v1;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) tail.pack[2 + tail.flag_words + k] = out[k];
+    }
+  }
+  if (tail.pack && tid < tail.flag_words) tail.pack[2 + tid] = my_flag;
+  __syncthreads();  // the flags are in registers or packed: the next build's counters may go
+  for (int k = tid; k < tail.clear_words; k += 256) tail.clear[k] = 0;
+}
+
 // walk_check_wrap_est, and in the work-group that finishes last: walk_tile_total and the TileTail duties (walk_split.h).
 // info[4] counts the finished groups, info[5] takes the estimate's total from the thread that meets the last target (zero
 // before, like the rest of info).
@@ -1039,45 +1080,113 @@ __global__ __launch_bounds__(256) void walk_check_est_tail(EstimateOf est, const
   __syncthreads();
   if (!last_group) return;
   __threadfence();
-  const int my_flag = tail.pack && tid < tail.flag_words ? tail.flags[tid] : 0;  // (on its way while thread 0 works)
+  // what the other groups left, past this compute unit's cache
+  const int wrapped = __hip_atomic_load(&info[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int wrapped2 = __hip_atomic_load(&info[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned long long total = (unsigned long long)(unsigned)__hip_atomic_load(&info[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  tile_tail_duties(total, wrapped, wrapped2, est.shift, n, extra_waves, grid_waves, (int)gridDim.x, info, tail, tid);
+}
+
+// The estimate's exclusive scan, its overflow check and the TileTail duties in ONE launch (the step enqueued ahead of the host
+// spent three on them: the library scan's two kernels and walk_check_est_tail, 32 us of a 1.1 ms step).  A single-pass scan
+// with decoupled look-back: a work-group takes a ticket (arrival order, so every predecessor is running or done), scans its
+// 1 024 estimates, publishes its aggregate, looks back over its predecessors' states until it meets an inclusive prefix, and
+// publishes its own.  States are 64-bit words {epoch : 30 | flag : 2 | value : 32} read and written whole; the epoch (kept
+// beside the ticket, advanced by the work-group with the last ticket, which also puts the ticket back to zero: by then every
+// group has read both) makes last launch's states invisible, so the host clears the area once, when it allocates it, and
+// keeps no books.  Values saturate at 2^31: a total that large is the overflow the walk must not run with (the old check's
+// wrapped 32-bit sums), and offsets are not needed then.  A look-back that waits absurdly long gives up with a saturated
+// prefix: the walk is then skipped and the host walks the plain way — never a hang.  The work-group with the last ticket
+// knows the total and does the tail's duties.
+constexpr int kScanPer = 4;
+constexpr int64_t kFusedScanMaxTargets = (int64_t)1 << 24;
+constexpr unsigned long long kScanSat = 0x80000000ull;
+constexpr unsigned long long kScanAgg = 1ull, kScanPrefix = 2ull;
+__device__ __forceinline__ unsigned long long scan_word(unsigned epoch, unsigned long long flag, unsigned long long v) {
+  return ((unsigned long long)epoch << 34) | (flag << 32) | (v > kScanSat ? kScanSat : v);
+}
+__global__ __launch_bounds__(256) void walk_scan_est_tail(EstimateOf est, uint32_t* __restrict__ off, int64_t n, unsigned long long* __restrict__ st,
+                                                          int64_t extra_waves, int64_t grid_waves, int* __restrict__ info, const TileTail tail) {
+  __shared__ unsigned s_b, s_epoch;
+  __shared__ unsigned long long s_wave[4], s_excl;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (tid == 0) {
-    // what the other groups left, past this compute unit's cache
-    const int wrapped = __hip_atomic_load(&info[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int wrapped2 = __hip_atomic_load(&info[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned long long total = (unsigned long long)(unsigned)__hip_atomic_load(&info[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    int out[8] = {0, wrapped, wrapped2, 0, 0, 0, 0, 0};
-    out[0] = (int)total;
-    // walk_tile_total's arithmetic (a total clipped to 2^31 - 1 has raised the flag already)
-    unsigned long long want = (total + (unsigned long long)extra_waves - 1) / (unsigned long long)extra_waves;
-    uint32_t budget = kTileBudget >> est.shift;
-    if (budget < 64) budget = 64;
-    while (budget < want && budget < (1u << 30)) budget <<= 1;
-    out[3] = (int)budget;
-    if (total / budget + (unsigned long long)(n / 64) + 1 >= (unsigned long long)grid_waves) out[1] = 1;
-    out[4] = (int)gridDim.x;
+    s_epoch = (unsigned)__hip_atomic_load(&st[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (before the ticket: see above)
+    s_b = atomicAdd((unsigned*)&st[0], 1u);
+  }
+  __syncthreads();
+  const unsigned b = s_b, epoch = s_epoch;
+  unsigned long long* __restrict__ state = st + 2;
+  const int64_t i0 = ((int64_t)b * 256 + tid) * kScanPer;
+  uint32_t e[kScanPer];
+  unsigned long long tsum = 0ull;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) info[k] = out[k];
-    int v0 = 0, v1 = 0;
-    if (tail.verdict) {
-      const int m = tail.flags[kBvhNodes];
-      const bool ok = tail.flags[kBvhFallback] == 0 && tail.flags[kBvhBadIndex] == 0 && m > 0 && m <= tail.node_cap &&
-                      tail.flags[kBvhNodeCount] <= tail.node_cap &&
-                      (tail.level_end <= 0 || tail.bigcount[tail.level_end] == 0);
-      v0 = ok ? m : 0;
-      v1 = ok ? 1 : 0;
-      tail.verdict[0] = v0;
-      tail.verdict[1] = v1;
+  for (int k = 0; k < kScanPer; ++k) {
+    e[k] = i0 + k < n ? est((int)(i0 + k)) : 0u;
+    tsum += e[k];
+  }
+  unsigned long long inc = tsum;  // inclusive over the wave
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const unsigned long long o = (unsigned long long)__shfl_up((long long)inc, d, 64);
+    if (lane >= d) inc += o;
+  }
+  if (lane == 63) s_wave[wave] = inc;
+  __syncthreads();
+  unsigned long long before = 0ull, block_total = 0ull;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    if (w < wave) before += s_wave[w];
+    block_total += s_wave[w];
+  }
+  if (wave == 0) {
+    unsigned long long excl = 0ull;
+    if (b > 0) {
+      if (lane == 0) __hip_atomic_store(&state[b], scan_word(epoch, kScanAgg, block_total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (long long j = (long long)b - 1;; j -= 64) {  // 64 predecessors at a time, the nearest in lane 0
+        const long long idx = j - lane;
+        unsigned long long v = scan_word(epoch, kScanPrefix, 0ull);  // before the first work-group: an empty prefix
+        if (idx >= 0) {
+          int patience = 1 << 20;
+          for (;;) {  // (its owner holds an earlier ticket: it is on its way.  The states carry their own data: relaxed loads do)
+            v = __hip_atomic_load(&state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (((unsigned)(v >> 34) == epoch && ((v >> 32) & 3ull) != 0ull) || --patience <= 0) break;
+            __builtin_amdgcn_s_sleep(2);
+          }
+          if (patience <= 0) v = scan_word(epoch, kScanPrefix, kScanSat);  // give up: saturated, the walk will not run on this scan
+        }
+        const unsigned long long has_prefix = __builtin_amdgcn_ballot_w64(((v >> 32) & 3ull) == kScanPrefix);
+        const int stop = has_prefix ? __builtin_ctzll(has_prefix) : 63;  // lanes 0 .. stop count
+        unsigned long long part = lane <= stop ? (v & 0xFFFFFFFFull) : 0ull;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) part += (unsigned long long)__shfl_xor((long long)part, d, 64);
+        excl += part;
+        if (excl > kScanSat) excl = kScanSat;
+        if (has_prefix) break;
+      }
     }
-    if (tail.pack) {
-      tail.pack[0] = v0;
-      tail.pack[1] = v1;
-#pragma unroll
-      for (int k = 0; k < 8; ++k) tail.pack[2 + tail.flag_words + k] = out[k];
+    if (lane == 0) {
+      __hip_atomic_store(&state[b], scan_word(epoch, kScanPrefix, excl + block_total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_excl = excl;
     }
   }
-  if (tail.pack && tid < tail.flag_words) tail.pack[2 + tid] = my_flag;
-  __syncthreads();  // the flags are in registers or packed: the next build's counters may go
-  for (int k = tid; k < tail.clear_words; k += 256) tail.clear[k] = 0;
+  __syncthreads();
+  const unsigned long long excl = s_excl;
+  unsigned long long run = excl + before + (inc - tsum);
+#pragma unroll
+  for (int k = 0; k < kScanPer; ++k) {
+    if (i0 + k < n) off[i0 + k] = (uint32_t)run;
+    run += e[k];
+  }
+  if (b + 1 != gridDim.x) return;
+  if (tid == 0) {  // every group holds its ticket and has read the epoch: both may move on
+    __hip_atomic_store(&st[1], (unsigned long long)((epoch + 1u) & 0x3FFFFFFFu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&st[0], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  unsigned long long total = excl + block_total;
+  if (total > kScanSat) total = kScanSat;
+  const int wrapped = total > 0x7fffffffull ? 1 : 0;
+  tile_tail_duties(total, wrapped, wrapped, est.shift, n, extra_waves, grid_waves, (int)gridDim.x, info, tail, tid);
 }
 
 inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -1104,6 +1213,10 @@ WalkSplitLayout walk_split_layout(int64_t n_tgt) {
   const size_t n = (size_t)(n_tgt > 0 ? n_tgt : 1);
   size_t o = 0;
   auto take = [&](size_t b) { size_t r = o; o += align_up(b); return r; };
+  // first, at the same place whatever n_tgt is (the caller zeroes it once per allocation): walk_scan_est_tail's ticket, epoch
+  // and one state per work-group of 1 024 targets, for up to kFusedScanMaxTargets of them
+  L.scan_state_bytes = 8 * (kFusedScanMaxTargets / (256 * kScanPer) + 4);
+  L.scan_state = take(L.scan_state_bytes);
   L.cnt = take(4 * n);
   L.off = take(4 * n);
   L.info = take(32);
@@ -1163,6 +1276,8 @@ hipError_t launch_tree_walk_tile_prep(hipStream_t s, const WalkArgs<T>& a, char*
     e = hipcub::DeviceScan::ExclusiveSum((void*)(scratch + L.cub_temp), tb, (const uint32_t*)cnt, off, (int)a.n_tgt, s);
     if (e != hipSuccess) return e;
     walk_check_wrap<<<dim3((unsigned)((a.n_tgt + 255) / 256)), dim3(256), 0, s>>>(cnt, off, a.n_tgt, info);
+  } else if (tail && tail->fused_scan) {
+    // (everything is done by the one kernel launched below)
   } else {
     hipcub::CountingInputIterator<int> idx(0);
     hipcub::TransformInputIterator<uint32_t, EstimateOf, hipcub::CountingInputIterator<int>> est(idx, EstimateOf{estimate == 1 ? hist : nullptr, tgt_ids, shift});
@@ -1183,6 +1298,13 @@ hipError_t launch_tree_walk_tile_prep(hipStream_t s, const WalkArgs<T>& a, char*
   if (extra < 1) extra = 1;
   const int64_t twaves = extra + a.n_tgt / 64 + 4;  // upper bound of g(t) + 1 (budget >= ceil(total / extra))
   *grid_waves = twaves;
+  if (tail && tail->fused_scan && a.n_tgt > kFusedScanMaxTargets) return hipErrorInvalidValue;
+  if (tail && tail->fused_scan) {
+    const unsigned groups = (unsigned)((a.n_tgt + 256 * kScanPer - 1) / (256 * kScanPer));
+    walk_scan_est_tail<<<dim3(groups), dim3(256), 0, s>>>(EstimateOf{hist, tgt_ids, shift}, off, a.n_tgt, (unsigned long long*)(scratch + L.scan_state),
+                                                       extra, twaves, info, *tail);
+    return hipGetLastError();
+  }
   if (tail) {
     int64_t groups = a.n_tgt / 2048;  // (every group ends with an atomic on one counter: few groups, longer loops)
     groups = groups < 32 ? 32 : (groups > 128 ? 128 : groups);
