@@ -143,7 +143,7 @@ int env_int(const char* name, int dflt) {
 // How the direct kernel covers (n_tgt x n_src): enough waves to fill 256 CUs x 4 SIMDs x 8 waves.
 DirectConfig choose_direct_config(int64_t n_src, int64_t n_tgt, bool uniform = true) {
   DirectConfig c;
-  c.use_asm = env_int("NBODY_DIRECT_ASM", 1) != 0;
+  c.use_asm = env_int("NBODY_DIRECT_ASM", 2);
   // near/far split: 0.05 ms (65 536 bodies) to 0.16 ms (1 M) of preparation per step against 10 % of the pair work: it pays
   // from 65 536 x 65 536 pairs on (profiles/r03_nearfar_hash_grid.txt; the sort-based split of rounds 1-2 broke even at
   // twice that).  NBODY_DIRECT_NEARFAR: 0 never, 1 by size (default), 2 always.

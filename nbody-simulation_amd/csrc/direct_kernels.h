@@ -35,7 +35,7 @@ struct DirectArgs {
 struct DirectConfig {
   int tpt = 1;     // targets per thread: 1 or 2
   int gsplit = 1;  // source split over blockIdx.y
-  bool use_asm = true;  // hand-ordered 8-pair block (tpt 1)
+  int use_asm = 2;      // tpt 1: 0 the compiler's schedule, 1 the hand-ordered 8-pair block, 2 packed couples (two pairs per packed op)
   bool nearfar = true;  // per-step near/far split of the sources
 };
 

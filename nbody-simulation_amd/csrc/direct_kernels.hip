@@ -148,6 +148,80 @@ __device__ __forceinline__ void fast_block8(v2f t, float clamp, v2f& p0, v2f& p1
   }
 }
 
+// Eight FAST pairs for one target with EVERY multiply-add packed over two pairs (round 3; USE_ASM = 2, the default).
+// Measured (profiles/r01_valu_microbench_wallclock.txt, r03_pair_body_packed.txt): a wave issues one VALU instruction per
+// 4-cycle slot; plain f32 ops reach 2 cycles only when two waves' plain ops share a slot, which a body that mixes plain,
+// packed and transcendental ops hardly ever achieves (30.4 cycles per pair for the 7-instruction block above against 24
+// for the sum of its parts), whereas a packed op fills its slot alone.  So the sources of a tile sit in LDS as COUPLES
+// {xA, xB, yA, yB}; the block forms (xA - tx, xB - tx) and (yA - ty, yB - ty) (op_sel picks the target's coordinate for both
+// halves), squares, denominators and the accumulation are v_pk_mul / v_pk_fma over the couple, and only |dx| + |dy| (no abs
+// modifier on packed ops) and the reciprocal stay one per pair: per couple 7 packed + 2 adds + 2 v_rcp = 13 slots = 26
+// cycles per pair.  The accumulators hold the even and the odd sources' sums side by side; the caller adds the halves.
+// c0..c3 come in as couples of source positions and leave as the differences.  Temporaries: couple k has Q = v[40+4k:41+4k]
+// (squared distances), S = v[42+4k:43+4k] (sum, denominator, reciprocal).  bias2 = {2^-90, 2^-90} in an SGPR pair (free on a
+// packed op).  With per-body masses mi0..mi3 are couples of INVERSE masses and scale the denominators.
+template <bool UNIFORM, bool NOCLAMP>
+__device__ __forceinline__ void fast_block8p(v2f t, float clamp, unsigned long long bias2, v2f& x0, v2f& y0, v2f& x1, v2f& y1, v2f& x2,
+                                             v2f& y2, v2f& x3, v2f& y3, v2f mi0, v2f mi1, v2f mi2, v2f mi3, v2f& accx, v2f& accy) {
+#define NB_SUBX(X) "v_pk_add_f32 %[" #X "], %[" #X "], %[t] op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+#define NB_SUBY(Y) "v_pk_add_f32 %[" #Y "], %[" #Y "], %[t] op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+  asm volatile(NB_SUBX(x0) NB_SUBY(y0) NB_SUBX(x1) NB_SUBY(y1) NB_SUBX(x2) NB_SUBY(y2) NB_SUBX(x3) NB_SUBY(y3)
+               : [x0] "+v"(x0), [y0] "+v"(y0), [x1] "+v"(x1), [y1] "+v"(y1), [x2] "+v"(x2), [y2] "+v"(y2), [x3] "+v"(x3), [y3] "+v"(y3)
+               : [t] "v"(t));
+#undef NB_SUBX
+#undef NB_SUBY
+#define NB_SQ(K, Q) "v_pk_mul_f32 v[" Q "], %[x" #K "], %[x" #K "]\n\t"
+#define NB_SQ2(K, Q) "v_pk_fma_f32 v[" Q "], %[y" #K "], %[y" #K "], v[" Q "]\n\t"
+#define NB_SUM(K, SL, SH) "v_add_f32 v" SL ", |%[x" #K "l]|, |%[y" #K "l]|\n\tv_add_f32 v" SH ", |%[x" #K "h]|, |%[y" #K "h]|\n\t"
+#define NB_MAX(QL, QH) "v_max_f32 v" QL ", v" QL ", %[c]\n\tv_max_f32 v" QH ", v" QH ", %[c]\n\t"
+#define NB_DEN(S, Q) "v_pk_fma_f32 v[" S "], v[" S "], v[" Q "], %[b]\n\t"
+#define NB_MINV(K, S) "v_pk_mul_f32 v[" S "], v[" S "], %[m" #K "]\n\t"
+#define NB_RCP(SL, SH) "v_rcp_f32 v" SL ", v" SL "\n\tv_rcp_f32 v" SH ", v" SH "\n\t"
+#define NB_ACC(K, S) "v_pk_fma_f32 %[ax], %[x" #K "], v[" S "], %[ax]\n\tv_pk_fma_f32 %[ay], %[y" #K "], v[" S "], %[ay]\n\t"
+#define NB_HEAD NB_SQ(0, "40:41") NB_SQ(1, "44:45") NB_SQ(2, "48:49") NB_SQ(3, "52:53") NB_SQ2(0, "40:41") NB_SQ2(1, "44:45") NB_SQ2(2, "48:49") NB_SQ2(3, "52:53") \
+                NB_SUM(0, "42", "43") NB_SUM(1, "46", "47") NB_SUM(2, "50", "51") NB_SUM(3, "54", "55")
+#define NB_CLAMP NB_MAX("40", "41") NB_MAX("44", "45") NB_MAX("48", "49") NB_MAX("52", "53")
+#define NB_DENS NB_DEN("42:43", "40:41") NB_DEN("46:47", "44:45") NB_DEN("50:51", "48:49") NB_DEN("54:55", "52:53")
+#define NB_MINVS NB_MINV(0, "42:43") NB_MINV(1, "46:47") NB_MINV(2, "50:51") NB_MINV(3, "54:55")
+#define NB_TAIL NB_RCP("42", "43") NB_RCP("46", "47") NB_RCP("50", "51") NB_RCP("54", "55") NB_ACC(0, "42:43") NB_ACC(1, "46:47") NB_ACC(2, "50:51") NB_ACC(3, "54:55")
+#define NB_OPS                                                                                                                      \
+  [x0] "v"(x0), [y0] "v"(y0), [x1] "v"(x1), [y1] "v"(y1), [x2] "v"(x2), [y2] "v"(y2), [x3] "v"(x3), [y3] "v"(y3), [x0l] "v"(x0.x),   \
+      [x0h] "v"(x0.y), [y0l] "v"(y0.x), [y0h] "v"(y0.y), [x1l] "v"(x1.x), [x1h] "v"(x1.y), [y1l] "v"(y1.x), [y1h] "v"(y1.y),        \
+      [x2l] "v"(x2.x), [x2h] "v"(x2.y), [y2l] "v"(y2.x), [y2h] "v"(y2.y), [x3l] "v"(x3.x), [x3h] "v"(x3.y), [y3l] "v"(y3.x),        \
+      [y3h] "v"(y3.y), [b] "s"(bias2)
+#define NB_CLOB "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55"
+  if constexpr (UNIFORM && NOCLAMP) {
+    asm volatile(NB_HEAD NB_DENS NB_TAIL : [ax] "+v"(accx), [ay] "+v"(accy) : NB_OPS : NB_CLOB);
+  } else if constexpr (UNIFORM && !NOCLAMP) {
+    asm volatile(NB_HEAD NB_CLAMP NB_DENS NB_TAIL : [ax] "+v"(accx), [ay] "+v"(accy) : NB_OPS, [c] "v"(clamp) : NB_CLOB);
+  } else if constexpr (!UNIFORM && NOCLAMP) {
+    asm volatile(NB_HEAD NB_DENS NB_MINVS NB_TAIL
+                 : [ax] "+v"(accx), [ay] "+v"(accy)
+                 : NB_OPS, [m0] "v"(mi0), [m1] "v"(mi1), [m2] "v"(mi2), [m3] "v"(mi3)
+                 : NB_CLOB);
+  } else {
+    asm volatile(NB_HEAD NB_CLAMP NB_DENS NB_MINVS NB_TAIL
+                 : [ax] "+v"(accx), [ay] "+v"(accy)
+                 : NB_OPS, [c] "v"(clamp), [m0] "v"(mi0), [m1] "v"(mi1), [m2] "v"(mi2), [m3] "v"(mi3)
+                 : NB_CLOB);
+  }
+#undef NB_SQ
+#undef NB_SQ2
+#undef NB_SUM
+#undef NB_MAX
+#undef NB_DEN
+#undef NB_MINV
+#undef NB_RCP
+#undef NB_ACC
+#undef NB_HEAD
+#undef NB_CLAMP
+#undef NB_DENS
+#undef NB_MINVS
+#undef NB_TAIL
+#undef NB_OPS
+#undef NB_CLOB
+}
+
 // One EXACT pair: src/main.rs:236-252 operation by operation.
 __device__ __forceinline__ void exact_pair(float xi, float yi, float xj, float yj, float mj, float clamp, float& ax,
                                            float& ay) {
@@ -185,7 +259,7 @@ __device__ __forceinline__ void integrate_store(const DirectArgs& a, int t_local
 // direct_finish completes the step.  Bitwise reproducible.
 // Two-level summation: each wave sums its 256-source share of a tile on its own and then adds it to the running
 // total (one extra add per 256 pairs; at N = 1M the error drops from ~1e-4 to ~2e-6 of sum|term|).
-template <int TPT, bool UNIFORM, bool NOCLAMP, bool USE_ASM>
+template <int TPT, bool UNIFORM, bool NOCLAMP, int USE_ASM>  // USE_ASM: 0 the compiler's schedule, 1 the hand-ordered block, 2 the packed couples
 __global__ __launch_bounds__(256) void direct_fast(const DirectArgs a) {
   if (!gate_open(a)) return;
 
@@ -210,14 +284,17 @@ __global__ __launch_bounds__(256) void direct_fast(const DirectArgs a) {
     ay[k] = 0.f;
   }
   float clamp = a.clamp;
-  if constexpr (USE_ASM) asm volatile("v_mov_b32 %0, %1" : "=v"(clamp) : "s"(a.clamp));  // keep it in a VGPR
+  if constexpr (USE_ASM != 0) asm volatile("v_mov_b32 %0, %1" : "=v"(clamp) : "s"(a.clamp));  // keep it in a VGPR
+  // USE_ASM = 2: source s of the tile lives in couple s / 2 = {xA, xB, yA, yB}: x at float 4 (s / 2) + (s & 1), y two floats on
+  constexpr bool COUPLES = USE_ASM == 2;
+  auto tile_x = [](int s) { return COUPLES ? 4 * (s >> 1) + (s & 1) : 2 * s; };
 
   __shared__ __attribute__((aligned(16))) float2 tile_pos[TILE];
   __shared__ __attribute__((aligned(16))) float4 tile_mass4[UNIFORM ? 1 : TILE / 4];  // masses, four per element
   float* tile_mass = reinterpret_cast<float*>(tile_mass4);
   // the hand-ordered block multiplies the denominator by 1/m before the reciprocal (one class switch fewer than
   // multiplying the reciprocal by m afterwards); 1/0 = inf makes a zero-mass source contribute exactly 0
-  __shared__ __attribute__((aligned(16))) float4 tile_minv4[(UNIFORM || !USE_ASM) ? 1 : TILE / 4];
+  __shared__ __attribute__((aligned(16))) float4 tile_minv4[(UNIFORM || USE_ASM == 0) ? 1 : TILE / 4];
   float* tile_minv = reinterpret_cast<float*>(tile_minv4);
 
   // sources of this grid split: [g0, g1)
@@ -245,17 +322,45 @@ __global__ __launch_bounds__(256) void direct_fast(const DirectArgs a) {
         p = src[base + s];
         if (!UNIFORM) m = a.mass_all[base + s];
       }
-      tile_pos[s] = p;
+      float* tile_f = reinterpret_cast<float*>(tile_pos);
+      tile_f[tile_x(s)] = p.x;
+      tile_f[tile_x(s) + (COUPLES ? 2 : 1)] = p.y;
       if (!UNIFORM) tile_mass[s] = m;
-      if (!UNIFORM && USE_ASM) tile_minv[s] = 1.0f / m;
+      if (!UNIFORM && USE_ASM != 0) tile_minv[s] = 1.0f / m;
     }
     __syncthreads();
     const int lo = ws * SHARE;
     int hi = lo + SHARE;
     if (hi > cnt) hi = cnt > lo ? cnt : lo;
     int u = lo;
-    if constexpr (USE_ASM) {
-      static_assert(!USE_ASM || TPT == 1, "the hand-ordered block handles one target per thread");
+    if constexpr (USE_ASM == 2) {
+      static_assert(TPT == 1, "the packed block handles one target per thread");
+      // the wave's share of the tile, four couples per block; the accumulators keep the even and the odd sources' sums apart
+      v2f accx = {0.f, 0.f}, accy = {0.f, 0.f};
+      const v2f tgt = {xi[0], yi[0]};
+      unsigned long long bias2 = 0x1280000012800000ull;  // {2^-90, 2^-90}
+      asm volatile("" : "+s"(bias2));                    // (an SGPR pair, set once: not a literal per use)
+      for (; u + UNR <= hi; u += UNR) {
+        const v4f* src4 = reinterpret_cast<const v4f*>(&tile_pos[u]);
+        const v4f s0 = src4[0], s1 = src4[1], s2 = src4[2], s3 = src4[3];
+        v2f x0 = s0.xy, y0 = s0.zw, x1 = s1.xy, y1 = s1.zw, x2 = s2.xy, y2 = s2.zw, x3 = s3.xy, y3 = s3.zw;
+        v4f ma = {1.f, 1.f, 1.f, 1.f}, mb = ma;
+        if constexpr (!UNIFORM) {  // u is a multiple of 8: two ds_read_b128 fetch the eight inverse masses
+          ma = reinterpret_cast<const v4f*>(tile_minv4)[(u >> 2)];
+          mb = reinterpret_cast<const v4f*>(tile_minv4)[(u >> 2) + 1];
+        }
+        fast_block8p<UNIFORM, NOCLAMP>(tgt, clamp, bias2, x0, y0, x1, y1, x2, y2, x3, y3, ma.xy, ma.zw, mb.xy, mb.zw, accx, accy);
+      }
+      float bx = accx.x + accx.y, by = accy.x + accy.y;
+      const float* tile_f = reinterpret_cast<const float*>(tile_pos);
+      for (; u < hi; ++u) {
+        float m = UNIFORM ? 1.0f : tile_mass[u];
+        fast_pair<UNIFORM, NOCLAMP>(xi[0], yi[0], tile_f[tile_x(u)], tile_f[tile_x(u) + 2], m, clamp, bx, by);
+      }
+      ax[0] = __builtin_fmaf(bx, tm, ax[0]);
+      ay[0] = __builtin_fmaf(by, tm, ay[0]);
+    } else if constexpr (USE_ASM == 1) {
+      static_assert(TPT == 1, "the hand-ordered block handles one target per thread");
       // the wave's share of the tile, 8 sources per block, summed on its own (two-level summation); everything the
       // block touches stays in 64-bit register pairs so that no repacking moves surround the asm
       v2f accb = {0.f, 0.f};
@@ -433,7 +538,7 @@ __global__ __launch_bounds__(256) void weights_to_mass(const uint32_t* __restric
 }
 
 // ------------------------------------------------------------------------------------------------ host launchers
-template <int TPT, bool UNIFORM, bool NOCLAMP, bool USE_ASM>
+template <int TPT, bool UNIFORM, bool NOCLAMP, int USE_ASM>
 static void launch_fast_k(hipStream_t s, const DirectArgs& a, int n_gsplit) {
   dim3 grid((unsigned)((a.n_tgt + 64 * TPT - 1) / (64 * TPT)), (unsigned)n_gsplit);
   hipLaunchKernelGGL((direct_fast<TPT, UNIFORM, NOCLAMP, USE_ASM>), grid, dim3(256), 0, s, a);
@@ -443,19 +548,22 @@ hipError_t launch_direct_fast(hipStream_t s, const DirectArgs& a, const DirectCo
   if (a.n_tgt <= 0) return hipSuccess;
   const bool uni = a.uniform_mass > 0.f;
   const int tpt = c.tpt == 2 ? 2 : 1;
-  const bool use_asm = c.use_asm && tpt == 1;
+  const int use_asm = tpt == 1 ? c.use_asm : 0;
 #define NB_GO(T, U, N, A) launch_fast_k<T, U, N, A>(s, a, c.gsplit)
   if (tpt == 1) {
-    if (use_asm) {
-      if (uni) { if (noclamp) NB_GO(1, true, true, true); else NB_GO(1, true, false, true); }
-      else     { if (noclamp) NB_GO(1, false, true, true); else NB_GO(1, false, false, true); }
+    if (use_asm == 2) {
+      if (uni) { if (noclamp) NB_GO(1, true, true, 2); else NB_GO(1, true, false, 2); }
+      else     { if (noclamp) NB_GO(1, false, true, 2); else NB_GO(1, false, false, 2); }
+    } else if (use_asm == 1) {
+      if (uni) { if (noclamp) NB_GO(1, true, true, 1); else NB_GO(1, true, false, 1); }
+      else     { if (noclamp) NB_GO(1, false, true, 1); else NB_GO(1, false, false, 1); }
     } else {
-      if (uni) { if (noclamp) NB_GO(1, true, true, false); else NB_GO(1, true, false, false); }
-      else     { if (noclamp) NB_GO(1, false, true, false); else NB_GO(1, false, false, false); }
+      if (uni) { if (noclamp) NB_GO(1, true, true, 0); else NB_GO(1, true, false, 0); }
+      else     { if (noclamp) NB_GO(1, false, true, 0); else NB_GO(1, false, false, 0); }
     }
   } else {
-    if (uni) { if (noclamp) NB_GO(2, true, true, false); else NB_GO(2, true, false, false); }
-    else     { if (noclamp) NB_GO(2, false, true, false); else NB_GO(2, false, false, false); }
+    if (uni) { if (noclamp) NB_GO(2, true, true, 0); else NB_GO(2, true, false, 0); }
+    else     { if (noclamp) NB_GO(2, false, true, 0); else NB_GO(2, false, false, 0); }
   }
 #undef NB_GO
   return hipGetLastError();
