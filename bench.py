@@ -30,11 +30,20 @@ sys.path.insert(0, ROOT)
 
 N_BODIES = 1 << 20          # BASELINE.json configs[2]
 FLOPS_PER_PAIR = 14         # SURVEY §8d / DESIGN.md: algorithmic flops of one force-law evaluation
-# what the timed instantiation (equal masses, far sources: direct_fast<1,true,true,true>) executes per pair:
-# v_pk_add 2, v_mul 1, v_fmac 2, v_add 1, v_fmaak 2 (the 2^-90 bias rides in its addend), v_rcp 1, v_pk_fma 4 = 13; against the
-# 14 algorithmic ones the mass multiply is hoisted out of the sum and the clamp is dropped for far sources (-2), the
-# bias add is extra (+1)
+# what the timed kernel (equal masses, far sources: direct_stream, packed couples) executes per pair: v_pk_add 2 x 1/2 x 2 = 2,
+# v_pk_mul 1, v_pk_fma 2 (the squares), v_add 1, v_pk_fma 2 (the denominator; the 2^-90 bias rides in its addend), v_rcp 1, two
+# v_pk_fma 4 = 13; against the 14 algorithmic ones the mass multiply is hoisted out of the sum and the clamp is dropped for far
+# sources (-2), the bias add is extra (+1)
 FLOPS_EXECUTED_PER_PAIR = 13
+
+
+def _main_pass_kernel(uniform=True):
+    """Name of the direct step's dominant kernel as the library picks it (capi.hip choose_direct_config, direct_kernels.hip
+    launch_direct_fast): NBODY_DIRECT_ASM 3 (default) streams the far sources of equal masses / mass classes through SGPRs."""
+    mode = int(os.environ.get("NBODY_DIRECT_ASM", "3") or 3)
+    if mode >= 3 and uniform:
+        return "nbody::direct_stream"
+    return "nbody::direct_fast<1,%s,true,%d>" % ("true" if uniform else "false", min(max(mode, 0), 2))
 PEAK_F32_TFLOPS = 157.3     # MI355X_MICROARCH.md: peak FP32 vector (= FP32 matrix) rate
 PEAK_F64_TFLOPS = 78.6      # FP64 vector: half the FP32 vector rate (256 CU x 2.4 GHz x 128 flop/clk/CU; AMD's MI355X figure)
 DT = 0.1                    # STEP_SIZE, main.rs:34
@@ -167,7 +176,7 @@ def _cpu_tree_steps(pos, vel, w, kind_name, theta, order_mode, steps):
                       f"(oracle/nbody_oracle.cpp, {'-march=native' if native else '-march=x86-64-v3'}; Counting split as main.rs:402/417/424)"}
 
 
-def _direct_leg(nb, name, workload, pos, vel, w, steps, profile_name, executed=None, cpu_targets=8192, kernel="nbody::direct_fast"):
+def _direct_leg(nb, name, workload, pos, vel, w, steps, profile_name, executed=None, cpu_targets=8192, kernel=None):
     """A direct-sum leg through the context path (nbody_update_direct_f32), timed like the headline."""
     C = nb._capi
     n = pos.shape[0]
@@ -185,7 +194,7 @@ def _direct_leg(nb, name, workload, pos, vel, w, steps, profile_name, executed=N
     pairs = float(n) * n
     kms_per_launch = kms                      # nbody_timer_read: average ms per timed region (one region = one step's main pass)
     ach = FLOPS_PER_PAIR * pairs / (kms_per_launch * 1e-3) / 1e12 if kms > 0 else 0.0
-    roof = {"bound": "valu_f32", "bound_class": "compute", "kernel": kernel, "achieved": ach, "peak": PEAK_F32_TFLOPS,
+    roof = {"bound": "valu_f32", "bound_class": "compute", "kernel": kernel or _main_pass_kernel(), "achieved": ach, "peak": PEAK_F32_TFLOPS,
             "unit": "TFLOP/s", "frac": ach / PEAK_F32_TFLOPS, "flops_per_pair": FLOPS_PER_PAIR, "pairs_per_launch": pairs,
             "kernel_ms": kms, "launches_timed": kl}
     if executed:
@@ -316,7 +325,7 @@ def _headline_roofline(n, n_tgt, kern_ms, kern_launches, steps, single_gpu_full)
     n_launch = max(1, kern_launches // max(1, steps))      # launches of the dominant kernel per step (= chunks)
     flops_per_launch = FLOPS_PER_PAIR * float(n) * float(n_tgt) / n_launch
     achieved = flops_per_launch / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
-    roof = {"bound": "valu_f32", "bound_class": "compute", "kernel": "nbody::direct_fast<1,true,true,true>", "achieved": achieved,
+    roof = {"bound": "valu_f32", "bound_class": "compute", "kernel": _main_pass_kernel(), "achieved": achieved,
             "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_TFLOPS,
             "flops_per_pair": FLOPS_PER_PAIR, "flops_executed_per_pair": FLOPS_EXECUTED_PER_PAIR,
             "frac_executed": achieved / PEAK_F32_TFLOPS * FLOPS_EXECUTED_PER_PAIR / FLOPS_PER_PAIR,

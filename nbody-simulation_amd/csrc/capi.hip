@@ -143,7 +143,7 @@ int env_int(const char* name, int dflt) {
 // How the direct kernel covers (n_tgt x n_src): enough waves to fill 256 CUs x 4 SIMDs x 8 waves.
 DirectConfig choose_direct_config(int64_t n_src, int64_t n_tgt, bool uniform = true) {
   DirectConfig c;
-  c.use_asm = env_int("NBODY_DIRECT_ASM", 2);
+  c.use_asm = env_int("NBODY_DIRECT_ASM", 3);
   // near/far split: 0.05 ms (65 536 bodies) to 0.16 ms (1 M) of preparation per step against 10 % of the pair work: it pays
   // from 65 536 x 65 536 pairs on (profiles/r03_nearfar_hash_grid.txt; the sort-based split of rounds 1-2 broke even at
   // twice that).  NBODY_DIRECT_NEARFAR: 0 never, 1 by size (default), 2 always.
@@ -284,6 +284,7 @@ struct DirectPlan {
   float sparse_base = 0.f;  // > 0: all masses equal this but a few bodies', which travel with the near list
   const State<float>::MassClasses* classes = nullptr;  // masses in a few classes: the far copy in class order, equal-mass arithmetic per tile
   bool nearfar = false;
+  bool couples = false;  // the far copy in couples {xA, xB, yA, yB}, padded to whole 16-source iterations (the packed kernels)
   int use_hazard = 0;
   size_t partial_bytes = 0;
 };
@@ -298,7 +299,11 @@ int direct_plan(nbody_ctx* c, int64_t n_src, const void* mass_all, float uniform
   DirectPlan p;
   p.arith = arith;
   p.uni = uniform_mass > 0.f && env_int("NBODY_DIRECT_NO_UNIFORM", 0) == 0;
-  p.nearfar = choose_direct_config(n_src, n_tgt_total, p.uni).nearfar;
+  {
+    const DirectConfig c0 = choose_direct_config(n_src, n_tgt_total, p.uni);
+    p.nearfar = c0.nearfar;
+    p.couples = c0.nearfar && c0.use_asm >= 2 && c0.tpt == 1;
+  }
   // uniform_mass < 0: every mass is -uniform_mass except a sparse set; the split hands those to direct_finish, so the
   // main pass runs at the equal-mass rate.  Without the split (small problems) the per-body-mass kernel is used.
   if (uniform_mass < 0.f && p.nearfar && env_int("NBODY_DIRECT_NO_UNIFORM", 0) == 0 && env_int("NBODY_DIRECT_NO_SPARSE", 0) == 0)
@@ -328,7 +333,7 @@ int direct_prep(nbody_ctx* c, hipStream_t stream, int64_t n_src, const void* pos
     const uint32_t* near_list = nullptr;
     HIPCHK(c, launch_nearfar(stream, (const float2*)pos_all, (const float*)mass_all, p.sparse_base, (int)n_src, clamp, p.use_hazard, flags,
                              nf_scratch, L, &pos_far, &near_list, p.classes ? p.classes->rank : nullptr,
-                             p.classes ? p.classes->pad_slots : nullptr, p.classes ? p.classes->n_pad_slots : 0));
+                             p.classes ? p.classes->pad_slots : nullptr, p.classes ? p.classes->n_pad_slots : 0, p.couples));
   } else {
     HIPCHK(c, launch_decide_simple(stream, p.use_hazard, flags));
   }
@@ -391,12 +396,14 @@ int direct_run(nbody_ctx* c, hipStream_t stream, int64_t n_src, const void* pos_
     if (cfg.nearfar) {  // state 0: main pass over the far sources without the clamp, near sources added by finish
       DirectArgs a0 = a;
       a0.src_pos = pos_far;
+      a0.src_couples = p.couples ? 1 : 0;
+      if (p.couples) a0.n_src = (int)far_padded(n_src);
       a0.near_list = near_list;
       a0.to_partial = 1;
       a0.run_state = 0;
       if (p.sparse_base > 0.f) a0.uniform_mass = p.sparse_base;  // the odd masses sit in the near list (state 1 reads them all)
       if (p.classes) {  // the far copy is in class order, padded: the equal-mass instantiation, a tile's mass in its closing FMA
-        a0.n_src = (int)p.classes->n_slots;
+        a0.n_src = (int)(p.couples ? far_padded(p.classes->n_slots) : p.classes->n_slots);
         a0.uniform_mass = 1.0f;
         a0.tile_mass = p.classes->tile_mass;
       }

@@ -28,6 +28,7 @@ struct DirectArgs {
   const int* flags;    // decision words
   int run_state;       // the kernel runs only when flags[kFlagState] == run_state; < 0: always
   const uint32_t* near_list;  // near sources (ascending body index), count in flags[kFlagNearCount]
+  int src_couples;            // src_pos is in couples {xA, xB, yA, yB} (nearfar.hip, far_store<true>), n_src a multiple of kFarPad
   const float* tile_mass;     // mass classes (capi.hip): src_pos is ordered by mass class, every 1024-source tile holds ONE class
                               // (classes padded with far-away points) and tile_mass[tile] is its mass; null otherwise
 };
@@ -35,7 +36,8 @@ struct DirectArgs {
 struct DirectConfig {
   int tpt = 1;     // targets per thread: 1 or 2
   int gsplit = 1;  // source split over blockIdx.y
-  int use_asm = 2;      // tpt 1: 0 the compiler's schedule, 1 the hand-ordered 8-pair block, 2 packed couples (two pairs per packed op)
+  int use_asm = 3;      // tpt 1: 0 the compiler's schedule, 1 the hand-ordered 8-pair block, 2 packed couples (two pairs per packed op) through
+                        // LDS, 3 packed couples with the far sources streamed through SGPRs (equal masses, no clamp; otherwise as 2)
   bool nearfar = true;  // per-step near/far split of the sources
 };
 
@@ -48,9 +50,11 @@ NearFarLayout nearfar_layout(int64_t n_src);
 // slots of pad_slots hold no body and receive the far-away point.  The far copy then has n + n_pad_slots entries.
 constexpr int64_t kMaxMassClasses = 32;
 constexpr int64_t kDirectTile = 1024;
+constexpr int kFarPad = 16;  // a far copy in couples is padded with far-away points to a multiple of this many sources
+__host__ __device__ inline int64_t far_padded(int64_t n_slots) { return (n_slots + kFarPad - 1) / kFarPad * kFarPad; }
 hipError_t launch_nearfar(hipStream_t s, const float2* pos, const float* mass, float heavy_base, int n, float clamp, int use_hazard,
                           int* flags, char* scratch, const NearFarLayout& L, const float2** pos_far, const uint32_t** near_list,
-                          const uint32_t* rank = nullptr, const uint32_t* pad_slots = nullptr, int n_pad_slots = 0);
+                          const uint32_t* rank = nullptr, const uint32_t* pad_slots = nullptr, int n_pad_slots = 0, bool couples = false);
 hipError_t launch_decide_simple(hipStream_t s, int use_hazard, int* flags);
 
 hipError_t launch_direct_fast(hipStream_t s, const DirectArgs& a, const DirectConfig& c, bool noclamp);

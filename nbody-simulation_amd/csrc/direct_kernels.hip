@@ -323,8 +323,12 @@ __global__ __launch_bounds__(256) void direct_fast(const DirectArgs a) {
         if (!UNIFORM) m = a.mass_all[base + s];
       }
       float* tile_f = reinterpret_cast<float*>(tile_pos);
-      tile_f[tile_x(s)] = p.x;
-      tile_f[tile_x(s) + (COUPLES ? 2 : 1)] = p.y;
+      if (COUPLES && a.src_couples) {  // the far copy is in couples already: its image
+        tile_pos[s] = p;
+      } else {
+        tile_f[tile_x(s)] = p.x;
+        tile_f[tile_x(s) + (COUPLES ? 2 : 1)] = p.y;
+      }
       if (!UNIFORM) tile_mass[s] = m;
       if (!UNIFORM && USE_ASM != 0) tile_minv[s] = 1.0f / m;
     }
@@ -456,6 +460,114 @@ __global__ __launch_bounds__(256) void direct_fast(const DirectArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------ FAST, streamed
+// The far sources of the near/far split (equal masses or mass classes, no clamp) straight from memory through SGPRs: a packed
+// op takes an SGPR pair as a source at no cost (profiles/r03_pair_body_packed.txt, P1s), so the couples {xA, xB, yA, yB} that
+// nearfar.hip writes arrive by s_load_dwordx16 (four couples = one 8-pair block) and feed the subtractions directly.  No LDS
+// tile, no ds_read, no barrier, no tile prologue: what a wave issues per block is the 52 slots of the block itself.  The loop
+// is one asm statement with fixed registers (the compiler cannot see an asm's scalar load in flight, so nothing of it is left
+// to the compiler): two register sets, the next block's load issued as soon as the current one has arrived, the last (unused)
+// prefetch drained before the statement ends.  It reads one block past the range it is given: the far copy carries that slack.
+// Same arithmetic, same order of additions as direct_fast<1, true, true, 2>: the two give the same bits.
+#define NB_S_SUBX(D, S) "v_pk_add_f32 v[" D "], s[" S "], %[t] op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+#define NB_S_SUBY(D, S) "v_pk_add_f32 v[" D "], s[" S "], %[t] op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+#define NB_S_COUPLE_A(X, Y, XL, XH, YL, YH, Q, SL, SH)                                                     \
+  "v_pk_mul_f32 v[" Q "], v[" X "], v[" X "]\n\tv_pk_fma_f32 v[" Q "], v[" Y "], v[" Y "], v[" Q "]\n\t" \
+  "v_add_f32 v" SL ", |v" XL "|, |v" YL "|\n\tv_add_f32 v" SH ", |v" XH "|, |v" YH "|\n\t"
+#define NB_S_COUPLE_B(X, Y, Q, S, SL, SH)                                                                  \
+  "v_pk_fma_f32 v[" S "], v[" S "], v[" Q "], %[b]\n\tv_rcp_f32 v" SL ", v" SL "\n\tv_rcp_f32 v" SH ", v" SH "\n\t"
+#define NB_S_COUPLE_C(X, Y, S) "v_pk_fma_f32 %[ax], v[" X "], v[" S "], %[ax]\n\tv_pk_fma_f32 %[ay], v[" Y "], v[" S "], %[ay]\n\t"
+// one 8-pair block from the SGPR set that starts at s[B]: differences in v[24:39], Q / S of couple k in v[40+4k:43+4k]
+#define NB_S_BLOCK(S0, S1, S2, S3, S4, S5, S6, S7)                                                                                      \
+  NB_S_SUBX("24:25", S0) NB_S_SUBY("26:27", S1) NB_S_SUBX("28:29", S2) NB_S_SUBY("30:31", S3) NB_S_SUBX("32:33", S4) NB_S_SUBY("34:35", S5) \
+  NB_S_SUBX("36:37", S6) NB_S_SUBY("38:39", S7)                                                                                          \
+  NB_S_COUPLE_A("24:25", "26:27", "24", "25", "26", "27", "40:41", "42", "43") NB_S_COUPLE_A("28:29", "30:31", "28", "29", "30", "31", "44:45", "46", "47") \
+  NB_S_COUPLE_A("32:33", "34:35", "32", "33", "34", "35", "48:49", "50", "51") NB_S_COUPLE_A("36:37", "38:39", "36", "37", "38", "39", "52:53", "54", "55") \
+  NB_S_COUPLE_B("24:25", "26:27", "40:41", "42:43", "42", "43") NB_S_COUPLE_B("28:29", "30:31", "44:45", "46:47", "46", "47")             \
+  NB_S_COUPLE_B("32:33", "34:35", "48:49", "50:51", "50", "51") NB_S_COUPLE_B("36:37", "38:39", "52:53", "54:55", "54", "55")             \
+  NB_S_COUPLE_C("24:25", "26:27", "42:43") NB_S_COUPLE_C("28:29", "30:31", "46:47") NB_S_COUPLE_C("32:33", "34:35", "50:51") NB_S_COUPLE_C("36:37", "38:39", "54:55")
+// n16 >= 1 iterations of 16 sources from `src` (wave-uniform, 64-byte aligned)
+__device__ __forceinline__ void stream_chunk(v2f t, unsigned long long bias2, const void* src, int n16, v2f& accx, v2f& accy) {
+  asm volatile(
+      "s_mov_b64 s[68:69], %[p]\n\t"
+      "s_mov_b32 s70, %[n]\n\t"
+      "s_load_dwordx16 s[36:51], s[68:69], 0x0\n"
+      ".Lnb_stream_%=:\n\t"
+      "s_waitcnt lgkmcnt(0)\n\t"
+      "s_load_dwordx16 s[52:67], s[68:69], 0x40\n\t"
+      NB_S_BLOCK("36:37", "38:39", "40:41", "42:43", "44:45", "46:47", "48:49", "50:51")
+      "s_add_u32 s68, s68, 0x80\n\t"
+      "s_addc_u32 s69, s69, 0\n\t"
+      "s_waitcnt lgkmcnt(0)\n\t"
+      "s_load_dwordx16 s[36:51], s[68:69], 0x0\n\t"
+      NB_S_BLOCK("52:53", "54:55", "56:57", "58:59", "60:61", "62:63", "64:65", "66:67")
+      "s_sub_u32 s70, s70, 1\n\t"
+      "s_cmp_lg_u32 s70, 0\n\t"
+      "s_cbranch_scc1 .Lnb_stream_%=\n\t"
+      "s_waitcnt lgkmcnt(0)\n\t"
+      : [ax] "+v"(accx), [ay] "+v"(accy)
+      : [t] "v"(t), [b] "s"(bias2), [p] "s"(src), [n] "s"(n16)
+      : "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42",
+        "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "s36", "s37", "s38", "s39", "s40", "s41",
+        "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60",
+        "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "scc", "memory");
+}
+#undef NB_S_SUBX
+#undef NB_S_SUBY
+#undef NB_S_COUPLE_A
+#undef NB_S_COUPLE_B
+#undef NB_S_COUPLE_C
+#undef NB_S_BLOCK
+
+// Block = 4 waves sharing 64 targets; wave w takes sources [256 w, 256 w + 256) of every 1024-source tile of its grid split —
+// the assignment and the two-level summation of direct_fast, so the sums are the same.
+__global__ __launch_bounds__(256) void direct_stream(const DirectArgs a) {
+  if (!gate_open(a)) return;
+  constexpr int TILE = 1024, SHARE = 256;
+  const int lane = threadIdx.x & 63;
+  const int ws = wave_id_uniform();
+  const int t = blockIdx.x * 64 + lane;
+  const float2 pt = (t < a.n_tgt) ? a.pos_all[a.tgt_begin + t] : make_float2(0.f, 0.f);
+  const v2f tgt = {pt.x, pt.y};
+  float ax = 0.f, ay = 0.f;
+  int gchunk = (a.n_src + (int)gridDim.y - 1) / (int)gridDim.y;
+  gchunk = (gchunk + 31) & ~31;
+  const float* __restrict__ class_mass = a.tile_mass;
+  if (class_mass) gchunk = (gchunk + TILE - 1) & ~(TILE - 1);
+  long g0l = (long)blockIdx.y * gchunk;
+  const int g0 = g0l < a.n_src ? (int)g0l : a.n_src;
+  const int g1 = (g0 + gchunk < a.n_src) ? g0 + gchunk : a.n_src;
+  unsigned long long bias2 = 0x1280000012800000ull;  // {2^-90, 2^-90}
+  for (int base = g0; base < g1; base += TILE) {
+    const int cnt = (g1 - base < TILE) ? g1 - base : TILE;
+    const float tm = class_mass ? class_mass[base / TILE] : 1.0f;
+    const int lo = ws * SHARE;
+    int hi = lo + SHARE;
+    if (hi > cnt) hi = cnt > lo ? cnt : lo;
+    v2f accx = {0.f, 0.f}, accy = {0.f, 0.f};
+    const int n16 = __builtin_amdgcn_readfirstlane((hi - lo) >> 4);  // (n_src, hence every bound here, is a multiple of 16)
+    if (n16 > 0) stream_chunk(tgt, bias2, reinterpret_cast<const char*>(a.src_pos) + (size_t)(base + lo) * 8, n16, accx, accy);
+    const float bx = accx.x + accx.y, by = accy.x + accy.y;
+    ax = __builtin_fmaf(bx, tm, ax);
+    ay = __builtin_fmaf(by, tm, ay);
+  }
+  ax *= a.uniform_mass;
+  ay *= a.uniform_mass;
+  __shared__ float2 red[3][64];
+  if (ws > 0) red[ws - 1][lane] = make_float2(ax, ay);
+  __syncthreads();
+  if (ws > 0) return;
+#pragma unroll
+  for (int w = 0; w < 3; ++w) {
+    float2 r = red[w][lane];
+    ax += r.x;
+    ay += r.y;
+  }
+  if (t >= a.n_tgt) return;
+  if (a.to_partial) a.partial[(size_t)blockIdx.y * a.n_tgt + t] = make_float2(ax, ay);
+  else integrate_store(a, t, ax, ay);
+}
+
 // Completes a step whose main pass wrote partial sums: adds the grid-split partials in ascending split order,
 // then (near/far split) the near sources with the clamp, in ascending body index, then integrates.
 __global__ __launch_bounds__(256) void direct_finish(const DirectArgs a, int n_gsplit, int add_near) {
@@ -549,9 +661,14 @@ hipError_t launch_direct_fast(hipStream_t s, const DirectArgs& a, const DirectCo
   const bool uni = a.uniform_mass > 0.f;
   const int tpt = c.tpt == 2 ? 2 : 1;
   const int use_asm = tpt == 1 ? c.use_asm : 0;
+  if (a.src_couples && (use_asm < 2 || (a.n_src % kFarPad) != 0)) return hipErrorInvalidValue;  // only the packed kernels read couples
+  if (use_asm == 3 && uni && noclamp && a.src_couples) {
+    hipLaunchKernelGGL(direct_stream, dim3((unsigned)((a.n_tgt + 63) / 64), (unsigned)c.gsplit), dim3(256), 0, s, a);
+    return hipGetLastError();
+  }
 #define NB_GO(T, U, N, A) launch_fast_k<T, U, N, A>(s, a, c.gsplit)
   if (tpt == 1) {
-    if (use_asm == 2) {
+    if (use_asm >= 2) {
       if (uni) { if (noclamp) NB_GO(1, true, true, 2); else NB_GO(1, true, false, 2); }
       else     { if (noclamp) NB_GO(1, false, true, 2); else NB_GO(1, false, false, 2); }
     } else if (use_asm == 1) {

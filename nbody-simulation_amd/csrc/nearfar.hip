@@ -128,13 +128,29 @@ __global__ __launch_bounds__(256) void nf_mark(const float2* __restrict__ pos, i
 
 // The near list (ascending body index: the near sum has a fixed order) and the far copy of the positions.
 // With mass classes the far copy is written in class order (rank[i]) and the threads past n fill the padding slots.
+// COUPLES (the packed direct kernels): slot s of the far copy lives in couple s / 2 = {xA, xB, yA, yB} — x at float
+// 4 (s / 2) + (s & 1), y two floats on — and the slots from n_slots up to the next multiple of kFarPad hold the far-away point,
+// so the main pass reads whole 16-source iterations.
+template <bool COUPLES>
+__device__ __forceinline__ void far_store(float2* __restrict__ pos_far, uint32_t slot, float2 p) {
+  if constexpr (COUPLES) {
+    float* f = reinterpret_cast<float*>(pos_far) + 4 * (size_t)(slot >> 1) + (slot & 1u);
+    f[0] = p.x;
+    f[2] = p.y;
+  } else {
+    pos_far[slot] = p;
+  }
+}
+template <bool COUPLES>
 __global__ __launch_bounds__(256) void nf_compact(const float2* __restrict__ pos, const uint32_t* __restrict__ is_near,
                                                   const uint32_t* __restrict__ scan, int n, float2* __restrict__ pos_far,
                                                   uint32_t* __restrict__ near_list, const uint32_t* __restrict__ rank,
-                                                  const uint32_t* __restrict__ pad_slots, int n_pad_slots) {
+                                                  const uint32_t* __restrict__ pad_slots, int n_pad_slots, int n_slots) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) {
-    if (i - n < n_pad_slots) pos_far[pad_slots[i - n]] = make_float2(1e30f, 1e30f);
+    const int k = i - n;
+    if (k < n_pad_slots) far_store<COUPLES>(pos_far, pad_slots[k], make_float2(1e30f, 1e30f));
+    else if (COUPLES && k - n_pad_slots < (int)far_padded(n_slots) - n_slots) far_store<COUPLES>(pos_far, (uint32_t)(n_slots + k - n_pad_slots), make_float2(1e30f, 1e30f));
     return;
   }
   float2 p = pos[i];
@@ -142,7 +158,7 @@ __global__ __launch_bounds__(256) void nf_compact(const float2* __restrict__ pos
     near_list[scan[i]] = (uint32_t)i;
     p = make_float2(1e30f, 1e30f);
   }
-  pos_far[rank ? rank[i] : (uint32_t)i] = p;
+  far_store<COUPLES>(pos_far, rank ? rank[i] : (uint32_t)i, p);
 }
 
 // state: 0 = near/far split (no clamp in the main pass), 1 = single clamped pass, 2 = EXACT kernel.
@@ -182,7 +198,7 @@ NearFarLayout nearfar_layout(int64_t n_src) {
   L.is_near = off; off += align_up(n * 4);
   L.scan = off; off += align_up(n * 4);
   L.near_list = off; off += align_up(n * 4);
-  L.pos_far = off; off += align_up((n + (size_t)(kMaxMassClasses + 1) * (size_t)kDirectTile) * 8);  // (room for the mass classes' padding)
+  L.pos_far = off; off += align_up((n + (size_t)(kMaxMassClasses + 1) * (size_t)kDirectTile + 2 * kFarPad) * 8);  // (room for the mass classes' padding, the couples' padding and one iteration read ahead)
   L.cub_temp = off;
   size_t need_scan = 0;
   (void)hipcub::DeviceScan::ExclusiveSum(nullptr, need_scan, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)n, (hipStream_t) nullptr);
@@ -195,7 +211,7 @@ NearFarLayout nearfar_layout(int64_t n_src) {
 // Enqueues the split.  On return flags[kFlagState] is (will be) valid on the stream.
 hipError_t launch_nearfar(hipStream_t s, const float2* pos, const float* mass, float heavy_base, int n, float clamp, int use_hazard,
                           int* flags, char* scratch, const NearFarLayout& L, const float2** pos_far, const uint32_t** near_list,
-                          const uint32_t* rank, const uint32_t* pad_slots, int n_pad_slots) {
+                          const uint32_t* rank, const uint32_t* pad_slots, int n_pad_slots, bool couples) {
   uint32_t* table = (uint32_t*)(scratch + L.table_keys);
   uint32_t* is_near = (uint32_t*)(scratch + L.is_near);
   uint32_t* scan = (uint32_t*)(scratch + L.scan);
@@ -216,8 +232,13 @@ hipError_t launch_nearfar(hipStream_t s, const float2* pos, const float* mass, f
   e = hipcub::DeviceScan::ExclusiveSum(scratch + L.cub_temp, tb, is_near, scan, n, s);
   if (e != hipSuccess) return e;
   if ((int64_t)n_pad_slots > (kMaxMassClasses + 1) * kDirectTile) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(nf_compact, dim3((unsigned)((n + (rank ? n_pad_slots : 0) + 255) / 256)), dim3(256), 0, s, pos, is_near, scan, n, far, list,
-                     rank, pad_slots, rank ? n_pad_slots : 0);
+  const int n_pad = rank ? n_pad_slots : 0;
+  const int n_slots = n + n_pad;  // (mass classes: the padded class order; otherwise the bodies themselves)
+  const unsigned cblocks = (unsigned)((n + n_pad + (couples ? kFarPad : 0) + 255) / 256);
+  if (couples)
+    hipLaunchKernelGGL(nf_compact<true>, dim3(cblocks), dim3(256), 0, s, pos, is_near, scan, n, far, list, rank, pad_slots, n_pad, n_slots);
+  else
+    hipLaunchKernelGGL(nf_compact<false>, dim3(cblocks), dim3(256), 0, s, pos, is_near, scan, n, far, list, rank, pad_slots, n_pad, n_slots);
   hipLaunchKernelGGL(nf_decide, dim3(1), dim3(1), 0, s, is_near, scan, n, n / 64, use_hazard, flags);
   return hipGetLastError();
 }

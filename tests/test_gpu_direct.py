@@ -473,3 +473,27 @@ def test_mass_classes_follow_the_rows_through_a_tree_build(nb, orc, ctx, monkeyp
     ctx.update_direct(0.1, 3)
     pb = ctx.download()
     assert np.abs(pa[0].astype(np.float64) - pb[0]).max() <= 1e-3 and np.abs(pa[1].astype(np.float64) - pb[1]).max() <= 1e-3
+
+
+# ------------------------------------------------------------------ the main pass's variants (NBODY_DIRECT_ASM)
+@pytest.mark.parametrize("n", [65536 + 16 * 5 + 3, 131072, 200003])
+def test_packed_and_streamed_main_pass_agree(nb, orc, ctx, monkeypatch, n):
+    """NBODY_DIRECT_ASM: 0 the compiler's schedule, 1 the hand-ordered block (a pair per instruction), 2 packed couples (two
+    pairs per packed op) through LDS, 3 (default) the same with the far sources streamed through SGPRs.  All four within the
+    tolerance of the oracle; 2 and 3 share the arithmetic and the order of additions, hence the bits — with equal masses,
+    with mass classes, with n not a multiple of anything (the far copy's padding), coincident and near bodies included."""
+    C = nb._capi
+    pos, vel, w1 = nb.scenes.plummer(n, seed=51)
+    pos[100] = pos[200]                                      # coincident: contributes nothing
+    pos[300] = pos[400] + F32(0.0078125)                     # inside the clamp radius: near bodies
+    tg = np.arange(0, n, 41)
+    for w in (w1, (1 + np.arange(n) % 5).astype(np.uint32)):
+        ref64, norm, cpu32 = _refs(orc, pos, w, targets=tg)
+        got = {}
+        for mode in ("0", "1", "2", "3"):
+            monkeypatch.setenv("NBODY_DIRECT_ASM", mode)
+            ctx.set_params(arith=C.ARITH_AUTO, clamp=0.001)
+            ctx.upload(pos, vel, w)
+            got[mode] = ctx.accel_direct()
+            check_fast(got[mode][tg], ref64, norm, cpu32, label=f" NBODY_DIRECT_ASM={mode}")
+        assert np.array_equal(got["2"], got["3"])

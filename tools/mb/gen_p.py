@@ -26,7 +26,7 @@ def current(npairs=8):
     return P + M + F2 + A + K + R + F
 
 
-def packed(npairs=8, order="phase", bias="v", adds="add", rcp="rcp"):
+def packed(npairs=8, order="phase", bias="v", adds="add", rcp="rcp", prio=None):
     """Two pairs per packed op.  Couple c: SX = (xA, xB) = v[18+4c:19+4c], SY = (yA, yB) = v[20+4c:21+4c] (differences in
     place), Q = v[34+2c:35+2c], S = v[42+2c:43+2c]; accumulators v[8:9] (x of even | odd sources), v[10:11] (y)."""
     PX, PY, M, F2, A, K, R, FX, FY = [], [], [], [], [], [], [], [], []
@@ -54,6 +54,10 @@ def packed(npairs=8, order="phase", bias="v", adds="add", rcp="rcp"):
             R.append(f"v_rcp_f32_e32 v{s+1}, v{s+1}")
         FX.append(f"v_pk_fma_f32 v[8:9], v[{sx}:{sx+1}], v[{s}:{s+1}], v[8:9]")
         FY.append(f"v_pk_fma_f32 v[10:11], v[{sy}:{sy+1}], v[{s}:{s+1}], v[10:11]")
+    if order == "phase" and prio is not None:  # the adds at another priority than the rest
+        return PX + PY + M + F2 + [f"s_setprio {prio[0]}"] + A + [f"s_setprio {prio[1]}"] + K + R + FX + FY
+    if order == "adds_first" and prio is not None:  # the NEXT block's adds cannot move up; the adds open the block
+        return [f"s_setprio {prio[0]}"] + A + [f"s_setprio {prio[1]}"] + PX + PY + M + F2 + K + R + FX + FY
     if order == "phase":
         return PX + PY + M + F2 + A + K + R + FX + FY
     if order == "couple":  # couple by couple
@@ -83,8 +87,9 @@ V["P1r packed, rcp spread over the fmas"] = packed(order="rcp_spread")
 V["P2 packed, adds -> v_max (model probe)"] = packed(adds="max")
 V["P3 packed, adds -> one pk_add (model probe)"] = packed(adds="pk")
 V["P4 packed, no rcp (model probe)"] = packed(rcp="none")
-V["P5 packed 16 pairs"] = None  # placeholder (kept out)
-del V["P5 packed 16 pairs"]
+V["Q1 packed, adds at LOW priority (1 elsewhere)"] = packed(bias="s", prio=(0, 1))
+V["Q2 packed, adds at HIGH priority (0 elsewhere)"] = packed(bias="s", prio=(1, 0))
+V["Q3 packed, adds at prio 0, rest at 3"] = packed(bias="s", prio=(0, 3))
 
 regs = list(range(6, 12)) + [14, 15] + list(range(18, 58))
 CLOB = ",".join(f'"v{r}"' for r in regs) + ',"s20","s21"'
