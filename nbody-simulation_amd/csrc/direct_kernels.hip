@@ -158,7 +158,8 @@ __device__ __forceinline__ void fast_block8(v2f t, float clamp, v2f& p0, v2f& p1
 // modifier on packed ops) and the reciprocal stay one per pair: per couple 7 packed + 2 adds + 2 v_rcp = 13 slots = 26
 // cycles per pair.  The accumulators hold the even and the odd sources' sums side by side; the caller adds the halves.
 // c0..c3 come in as couples of source positions and leave as the differences.  Temporaries: couple k has Q = v[40+4k:41+4k]
-// (squared distances), S = v[42+4k:43+4k] (sum, denominator, reciprocal).  bias2 = {2^-90, 2^-90} in an SGPR pair (free on a
+// (squared distances), S = v[42+4k:43+4k] (sum, denominator, reciprocal).  The eight plain adds issue at wave priority 0, the rest
+// at 1, so that the adds of different waves pair up in a slot (see direct_stream below).  bias2 = {2^-90, 2^-90} in an SGPR pair (free on a
 // packed op).  With per-body masses mi0..mi3 are couples of INVERSE masses and scale the denominators.
 template <bool UNIFORM, bool NOCLAMP>
 __device__ __forceinline__ void fast_block8p(v2f t, float clamp, unsigned long long bias2, v2f& x0, v2f& y0, v2f& x1, v2f& y1, v2f& x2,
@@ -179,7 +180,7 @@ __device__ __forceinline__ void fast_block8p(v2f t, float clamp, unsigned long l
 #define NB_RCP(SL, SH) "v_rcp_f32 v" SL ", v" SL "\n\tv_rcp_f32 v" SH ", v" SH "\n\t"
 #define NB_ACC(K, S) "v_pk_fma_f32 %[ax], %[x" #K "], v[" S "], %[ax]\n\tv_pk_fma_f32 %[ay], %[y" #K "], v[" S "], %[ay]\n\t"
 #define NB_HEAD NB_SQ(0, "40:41") NB_SQ(1, "44:45") NB_SQ(2, "48:49") NB_SQ(3, "52:53") NB_SQ2(0, "40:41") NB_SQ2(1, "44:45") NB_SQ2(2, "48:49") NB_SQ2(3, "52:53") \
-                NB_SUM(0, "42", "43") NB_SUM(1, "46", "47") NB_SUM(2, "50", "51") NB_SUM(3, "54", "55")
+                "s_setprio 0\n\t" NB_SUM(0, "42", "43") NB_SUM(1, "46", "47") NB_SUM(2, "50", "51") NB_SUM(3, "54", "55") "s_setprio 1\n\t"
 #define NB_CLAMP NB_MAX("40", "41") NB_MAX("44", "45") NB_MAX("48", "49") NB_MAX("52", "53")
 #define NB_DENS NB_DEN("42:43", "40:41") NB_DEN("46:47", "44:45") NB_DEN("50:51", "48:49") NB_DEN("54:55", "52:53")
 #define NB_MINVS NB_MINV(0, "42:43") NB_MINV(1, "46:47") NB_MINV(2, "50:51") NB_MINV(3, "54:55")
@@ -344,6 +345,7 @@ __global__ __launch_bounds__(256) void direct_fast(const DirectArgs a) {
       const v2f tgt = {xi[0], yi[0]};
       unsigned long long bias2 = 0x1280000012800000ull;  // {2^-90, 2^-90}
       asm volatile("" : "+s"(bias2));                    // (an SGPR pair, set once: not a literal per use)
+      __builtin_amdgcn_s_setprio(1);                     // the block's plain adds run at priority 0 (see direct_stream)
       for (; u + UNR <= hi; u += UNR) {
         const v4f* src4 = reinterpret_cast<const v4f*>(&tile_pos[u]);
         const v4f s0 = src4[0], s1 = src4[1], s2 = src4[2], s3 = src4[3];
@@ -469,11 +471,14 @@ __global__ __launch_bounds__(256) void direct_fast(const DirectArgs a) {
 // to the compiler): two register sets, the next block's load issued as soon as the current one has arrived, the last (unused)
 // prefetch drained before the statement ends.  It reads one block past the range it is given: the far copy carries that slack.
 // Same arithmetic, same order of additions as direct_fast<1, true, true, 2>: the two give the same bits.
+// Wave priority: the eight plain adds of a block (|dx| + |dy|: packed ops have no abs modifier) issue at priority 0, everything
+// else at 1.  A lone plain op takes a whole 4-cycle slot; two waves' plain ops can share one, but the arbiter only pairs
+// them when no wave has anything else to issue — at the lower priority the adds wait until every wave of the SIMD is at
+// its adds, and then go two to a slot: 13 -> 12 slots per couple (profiles/r03_pair_body_packed.txt, Q1: 26.1 -> 24.7 cycles).
 #define NB_S_SUBX(D, S) "v_pk_add_f32 v[" D "], s[" S "], %[t] op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
 #define NB_S_SUBY(D, S) "v_pk_add_f32 v[" D "], s[" S "], %[t] op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
-#define NB_S_COUPLE_A(X, Y, XL, XH, YL, YH, Q, SL, SH)                                                     \
-  "v_pk_mul_f32 v[" Q "], v[" X "], v[" X "]\n\tv_pk_fma_f32 v[" Q "], v[" Y "], v[" Y "], v[" Q "]\n\t" \
-  "v_add_f32 v" SL ", |v" XL "|, |v" YL "|\n\tv_add_f32 v" SH ", |v" XH "|, |v" YH "|\n\t"
+#define NB_S_COUPLE_A(X, Y, Q) "v_pk_mul_f32 v[" Q "], v[" X "], v[" X "]\n\tv_pk_fma_f32 v[" Q "], v[" Y "], v[" Y "], v[" Q "]\n\t"
+#define NB_S_COUPLE_S(XL, XH, YL, YH, SL, SH) "v_add_f32 v" SL ", |v" XL "|, |v" YL "|\n\tv_add_f32 v" SH ", |v" XH "|, |v" YH "|\n\t"
 #define NB_S_COUPLE_B(X, Y, Q, S, SL, SH)                                                                  \
   "v_pk_fma_f32 v[" S "], v[" S "], v[" Q "], %[b]\n\tv_rcp_f32 v" SL ", v" SL "\n\tv_rcp_f32 v" SH ", v" SH "\n\t"
 #define NB_S_COUPLE_C(X, Y, S) "v_pk_fma_f32 %[ax], v[" X "], v[" S "], %[ax]\n\tv_pk_fma_f32 %[ay], v[" Y "], v[" S "], %[ay]\n\t"
@@ -481,8 +486,11 @@ __global__ __launch_bounds__(256) void direct_fast(const DirectArgs a) {
 #define NB_S_BLOCK(S0, S1, S2, S3, S4, S5, S6, S7)                                                                                      \
   NB_S_SUBX("24:25", S0) NB_S_SUBY("26:27", S1) NB_S_SUBX("28:29", S2) NB_S_SUBY("30:31", S3) NB_S_SUBX("32:33", S4) NB_S_SUBY("34:35", S5) \
   NB_S_SUBX("36:37", S6) NB_S_SUBY("38:39", S7)                                                                                          \
-  NB_S_COUPLE_A("24:25", "26:27", "24", "25", "26", "27", "40:41", "42", "43") NB_S_COUPLE_A("28:29", "30:31", "28", "29", "30", "31", "44:45", "46", "47") \
-  NB_S_COUPLE_A("32:33", "34:35", "32", "33", "34", "35", "48:49", "50", "51") NB_S_COUPLE_A("36:37", "38:39", "36", "37", "38", "39", "52:53", "54", "55") \
+  NB_S_COUPLE_A("24:25", "26:27", "40:41") NB_S_COUPLE_A("28:29", "30:31", "44:45") NB_S_COUPLE_A("32:33", "34:35", "48:49") NB_S_COUPLE_A("36:37", "38:39", "52:53") \
+  "s_setprio 0\n\t"                                                                                                                    \
+  NB_S_COUPLE_S("24", "25", "26", "27", "42", "43") NB_S_COUPLE_S("28", "29", "30", "31", "46", "47")                                    \
+  NB_S_COUPLE_S("32", "33", "34", "35", "50", "51") NB_S_COUPLE_S("36", "37", "38", "39", "54", "55")                                    \
+  "s_setprio 1\n\t"                                                                                                                    \
   NB_S_COUPLE_B("24:25", "26:27", "40:41", "42:43", "42", "43") NB_S_COUPLE_B("28:29", "30:31", "44:45", "46:47", "46", "47")             \
   NB_S_COUPLE_B("32:33", "34:35", "48:49", "50:51", "50", "51") NB_S_COUPLE_B("36:37", "38:39", "52:53", "54:55", "54", "55")             \
   NB_S_COUPLE_C("24:25", "26:27", "42:43") NB_S_COUPLE_C("28:29", "30:31", "46:47") NB_S_COUPLE_C("32:33", "34:35", "50:51") NB_S_COUPLE_C("36:37", "38:39", "54:55")
@@ -515,6 +523,7 @@ __device__ __forceinline__ void stream_chunk(v2f t, unsigned long long bias2, co
 #undef NB_S_SUBX
 #undef NB_S_SUBY
 #undef NB_S_COUPLE_A
+#undef NB_S_COUPLE_S
 #undef NB_S_COUPLE_B
 #undef NB_S_COUPLE_C
 #undef NB_S_BLOCK
@@ -538,6 +547,7 @@ __global__ __launch_bounds__(256) void direct_stream(const DirectArgs a) {
   const int g0 = g0l < a.n_src ? (int)g0l : a.n_src;
   const int g1 = (g0 + gchunk < a.n_src) ? g0 + gchunk : a.n_src;
   unsigned long long bias2 = 0x1280000012800000ull;  // {2^-90, 2^-90}
+  __builtin_amdgcn_s_setprio(1);
   for (int base = g0; base < g1; base += TILE) {
     const int cnt = (g1 - base < TILE) ? g1 - base : TILE;
     const float tm = class_mass ? class_mass[base / TILE] : 1.0f;
