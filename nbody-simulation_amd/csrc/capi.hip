@@ -1175,7 +1175,8 @@ template <class T> int bvh_step_ahead(nbody_ctx* c, State<T>& s, T delta, PhaseE
     if (L.bigcount - L.flags + kBvhLevels * sizeof(int) > 128 * sizeof(int)) return 1;
     if (!c->spec_dev) {
       HIPCHK(c, hipMalloc((void**)&c->spec_dev, (2 + kSpecWords) * sizeof(int)));  // the verdict, then the record packed for the host
-      HIPCHK(c, hipHostMalloc((void**)&c->spec_host, kSpecWords * sizeof(int), hipHostMallocDefault));
+      HIPCHK(c, hipHostMalloc((void**)&c->spec_host, kSpecWords * sizeof(int), hipHostMallocMapped));
+      HIPCHK(c, hipHostGetDevicePointer((void**)&c->spec_host_dev, c->spec_host, 0));
       HIPCHK(c, hipEventCreateWithFlags(&c->spec_event, hipEventDisableTiming));
     }
     PhaseEvents ph;
@@ -1245,7 +1246,7 @@ template <class T> int bvh_step_ahead(nbody_ctx* c, State<T>& s, T delta, PhaseE
     tail.level_end = lv_end;
     tail.node_cap = L.node_cap;
     tail.verdict = c->spec_dev;
-    tail.pack = c->spec_dev + 2;
+    tail.pack = c->spec_host_dev;  // (straight into the host's pinned record: no copy on the stream)
     tail.clear = (int*)(s.bb_scratch + L.flags);
     tail.clear_words = (int)((L.zero_end - L.flags) / sizeof(int));
     tail.info_zeroed = true;
@@ -1254,13 +1255,11 @@ template <class T> int bvh_step_ahead(nbody_ctx* c, State<T>& s, T delta, PhaseE
     HIPCHK(c, launch_tree_walk_tile_prep<T>(c->stream, w, s.ws_scratch, WL, tgt_ids, s.wt_hist, 1, shift, &waves, &tail));
     s.bb_flags_clean = true;
     int* h = c->spec_host;
-    HIPCHK(c, hipMemcpyAsync(h, c->spec_dev + 2, (2 + 128 + 8) * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipEventRecord(c->spec_event, c->stream));
+    HIPCHK(c, hipEventRecord(c->spec_event, c->stream));  // (the tail kernel has written h[0 .. 2 + 128 + 8) by then)
     {
       TimerScope ts(c->timer, c->stream);
       HIPCHK(c, launch_tree_walk_tile_main<T>(c->stream, w, s.ws_scratch, WL, tgt_ids, s.wt_hist, waves));
     }
-    HIPCHK(c, hipMemcpyAsync(h + 2 + 128 + 8, walk_info, 8 * sizeof(int), hipMemcpyDeviceToHost, c->stream));  // read one step late
     rc = phase_mark(c, ph, 2);
     if (rc) return rc;
     // ---- the step's one wait: for the event in front of the walk kernel
@@ -1304,7 +1303,11 @@ template <class T> int bvh_step_ahead(nbody_ctx* c, State<T>& s, T delta, PhaseE
     } else {
       s.ahead_total_due = true;
     }
-    HIPCHK(c, launch_integrate<T>(c->stream, s.set[s.cur].pos, s.set[s.cur].vel, s.acc, s.n, delta));
+    Gate carry;  // the walk's info after the walk (its exact term count), read one step late: the integration's first threads take it along
+    carry.carry_src = walk_info;
+    carry.carry_dst = c->spec_host_dev + 2 + 128 + 8;
+    carry.carry_words = 8;
+    HIPCHK(c, launch_integrate<T>(c->stream, s.set[s.cur].pos, s.set[s.cur].vel, s.acc, s.n, delta, carry));
     rc = phase_mark(c, ph, 3);
     if (!rc) *chain = ph;  // the next step starts where this one ends
     return rc;

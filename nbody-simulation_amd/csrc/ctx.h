@@ -182,6 +182,7 @@ struct nbody_ctx {
   nbody_counting* ph_counter = nullptr;                // the caller's counter of the call in progress
   // a BVH step enqueued whole, ahead of the host's knowledge of its build (capi.hip, bvh_step_ahead)
   int* spec_dev = nullptr;    // [2] verdict of the build: node count or 0, ok
+  int* spec_host_dev = nullptr;  // spec_host as the device addresses it (kernels write the record there themselves)
   int* spec_host = nullptr;   // pinned: verdict [2] | build flags + level counters [128] | walk info before [8] and after [8] the walk
   hipEvent_t spec_event = nullptr;
 };

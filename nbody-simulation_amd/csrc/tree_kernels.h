@@ -42,6 +42,11 @@ template <class T> struct WalkArgs {
 struct Gate {
   const int* nonzero = nullptr;
   const int* zero = nullptr;
+  // a few words carried along by the kernel's first thread (a record the host reads later, written straight into its pinned
+  // memory: no copy kernel of its own on the stream)
+  const int* carry_src = nullptr;
+  int* carry_dst = nullptr;
+  int carry_words = 0;
 };
 
 template <class T> struct GatherArgs {

@@ -412,6 +412,7 @@ __global__ __launch_bounds__(256) void integrate_inplace(void* pos, void* vel, c
   using T2 = typename V2<T>::type;
   if ((gate.nonzero && *gate.nonzero == 0) || (gate.zero && *gate.zero != 0)) return;
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < gate.carry_words) gate.carry_dst[i] = gate.carry_src[i];
   if (i >= n) return;
   T2 v = reinterpret_cast<T2*>(vel)[i];
   T2 p = reinterpret_cast<T2*>(pos)[i];
