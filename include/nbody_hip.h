@@ -336,6 +336,10 @@ int nbody_selftest_exact_sum_f64(const double* x, int64_t n, int tile, int seq_r
 /* ... and its segmented form for long chains (runs prepared per segment for a predicted binade, used only when the
  * prediction and the run's bounds hold for the true state); *out_runs_used counts the runs that were applied. */
 int nbody_selftest_exact_sum_f64_segmented(const double* x, int64_t n, int seg, double* out_sum, int64_t* out_runs_used);
+/* The exact kernels divide by csrc/div_pair.h: (nx / den, ny / den), the two IEEE f32 divisions of main.rs:252 with their
+ * multiply-adds issued as packed instructions.  This runs it on device `device` over n host triples and hands the quotients
+ * back, so that a test can compare them bit for bit with the host's IEEE division (needs a GPU). */
+int nbody_selftest_div_pair(int device, const float* nx, const float* ny, const float* den, int64_t n, float* qx, float* qy);
 /* Restarts of that scan during the last device BVH build of this context (diagnostic; 0 after a host build). */
 int nbody_bvh_build_restarts(const nbody_ctx* ctx);
 /* 1 if the last tree build of this context ran on the device, 0 if the host builder did it (the device builders

@@ -119,6 +119,7 @@ _SIGS = {
     "nbody_selftest_exact_sum": (C.c_int, [_vp, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int64)]),
     "nbody_selftest_exact_sum_f64": (C.c_int, [_vp, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "nbody_selftest_exact_sum_f64_segmented": (C.c_int, [_vp, C.c_int64, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "nbody_selftest_div_pair": (C.c_int, [C.c_int, _vp, _vp, _vp, C.c_int64, _vp, _vp]),
     "nbody_selftest_exact_sum_chunked": (C.c_int, [_vp, C.c_int64, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int64)]),
     "nbody_bvh_build_restarts": (C.c_int, [_vp]),
     "nbody_last_build_on_device": (C.c_int, [_vp]),
@@ -248,6 +249,16 @@ def selftest_exact_sum_f64_segmented(x, seg=8192):
     out, used = C.c_double(0), _i64(0)
     check(None, load().nbody_selftest_exact_sum_f64_segmented(_ptr(x) if x.size else None, x.size, int(seg), C.byref(out), C.byref(used)))
     return np.float64(out.value), used.value
+
+
+def selftest_div_pair(nx, ny, den, device=0):
+    """csrc/div_pair.h on the device: (nx / den, ny / den) as the exact kernels compute them."""
+    nx, ny, den = (np.ascontiguousarray(a, np.float32) for a in (nx, ny, den))
+    assert nx.shape == ny.shape == den.shape and nx.ndim == 1
+    qx, qy = np.empty_like(nx), np.empty_like(nx)
+    if nx.size:
+        check(None, load().nbody_selftest_div_pair(int(device), _ptr(nx), _ptr(ny), _ptr(den), nx.size, _ptr(qx), _ptr(qy)))
+    return qx, qy
 
 
 def selftest_exact_sum_chunked(x, chunk=2048):

@@ -2196,6 +2196,22 @@ NB_API int nbody_selftest_exact_sum(const float* x, int64_t n, int tile, int seq
   *out_sum = xsum::emulate_fold(x, n, tile, seq_run, out_restarts);
   return NBODY_OK;
 }
+NB_API int nbody_selftest_div_pair(int device, const float* nx, const float* ny, const float* den, int64_t n, float* qx, float* qy) {
+  if (n < 0 || (n > 0 && (!nx || !ny || !den || !qx || !qy))) return NBODY_ERR_INVALID;
+  if (n == 0) return NBODY_OK;
+  if (hipSetDevice(device) != hipSuccess) return NBODY_ERR_NO_DEVICE;
+  float* d = nullptr;
+  const size_t b = (size_t)n * sizeof(float);
+  if (hipMalloc((void**)&d, 5 * b) != hipSuccess) return NBODY_ERR_HIP;
+  hipError_t e = hipMemcpy(d, nx, b, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d + n, ny, b, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d + 2 * n, den, b, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = launch_div_pair_selftest(nullptr, d, d + n, d + 2 * n, n, d + 3 * n, d + 4 * n);
+  if (e == hipSuccess) e = hipMemcpy(qx, d + 3 * n, b, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(qy, d + 4 * n, b, hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  return e == hipSuccess ? NBODY_OK : NBODY_ERR_HIP;
+}
 NB_API int nbody_selftest_exact_sum_chunked(const float* x, int64_t n, int chunk, float* out_sum, int64_t* out_runs_used) {
   if ((!x && n > 0) || n < 0 || chunk < 1 || !out_sum) return NBODY_ERR_INVALID;
   // segments of 8 addends per thread, as bvh_chunk_runs cuts a chunk

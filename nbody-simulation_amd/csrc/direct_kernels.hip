@@ -26,6 +26,7 @@
 #include <stdint.h>
 
 #include "direct_kernels.h"
+#include "div_pair.h"
 
 namespace nbody {
 
@@ -233,8 +234,9 @@ __device__ __forceinline__ void exact_pair(float xi, float yi, float xj, float y
   float distance = dx * dx + dy * dy;                     // :245
   distance = __builtin_fmaxf(distance, clamp);            // :247-249 (one v_max_f32; `distance` is never NaN after the is_normal test)
   float den = sum * distance;
-  ax = ax + (dx * mj) / den;                              // :252
-  ay = ay + (dy * mj) / den;
+  const float2 q = div_pair(dx * mj, dy * mj, den);       // :252 (div_pair.h: the two quotients, their multiply-adds packed)
+  ax = ax + q.x;
+  ay = ay + q.y;
 }
 
 // main.rs:419-423, no contraction (TU flag).

@@ -62,6 +62,7 @@ template <class T> struct GatherArgs {
 };
 
 template <class T> hipError_t launch_tree_walk(hipStream_t s, const WalkArgs<T>& a, bool wave_uniform);
+hipError_t launch_div_pair_selftest(hipStream_t s, const float* nx, const float* ny, const float* den, int64_t n, float* qx, float* qy);
 template <class T> hipError_t launch_gather(hipStream_t s, const GatherArgs<T>& a);
 template <class T> hipError_t launch_integrate(hipStream_t s, void* pos, void* vel, const void* acc, int64_t n, T delta, Gate gate = Gate{});
 

@@ -12,6 +12,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include "div_pair.h"
 #include "tree_kernels.h"
 
 namespace nbody {
@@ -49,8 +50,9 @@ __device__ __forceinline__ void pair_as_written<float>(float px, float py, float
   float distance = dx * dx + dy * dy;
   distance = __builtin_fmaxf(distance, clamp);
   float den = sum * distance;
-  ax = ax + (dx * force) / den;
-  ay = ay + (dy * force) / den;
+  const float2 q = div_pair(dx * force, dy * force, den);  // the two quotients of :252, their multiply-adds packed (div_pair.h)
+  ax = ax + q.x;
+  ay = ay + q.y;
 }
 
 // FAST pair for the walk (opt-in, nbody_arith FAST): one reciprocal instead of two IEEE divisions, fused
@@ -272,6 +274,10 @@ template <class T> __device__ __forceinline__ typename V2<T>::type pair_term_t(T
   T distance = dx * dx + dy * dy;
   distance = sizeof(T) == 8 ? (T)__builtin_fmax((double)distance, (double)clamp) : (T)__builtin_fmaxf((float)distance, (float)clamp);
   const T den = sum * distance;
+  if constexpr (sizeof(T) == 4) {
+    const float2 q = div_pair((float)(dx * force), (float)(dy * force), (float)den);
+    return T2{(T)q.x, (T)q.y};
+  }
   return T2{(dx * force) / den, (dy * force) / den};
 }
 
@@ -521,6 +527,19 @@ template <class T> hipError_t launch_tree_walk(hipStream_t s, const WalkArgs<T>&
   else if (lb >= 4) { if (pf) NB_W(4, true); else NB_W(4, false); }
   else { if (pf) NB_W(2, true); else NB_W(2, false); }
 #undef NB_W
+  return hipGetLastError();
+}
+__global__ __launch_bounds__(256) void div_pair_selftest(const float* __restrict__ nx, const float* __restrict__ ny, const float* __restrict__ den,
+                                                         int64_t n, float* __restrict__ qx, float* __restrict__ qy) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float2 q = div_pair(nx[i], ny[i], den[i]);
+  qx[i] = q.x;
+  qy[i] = q.y;
+}
+hipError_t launch_div_pair_selftest(hipStream_t s, const float* nx, const float* ny, const float* den, int64_t n, float* qx, float* qy) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(div_pair_selftest, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, nx, ny, den, n, qx, qy);
   return hipGetLastError();
 }
 template <class T> hipError_t launch_gather(hipStream_t s, const GatherArgs<T>& a) {

@@ -24,6 +24,7 @@
 #include <vector>
 
 #include "bvh_build.h"
+#include "div_pair.h"
 #include "walk_split.h"
 
 namespace nbody {
@@ -56,7 +57,7 @@ __device__ __forceinline__ float2 pair_term(float px, float py, float qx, float 
   // is never NaN here (a normal `sum` means finite dx, dy), and for a NaN clamp both forms keep `distance`
   distance = __builtin_fmaxf(distance, clamp);
   const float den = sum * distance;
-  return make_float2((dx * force) / den, (dy * force) / den);      // :252
+  return div_pair(dx * force, dy * force, den);                    // :252 (div_pair.h: the two quotients, packed)
 }
 // The same with a per-lane `valid` folded into the skip: a lane past the leaf's end yields -0.0 like a skipped pair, under
 // the one exec mask (a select afterwards costs two v_cndmask per round).
@@ -68,7 +69,7 @@ __device__ __forceinline__ float2 pair_term_if(bool valid, float px, float py, f
   float distance = dx * dx + dy * dy;
   distance = __builtin_fmaxf(distance, clamp);
   const float den = sum * distance;
-  return make_float2((dx * force) / den, (dy * force) / den);
+  return div_pair(dx * force, dy * force, den);
 }
 
 // nbody_arith FAST (opt-in, tolerance instead of bit parity): one reciprocal instead of two IEEE divisions; a zero difference

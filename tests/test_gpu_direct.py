@@ -497,3 +497,35 @@ def test_packed_and_streamed_main_pass_agree(nb, orc, ctx, monkeypatch, n):
             got[mode] = ctx.accel_direct()
             check_fast(got[mode][tg], ref64, norm, cpu32, label=f" NBODY_DIRECT_ASM={mode}")
         assert np.array_equal(got["2"], got["3"])
+
+
+# ------------------------------------------------------------------ the exact kernels' division (csrc/div_pair.h)
+def test_div_pair_is_the_ieee_division_bit_for_bit(nb):
+    """main.rs:252 divides a Vector2F by an f32: two IEEE divisions by one denominator.  The exact kernels run the compiler's
+    own expansion of `/` for both quotients with the multiply-adds issued as packed instructions (csrc/div_pair.h); the
+    quotients must be the host's IEEE quotients, bit for bit: random bit patterns (every exponent, both signs), denormal
+    operands and results, zeros, infinities, overflow and underflow; NaN results need only be NaN on both sides."""
+    rng = np.random.default_rng(52)
+    n = 1 << 20
+
+    def bits(k):
+        return rng.integers(0, 1 << 32, k, dtype=np.uint64).astype(np.uint32).view(F32)
+
+    def moderate(k):  # what the walks mostly see
+        return (rng.standard_normal(k) * 10.0 ** rng.integers(-6, 7, k)).astype(F32)
+
+    tiny, big = np.finfo(F32).tiny, np.finfo(F32).max
+    special = np.array([0.0, -0.0, tiny, -tiny, tiny / 2, 1e-45, -1e-45, big, -big, np.inf, -np.inf, np.nan, 1.0, -1.0, 3.0, 1.0 / 3.0,
+                        2.0 ** -126, 2.0 ** -149, 2.0 ** 127, 1.5 * 2.0 ** -126, 0.75 * 2.0 ** -126], F32)
+    g = np.meshgrid(special, special, special, indexing="ij")
+    nx = np.concatenate([bits(n), moderate(n), g[0].ravel(), bits(n) * F32(0) + moderate(n)])
+    ny = np.concatenate([bits(n), moderate(n), g[1].ravel(), bits(n)])
+    den = np.concatenate([bits(n), np.abs(moderate(n)), g[2].ravel(), np.abs(moderate(n)) * F32(1e-30)])
+    with np.errstate(all="ignore"):
+        ex, ey = nx / den, ny / den
+    qx, qy = nb._capi.selftest_div_pair(nx, ny, den)
+    for got, want, name in ((qx, ex, "x"), (qy, ey, "y")):
+        nan = np.isnan(want)
+        assert np.array_equal(np.isnan(got), nan), name
+        bad = (got.view(np.uint32) != want.view(np.uint32)) & ~nan
+        assert not bad.any(), (name, int(bad.sum()), nx[bad][:4], ny[bad][:4], den[bad][:4], got[bad][:4], want[bad][:4])
