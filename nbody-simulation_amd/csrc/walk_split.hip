@@ -381,7 +381,23 @@ __global__ __launch_bounds__(256) void walk_sum(const WalkArgs<float> a, const u
 // targets' particles (by id: the build permutes the rows) had in the PREVIOUS walk or, when there is none, of a
 // counting traversal.  A bad estimate costs balance, never correctness: each target's additions are the fused
 // walk's, in its order.  f32 and f64 (rows of 16-byte terms: half as many waves stay resident).
-template <class T, bool FAST, int TT>
+// A node's three records by SCALAR loads: the index is wave-uniform, but the compiler only picks s_load for memory it can prove
+// unwritten during the kernel, which it cannot here (the kernels store accelerations and history) — so plain loads become
+// vector loads of one address (a round trip through the vector L1 and 64 lanes' worth of return data for 48 bytes).  The tree was
+// written by the kernels BEFORE this one, so reading it through the constant address space is sound (as `off` is read).
+template <class T> struct NodeRec { int4 l; typename Vec4Of<T>::type b, c; };
+template <class T>
+__device__ __forceinline__ NodeRec<T> scalar_node_rec(const void* link, const void* geom0, const void* geom1, const int k) {
+  typedef int v4i __attribute__((ext_vector_type(4)));
+  typedef T v4t __attribute__((ext_vector_type(4)));
+  using T4 = typename Vec4Of<T>::type;
+  const v4i l = ((const v4i __attribute__((address_space(4)))*)link)[k];
+  const v4t b = ((const v4t __attribute__((address_space(4)))*)geom0)[k];
+  const v4t c = ((const v4t __attribute__((address_space(4)))*)geom1)[k];
+  return NodeRec<T>{int4{l.x, l.y, l.z, l.w}, T4{b.x, b.y, b.z, b.w}, T4{c.x, c.y, c.z, c.w}};
+}
+
+template <class T, bool FAST, int TT, bool SREC = false>
 __global__ __launch_bounds__(256) void walk_tile(const WalkArgs<T> a, const uint32_t* __restrict__ off, const int* __restrict__ info,
                                                  const uint32_t* __restrict__ tgt_ids, uint32_t* __restrict__ hist,
                                                  unsigned long long* __restrict__ total_out) {
@@ -522,9 +538,10 @@ __global__ __launch_bounds__(256) void walk_tile(const WalkArgs<T> a, const uint
     }
   };
   while (i < n_nodes) {  // i is wave-uniform
-    const int4 l = lk[i];
-    const T4 b = g0[i];
-    const T4 c = g1[i];
+    const NodeRec<T> rec = SREC ? scalar_node_rec<T>(a.link, a.geom0, a.geom1, i) : NodeRec<T>{lk[i], g0[i], g1[i]};
+    const int4 l = rec.l;
+    const T4 b = rec.b;
+    const T4 c = rec.c;
 #ifndef NB_TILE_LATE_GEOM
     asm volatile("" : : "s"(b.x), "s"(c.w));  // the three records together: one latency per step (the compiler sinks the two
                                               // it needs in the node arm only into that arm, behind the first one's wait)
@@ -540,22 +557,22 @@ __global__ __launch_bounds__(256) void walk_tile(const WalkArgs<T> a, const uint
       }
       next = l.x;
     } else {
-      bool descend = false;
-      if (act) {
-        const bool contains = p.y > b.y && p.x > b.x && p.x < b.z && p.y < b.w;  // bvh_tree.rs:15-20 (all strict)
-        const T ddx = p.x - c.x, ddy = p.y - c.y;                              // dist2(p, cog), main.rs:228-232
-        const T d2 = ddx * ddx + ddy * ddy;
-        if (!contains && c.w < d2 * theta * theta) {                               // :370-372
-          const T2 term = term_of<FAST>(p.x, p.y, c.x, c.y, c.z, clamp);           // :374-379
-          ax = ax + term.x;
-          ay = ay + term.y;
-          ++n_terms;
-          resume = l.x;
-        } else {
-          descend = true;                                                          // :381-382
-          resume = i + 1;
-        }
+      // The node test as straight-line code: compares and-ed as masks, selects instead of nested exec regions (what `if (act) { if
+      // (...) {...} else {...} }` compiles to: four s_and_saveexec / s_or exec pairs, their copies and branches — about half of the
+      // ≈ 100 instructions of a node step, which is what a wave that runs alone pays for: it issues one instruction per ≈ 8-15 cycles).
+      const bool contains = (p.y > b.y) & (p.x > b.x) & (p.x < b.z) & (p.y < b.w);  // bvh_tree.rs:15-20 (all strict)
+      const T ddx = p.x - c.x, ddy = p.y - c.y;                                   // dist2(p, cog), main.rs:228-232
+      const T d2 = ddx * ddx + ddy * ddy;
+      const bool accept = act & !contains & (c.w < d2 * theta * theta);              // :370-372
+      const bool descend = act & !accept;                                            // :381-382
+      if (__builtin_amdgcn_ballot_w64(accept) != 0) {  // (wave-uniform: the as-written term is two IEEE divisions)
+        const T2 term = term_of<FAST>(p.x, p.y, c.x, c.y, c.z, clamp);               // :374-379
+        const T nax = ax + term.x, nay = ay + term.y;
+        ax = accept ? nax : ax;
+        ay = accept ? nay : ay;
       }
+      n_terms += accept ? 1u : 0u;
+      resume = accept ? l.x : (descend ? i + 1 : resume);
       const unsigned long long dmask = __builtin_amdgcn_ballot_w64(descend);
       if (l.x - i == 3) {
         // A subtree of three nodes: both children are leaves and a lane that descends takes both, whole (main.rs:381-382:
@@ -781,7 +798,16 @@ __global__ __launch_bounds__(256) void walk_tile_fast(const WalkArgs<T> a, const
   asm volatile("v_mov_b32 %0, 0" : "=v"(lane_zero));
   auto fetch = [&](int k) -> Rec {
     k = k < last ? k : last;
-    if constexpr (REC == 0) return Rec{lk[k], g0[k], g1[k]};
+    if constexpr (REC == 3) {  // scalar loads through the constant address space (scalar_node_rec)
+      const NodeRec<T> r = scalar_node_rec<T>(a.link, a.geom0, a.geom1, k);
+      asm volatile("" : : "s"(r.b.x), "s"(r.c.w));  // the three records together, before anything branches on the first
+      return Rec{r.l, r.b, r.c};
+    }
+    if constexpr (REC == 0) {
+      const Rec r{lk[k], g0[k], g1[k]};
+      asm volatile("" : : "s"(r.b.x), "s"(r.c.w));  // (as in walk_tile: without it the compiler sinks the box and the centre of gravity
+      return r;                                     // into the node arm, behind the link's wait: two round trips per node step)
+    }
     const unsigned o16 = (unsigned)k * 16u + lane_zero;
     const unsigned ot = (unsigned)k * (unsigned)sizeof(T4) + lane_zero;
     return Rec{*reinterpret_cast<const int4*>(reinterpret_cast<const char*>(lk) + o16), *reinterpret_cast<const T4*>(reinterpret_cast<const char*>(g0) + ot),
@@ -838,7 +864,9 @@ __global__ __launch_bounds__(256) void walk_tile_fast(const WalkArgs<T> a, const
             if (left_t > 4) {  // eight targets (missing ones contribute zeros): x and y reduced side by side
               T X[8], Y[8];
 #pragma unroll
-              for (int sl = 0; sl < 8; ++sl) {
+              for (int sl = 0; sl < 5; ++sl) NB_FAST_ROUND(X[sl], Y[sl])  // (five are there: one basic block, so the scheduler
+#pragma unroll                                                            // interleaves their chains — what a wave that runs alone lives on)
+              for (int sl = 5; sl < 8; ++sl) {
                 X[sl] = 0;
                 Y[sl] = 0;
                 if (todo) NB_FAST_ROUND(X[sl], Y[sl])
@@ -851,11 +879,10 @@ __global__ __launch_bounds__(256) void walk_tile_fast(const WalkArgs<T> a, const
             } else if (left_t > 2) {  // three or four targets: their x and y are the eight values of ONE reduction
               T V[8];
 #pragma unroll
-              for (int sl = 0; sl < 4; ++sl) {
-                V[2 * sl] = 0;
-                V[2 * sl + 1] = 0;
-                if (todo) NB_FAST_ROUND(V[2 * sl], V[2 * sl + 1])
-              }
+              for (int sl = 0; sl < 3; ++sl) NB_FAST_ROUND(V[2 * sl], V[2 * sl + 1])  // (three are there)
+              V[6] = 0;
+              V[7] = 0;
+              if (todo) NB_FAST_ROUND(V[6], V[7])
               const T r = reduce8(V);
               const int src = 16 * (k & 1) + 8 * ((k >> 1) & 1);  // slot_lane8(2k); y sits 32 lanes on (slot_lane8(2k + 1))
               gx = lane_fetch(r, src);
@@ -904,24 +931,21 @@ __global__ __launch_bounds__(256) void walk_tile_fast(const WalkArgs<T> a, const
       }
       next = l.x;
     } else {
-      bool descend = false;
       if constexpr (LOG) ++log_nodes;
-      if (act) {
-        const bool contains = p.y > b.y && p.x > b.x && p.x < b.z && p.y < b.w;  // bvh_tree.rs:15-20 (all strict)
-        const T ddx = p.x - c.x, ddy = p.y - c.y;                              // dist2(p, cog), main.rs:228-232
-        const T d2 = ddx * ddx + ddy * ddy;
-        if (!contains && c.w < d2 * theta * theta) {                               // :370-372 (the test is the exact walk's, bit for bit)
-          const T dx = c.x - p.x, dy = c.y - p.y;                                  // :374-379
-          const T sc = fast_scale(dx, dy, c.z, clamp);
-          ax = fma_t(dx, sc, ax);
-          ay = fma_t(dy, sc, ay);
-          ++n_terms;
-          resume = l.x;
-        } else {
-          descend = true;                                                          // :381-382
-          resume = i + 1;
-        }
-      }
+      // straight-line: masks and selects instead of nested exec regions (see walk_tile); the term is computed for every lane and
+      // kept by the lanes that accept (a select on the RESULT: an empty node's centre of gravity is NaN, and NaN x 0 is not 0)
+      const bool contains = (p.y > b.y) & (p.x > b.x) & (p.x < b.z) & (p.y < b.w);  // bvh_tree.rs:15-20 (all strict)
+      const T ddx = p.x - c.x, ddy = p.y - c.y;                                   // dist2(p, cog), main.rs:228-232
+      const T d2 = ddx * ddx + ddy * ddy;
+      const bool accept = act & !contains & (c.w < d2 * theta * theta);              // :370-372 (the test is the exact walk's, bit for bit)
+      const bool descend = act & !accept;                                            // :381-382
+      const T dx = c.x - p.x, dy = c.y - p.y;                                        // :374-379
+      const T sc = fast_scale(dx, dy, c.z, clamp);
+      const T nax = fma_t(dx, sc, ax), nay = fma_t(dy, sc, ay);
+      ax = accept ? nax : ax;
+      ay = accept ? nay : ay;
+      n_terms += accept ? 1u : 0u;
+      resume = accept ? l.x : (descend ? i + 1 : resume);
       const unsigned long long dmask = __builtin_amdgcn_ballot_w64(descend);
       if (l.x - i == 3) {
         // A subtree of three nodes: both children are leaves, and a lane that descends here takes both, whole — their
@@ -1328,7 +1352,11 @@ hipError_t launch_tree_walk_tile_main(hipStream_t s, const WalkArgs<T>& a_in, ch
   unsigned long long* total_out = (unsigned long long*)(info + 6);
   const int tt = sizeof(T) == 8 ? tile_targets_f64() : tile_targets();
   const dim3 grid((unsigned)((grid_waves + 3) / 4));
-#define NB_TILE(F, R) walk_tile<T, F, R><<<grid, dim3(256), 0, s>>>(a, off, info, tgt_ids, hist, total_out)
+  // node records by scalar loads (scalar_node_rec): the exact walk always (62 instead of 72 VGPRs: eight waves per SIMD instead of seven;
+  // reference scene 0.579 -> 0.567 ms, Plummer 1 M 6.07 -> 5.96); NBODY_WALK_SCALAR_REC=0: the vector loads of one address
+  static const bool srec = !(getenv("NBODY_WALK_SCALAR_REC") && atoi(getenv("NBODY_WALK_SCALAR_REC")) == 0);
+#define NB_TILE(F, R) do { if (srec) walk_tile<T, F, R, true><<<grid, dim3(256), 0, s>>>(a, off, info, tgt_ids, hist, total_out); \
+                           else walk_tile<T, F, R, false><<<grid, dim3(256), 0, s>>>(a, off, info, tgt_ids, hist, total_out); } while (0)
   static const bool fast_rows = getenv("NBODY_WALK_FAST_ROWS") && atoi(getenv("NBODY_WALK_FAST_ROWS")) != 0;  // the round-2 FAST arm (rows + ordered adds), for A/B runs
   unsigned long long* wave_log = nullptr;
   WalkArgs<T> a_log = a_in;
@@ -1338,10 +1366,14 @@ hipError_t launch_tree_walk_tile_main(hipStream_t s, const WalkArgs<T>& a_in, ch
     a_log.wave_log = wave_log;
   }
   const WalkArgs<T>& a = a_log;
-  static const int rec_mode = getenv("NBODY_WALK_FAST_REC") ? atoi(getenv("NBODY_WALK_FAST_REC")) : 0;
+  // FAST: scalar loads where the walk is bound by what it issues (Plummer 1 M 3.10 -> 3.03 ms), vector loads of one address where it
+  // is bound by its longest waves' chains (reference scene 0.298 against 0.322 ms: the scalar path's round trip is the longer one)
+  static const int rec_env = getenv("NBODY_WALK_FAST_REC") ? atoi(getenv("NBODY_WALK_FAST_REC")) : -1;
+  const int rec_mode = rec_env >= 0 ? rec_env : (a.n_tgt >= 400000 ? 3 : 0);
   if (a.fast && !fast_rows) {
     if (wave_log) walk_tile_fast<T, 0, true><<<grid, dim3(256), 0, s>>>(a, off, info, tgt_ids, hist, total_out);
     else if (rec_mode == 1) walk_tile_fast<T, 1, false><<<grid, dim3(256), 0, s>>>(a, off, info, tgt_ids, hist, total_out);
+    else if (rec_mode == 3) walk_tile_fast<T, 3, false><<<grid, dim3(256), 0, s>>>(a, off, info, tgt_ids, hist, total_out);
     else walk_tile_fast<T, 0, false><<<grid, dim3(256), 0, s>>>(a, off, info, tgt_ids, hist, total_out);
   }
   else if (a.fast) { if (tt == 16) NB_TILE(true, 16); else if (tt == 4) NB_TILE(true, 4); else NB_TILE(true, 8); }
