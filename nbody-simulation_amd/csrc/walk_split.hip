@@ -72,6 +72,21 @@ __device__ __forceinline__ float2 pair_term_if(bool valid, float px, float py, f
   return div_pair(dx * force, dy * force, den);
 }
 
+// ... and as straight-line code: the term computed for every lane, kept by a select (the quotients of a skipped pair are whatever
+// the division makes of its operands and are thrown away).  No exec region, so the rounds of two targets sit in ONE basic block.
+// (The two rounds written as packed ops over the two targets — subtractions, squares, denominators, numerators and the divisions'
+// multiply-adds — are bit-identical too and measured SLOWER: 66 VGPRs instead of 60, seven waves per SIMD, Plummer 1 M 5.70 -> 6.00 ms.)
+__device__ __forceinline__ float2 pair_term_sel(bool valid, float px, float py, float qx, float qy, float force, float clamp) {
+  const float dx = qx - px;
+  const float dy = qy - py;
+  const float sum = __builtin_fabsf(dx) + __builtin_fabsf(dy);
+  const bool ok = valid & __builtin_isnormal(sum);
+  const float distance = __builtin_fmaxf(dx * dx + dy * dy, clamp);
+  const float den = sum * distance;
+  const float2 t = div_pair(dx * force, dy * force, den);
+  return make_float2(ok ? t.x : -0.0f, ok ? t.y : -0.0f);
+}
+
 // nbody_arith FAST (opt-in, tolerance instead of bit parity): one reciprocal instead of two IEEE divisions; a zero difference
 // contributes exactly 0 through the biased denominator (direct_kernels.hip)
 __device__ __forceinline__ float2 pair_term_fast(float px, float py, float qx, float qy, float force, float clamp) {
@@ -118,6 +133,16 @@ __device__ __forceinline__ double2 pair_term_if(bool valid, double px, double py
   distance = __builtin_fmax(distance, clamp);
   const double den = sum * distance;
   return make_double2((dx * force) / den, (dy * force) / den);
+}
+__device__ __forceinline__ double2 pair_term_sel(bool valid, double px, double py, double qx, double qy, double force, double clamp) {
+  const double dx = qx - px;
+  const double dy = qy - py;
+  const double sum = __builtin_fabs(dx) + __builtin_fabs(dy);
+  const bool ok = valid & __builtin_isnormal(sum);
+  const double distance = __builtin_fmax(dx * dx + dy * dy, clamp);
+  const double den = sum * distance;
+  const double tx = (dx * force) / den, ty = (dy * force) / den;
+  return make_double2(ok ? tx : -0.0, ok ? ty : -0.0);
 }
 __device__ __forceinline__ double2 pair_term_fast(double px, double py, double qx, double qy, double force, double clamp) {
   const double dx = qx - px, dy = qy - py;
@@ -478,6 +503,20 @@ __global__ __launch_bounds__(256) void walk_tile(const WalkArgs<T> a, const uint
           while (todo) {
             int slot = 0;
             while (todo && slot < TT) {  // lane = particle: one acting target per round, its terms into row `slot`
+              if constexpr (!FAST && TT >= 2) {
+                if (slot + 2 <= TT && (todo & (todo - 1)) != 0) {  // two acting targets are there: their rounds as one basic block
+                  const int ta = __builtin_ctzll(todo);
+                  todo &= todo - 1;
+                  const int tb = __builtin_ctzll(todo);
+                  todo &= todo - 1;
+                  const T2 ra = pair_term_sel(valid, lane_t(p.x, ta), lane_t(p.y, ta), q.x, q.y, m, clamp);
+                  const T2 rb = pair_term_sel(valid, lane_t(p.x, tb), lane_t(p.y, tb), q.x, q.y, m, clamp);
+                  tile[slot * kStride + lane] = ra;
+                  tile[(slot + 1) * kStride + lane] = rb;
+                  slot += 2;
+                  continue;
+                }
+              }
               const int tl = __builtin_ctzll(todo);
               todo &= todo - 1;
               const T tx = lane_t(p.x, tl), ty = lane_t(p.y, tl);
