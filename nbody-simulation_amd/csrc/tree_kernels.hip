@@ -217,20 +217,24 @@ __global__ __launch_bounds__(256) void tree_walk_wave(const WalkArgs<T> a) {
       }
       next = l.x;
     } else {
-      bool descend = false;
-      if (act) {
-        const bool contains = p.y > b.y && p.x > b.x && p.x < b.z && p.y < b.w;  // bvh_tree.rs:15-20
-        const T ddx = p.x - c.x, ddy = p.y - c.y;
-        const T d2 = ddx * ddx + ddy * ddy;                                        // main.rs:228-232
-        if (!contains && c.w < d2 * theta * theta) {                               // :370-372
-          walk_pair<T, FAST>(p.x, p.y, c.x, c.y, c.z, clamp, ax, ay);              // :374-379
-          resume = l.x;
-          if (a.stats) accepted++;
-        } else {
-          descend = true;                                                          // :381-382
-          resume = i + 1;
-        }
-        if (a.stats) visits++;
+      // The node test as straight-line code — compares and-ed as masks, selects instead of `if (act) { if (...) {...} else {...} }`,
+      // which compiles to nested exec regions with their saves, restores and branches: a third of a node step's instructions,
+      // and every instruction of a wave costs an issue slot.  The term is under ONE wave-uniform branch.
+      const bool contains = (p.y > b.y) & (p.x > b.x) & (p.x < b.z) & (p.y < b.w);  // bvh_tree.rs:15-20
+      const T ddx = p.x - c.x, ddy = p.y - c.y;
+      const T d2 = ddx * ddx + ddy * ddy;                                          // main.rs:228-232
+      const bool accept = act & !contains & (c.w < d2 * theta * theta);              // :370-372
+      const bool descend = act & !accept;                                            // :381-382
+      if (__builtin_amdgcn_ballot_w64(accept) != 0) {
+        T nax = ax, nay = ay;
+        walk_pair<T, FAST>(p.x, p.y, c.x, c.y, c.z, clamp, nax, nay);                // :374-379
+        ax = accept ? nax : ax;
+        ay = accept ? nay : ay;
+      }
+      resume = accept ? l.x : (descend ? i + 1 : resume);
+      if (a.stats) {
+        accepted += accept ? 1u : 0u;
+        visits += act ? 1u : 0u;
       }
       next = __builtin_amdgcn_ballot_w64(descend) != 0 ? i + 1 : l.x;
     }
@@ -375,19 +379,19 @@ __global__ __launch_bounds__(256) void tree_walk_small(const WalkArgs<T> a, cons
       if (act) resume = l.x;
       next = l.x;
     } else {
-      bool descend = false;
-      if (act) {
-        const bool contains = p.y > b.y && p.x > b.x && p.x < b.z && p.y < b.w;  // bvh_tree.rs:15-20
-        const T ddx = p.x - c.x, ddy = p.y - c.y;
-        const T d2 = ddx * ddx + ddy * ddy;                                        // main.rs:228-232
-        if (!contains && c.w < d2 * theta * theta) {                               // :370-372
-          pair_as_written<T>(p.x, p.y, c.x, c.y, c.z, clamp, ax, ay);              // :374-379
-          resume = l.x;
-        } else {
-          descend = true;                                                          // :381-382
-          resume = i + 1;
-        }
+      // straight-line node test (see tree_walk_wave): masks and selects, the term under one wave-uniform branch
+      const bool contains = (p.y > b.y) & (p.x > b.x) & (p.x < b.z) & (p.y < b.w);  // bvh_tree.rs:15-20
+      const T ddx = p.x - c.x, ddy = p.y - c.y;
+      const T d2 = ddx * ddx + ddy * ddy;                                          // main.rs:228-232
+      const bool accept = act & !contains & (c.w < d2 * theta * theta);              // :370-372
+      const bool descend = act & !accept;                                            // :381-382
+      if (__builtin_amdgcn_ballot_w64(accept) != 0) {
+        T nax = ax, nay = ay;
+        pair_as_written<T>(p.x, p.y, c.x, c.y, c.z, clamp, nax, nay);                // :374-379
+        ax = accept ? nax : ax;
+        ay = accept ? nay : ay;
       }
+      resume = accept ? l.x : (descend ? i + 1 : resume);
       next = __builtin_amdgcn_ballot_w64(descend) != 0 ? i + 1 : l.x;
     }
     i = __builtin_amdgcn_readfirstlane(next);
