@@ -1396,7 +1396,11 @@ hipError_t launch_tree_walk_tile_main(hipStream_t s, const WalkArgs<T>& a_in, ch
   static const bool srec = !(getenv("NBODY_WALK_SCALAR_REC") && atoi(getenv("NBODY_WALK_SCALAR_REC")) == 0);
 #define NB_TILE(F, R) do { if (srec) walk_tile<T, F, R, true><<<grid, dim3(256), 0, s>>>(a, off, info, tgt_ids, hist, total_out); \
                            else walk_tile<T, F, R, false><<<grid, dim3(256), 0, s>>>(a, off, info, tgt_ids, hist, total_out); } while (0)
-  static const bool fast_rows = getenv("NBODY_WALK_FAST_ROWS") && atoi(getenv("NBODY_WALK_FAST_ROWS")) != 0;  // the round-2 FAST arm (rows + ordered adds), for A/B runs
+  // FAST: f32 takes walk_tile_fast (registers, lane-parallel sums); f64 the rows arm (walk_tile<double, true>: LDS rows + ordered adds with
+  // the one-reciprocal term) — walk_tile_fast<double> moves every value as two 32-bit halves through the swaps and runs at half
+  // the occupancy: Plummer 4 M f64 205 ms against 92 (the exact walk: 124).  NBODY_WALK_FAST_ROWS=0/1 forces one or the other.
+  static const int fast_rows_env = getenv("NBODY_WALK_FAST_ROWS") ? atoi(getenv("NBODY_WALK_FAST_ROWS")) : -1;
+  const bool fast_rows = fast_rows_env >= 0 ? fast_rows_env != 0 : sizeof(T) == 8;
   unsigned long long* wave_log = nullptr;
   WalkArgs<T> a_log = a_in;
   if (a_in.fast && getenv("NBODY_WALK_WAVE_LOG") && atoi(getenv("NBODY_WALK_WAVE_LOG")) != 0) {  // development: per-wave time and step counts
