@@ -162,6 +162,11 @@ DirectConfig choose_direct_config(int64_t n_src, int64_t n_tgt, bool uniform = t
   int64_t g = waves > 0 ? (want_waves + waves - 1) / waves : 1;
   if (g < 1) g = 1;
   if (g > 16) g = 16;
+  // ... and until a split's sources (8 B each) are at most half an XCD's 4 MB L2, where 16 splits can do that: the work-groups of
+  // one split run together (blockIdx.x varies fastest), so the range they stream stays L2-resident instead of being re-read
+  // from HBM by waves that have drifted apart (N = 1 M: 2 -> 4 splits, FETCH_SIZE 524 -> 82 MB per launch, the same 173.1 ms)
+  const int64_t g_l2 = (n_src + 262143) / 262144;
+  if (g_l2 <= 16 && g < g_l2) g = g_l2;
   g = env_int("NBODY_DIRECT_GSPLIT", (int)g);
   if (g < 1) g = 1;
   if (g > 64) g = 64;
@@ -185,6 +190,8 @@ size_t direct_partial_bytes(int64_t n_src, int64_t n_tgt) {
   }
   size_t any_block = (size_t)std::min<int64_t>(16 * n_tgt, 2097152 + n_tgt) * sizeof(float2);
   if (any_block > partial) partial = any_block;
+  const int64_t g_l2 = (n_src + 262143) / 262144;  // (the L2 rule of choose_direct_config holds for every block size)
+  if (g_l2 <= 16 && (size_t)(g_l2 * n_tgt) * sizeof(float2) > partial) partial = (size_t)(g_l2 * n_tgt) * sizeof(float2);
   return (partial + 255) & ~(size_t)255;
 }
 size_t direct_ws_bytes(int64_t n_src, int64_t n_tgt) {
