@@ -434,6 +434,7 @@ __global__ __launch_bounds__(256) void walk_tile(const WalkArgs<T> a, const uint
   T2* __restrict__ tile = tile_all[threadIdx.x >> 6];
   const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
   if (info[1] != 0) return;  // the estimate's scan wrapped: the caller takes the fused walk
+  if (wave > info[5]) return;  // past the last wave that can hold a target (most of the grid on a small scene): no searches
   // first t with g(t) >= wave, g(t) = off[t] / budget + t / 64 (see walk_pass), then the first with g(t) > wave: all on the
   // scalar side (`off` through the constant address space; the budget is a power of two, tile_total)
   const int bshift = 31 - __builtin_clz((unsigned)__builtin_amdgcn_readfirstlane(info[3]));
@@ -788,6 +789,7 @@ __global__ __launch_bounds__(256) void walk_tile_fast(const WalkArgs<T> a, const
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
   if (info[1] != 0) return;  // the estimate's scan wrapped: the caller walks again without one
+  if (wave > info[5]) return;  // past the last wave that can hold a target (most of the grid on a small scene): no searches
   const long long log_t0 = LOG ? wall_clock64() : 0;
   // Which targets are this wave's: those with g(t) = off[t] / budget + t / 64 == wave (see walk_pass), by two binary searches.
   // Everything in them is wave-uniform, and kept on the scalar side on purpose: `off` is read through the constant address
@@ -1054,6 +1056,7 @@ __device__ __forceinline__ void tile_total(const uint32_t* __restrict__ cnt, con
   if (budget < 64) budget = 64;
   while (budget < want && budget < (1u << 30)) budget <<= 1;
   info[3] = (int)budget;
+  info[5] = (int)(total / budget + (unsigned long long)((n > 0 ? n - 1 : 0) / 64));  // the last wave that can hold a target (g of the last one)
   // belt and braces: a wave index the grid does not hold would leave its targets unwalked — flag it like a wrapped scan,
   // the host then repeats the walk without an estimate (64 targets per wave, which always fits)
   if (total / budget + (unsigned long long)(n / 64) + 1 >= (unsigned long long)grid_waves) info[1] = 1;
@@ -1078,6 +1081,7 @@ __device__ __forceinline__ void tile_tail_duties(unsigned long long total, int w
     if (budget < 64) budget = 64;
     while (budget < want && budget < (1u << 30)) budget <<= 1;
     out[3] = (int)budget;
+    out[5] = (int)(total / budget + (unsigned long long)((n > 0 ? n - 1 : 0) / 64));  // the last wave that can hold a target
     if (total / budget + (unsigned long long)(n / 64) + 1 >= (unsigned long long)grid_waves) out[1] = 1;
     out[4] = groups;
 #pragma unroll
