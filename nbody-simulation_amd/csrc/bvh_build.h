@@ -35,7 +35,9 @@ BvhBuildLayout bvh_build_layout(int64_t n, int leaf_size);
 
 // Zeroes the counters, copies the positions into the working array and seeds the root.
 // flags_clean: the flags and level counters are zero already (the step before left them so: TileTail::clear_flags).
-hipError_t bvh_build_begin(hipStream_t s, const void* pos, int n, char* scratch, const BvhBuildLayout& L, bool flags_clean = false);
+// stamp_begin / stamp_prev_end (optional): the first thread writes the 100 MHz wall clock there (phase timing without event records)
+hipError_t bvh_build_begin(hipStream_t s, const void* pos, int n, char* scratch, const BvhBuildLayout& L, bool flags_clean = false,
+                           unsigned long long* stamp_begin = nullptr, unsigned long long* stamp_prev_end = nullptr);
 // Levels of long nodes a balanced tree over n points has (the caller enqueues these blind, then asks).
 int bvh_build_first_levels(int64_t n);
 // Enqueues the long-node passes of levels [level_begin, level_end).  bigcount[level_end] != 0 afterwards: more to do.

@@ -625,8 +625,14 @@ __device__ __forceinline__ int alloc_nodes(const BvhPtrs& a, int count) {
 }
 
 // ---- init --------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bvh_init(BvhPtrs a, const float2* __restrict__ pos, int n) {
+__global__ __launch_bounds__(256) void bvh_init(BvhPtrs a, const float2* __restrict__ pos, int n, unsigned long long* __restrict__ stamp_begin,
+                                                unsigned long long* __restrict__ stamp_prev_end) {
   const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i == 0 && (stamp_begin || stamp_prev_end)) {  // phase clock (capi.hip, PhaseStamps): this step begins where the one before ends
+    const unsigned long long now = (unsigned long long)wall_clock64();
+    if (stamp_begin) *stamp_begin = now;
+    if (stamp_prev_end) *stamp_prev_end = now;
+  }
   if (i < n) {
     const float2 p = pos[i];
     a.P[i] = p;
@@ -1984,11 +1990,12 @@ int bvh_build_first_levels(int64_t n) {
   return lv;
 }
 
-hipError_t bvh_build_begin(hipStream_t s, const void* pos, int n, char* scratch, const BvhBuildLayout& L, bool flags_clean) {
+hipError_t bvh_build_begin(hipStream_t s, const void* pos, int n, char* scratch, const BvhBuildLayout& L, bool flags_clean,
+                           unsigned long long* stamp_begin, unsigned long long* stamp_prev_end) {
   hipError_t e = flags_clean ? hipSuccess : hipMemsetAsync(scratch + L.flags, 0, L.zero_end - L.flags, s);  // flags + level counters
   if (e != hipSuccess) return e;
   BvhPtrs a = make_ptrs(scratch, L);
-  bvh_init<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>(a, (const float2*)pos, n);
+  bvh_init<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>(a, (const float2*)pos, n, stamp_begin, stamp_prev_end);
   return hipGetLastError();
 }
 

@@ -864,7 +864,16 @@ template <class T> int download_tree(nbody_ctx* c, State<T>& s) {
 // ---- phase timing by events (see PhaseEvents in ctx.h)
 // `prev`: the step enqueued just before this one, with nothing in between — its end event doubles as this step's start
 // (every recorded event is a marker in the queue, ~6 us of idle stream: two back to back would be the largest gap of a step).
+// ---- ... and by the kernels' own clock for the steps enqueued ahead (ctx.h, stamp_*): no event records between the phases
+constexpr int kStampSlots = 256;
+int close_open_stamp(nbody_ctx* c) {  // the last stamped step's end, when no stamped step follows it directly
+  if (c->stamp_open < 0) return NBODY_OK;
+  HIPCHK(c, launch_stamp(c->stream, c->stamp_dev + 4 * (size_t)c->stamp_open + 3));
+  c->stamp_open = -1;
+  return NBODY_OK;
+}
 int phase_begin(nbody_ctx* c, PhaseEvents* out, const PhaseEvents* prev = nullptr) {
+  if (int rc = close_open_stamp(c)) return rc;
   PhaseEvents p;
   for (int k = prev ? 1 : 0; k < 4; ++k) {
     if (!c->ph_free.empty()) {
@@ -890,6 +899,25 @@ int phase_mark(nbody_ctx* c, const PhaseEvents& p, int k) {
 }
 // Reads every recorded step's phases into the context's (and the caller's) Counting.  Waits for them.
 int phase_drain(nbody_ctx* c) {
+  if (int rc = close_open_stamp(c)) return rc;
+  if (!c->stamp_pending.empty()) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::vector<unsigned long long> h((size_t)kStampSlots * 4);
+    HIPCHK(c, hipMemcpy(h.data(), c->stamp_dev, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    for (int slot : c->stamp_pending) {
+      const unsigned long long* t = h.data() + 4 * (size_t)slot;
+      const double sec[3] = {1e-8 * (double)(long long)(t[1] - t[0]), 1e-8 * (double)(long long)(t[2] - t[1]), 1e-8 * (double)(long long)(t[3] - t[2])};  // 100 MHz ticks
+      c->counting.build_bvh += sec[0];
+      c->counting.sum_gravity += sec[1];
+      c->counting.post_calculations += sec[2];
+      if (c->ph_counter) {
+        c->ph_counter->build_bvh += sec[0];
+        c->ph_counter->sum_gravity += sec[1];
+        c->ph_counter->post_calculations += sec[2];
+      }
+    }
+    c->stamp_pending.clear();
+  }
   for (auto& p : c->ph_pending) {
     HIPCHK(c, hipEventSynchronize(p.e[3]));
     float ms[3] = {0.f, 0.f, 0.f};
@@ -1186,8 +1214,28 @@ template <class T> int bvh_step_ahead(nbody_ctx* c, State<T>& s, T delta, PhaseE
       HIPCHK(c, hipHostGetDevicePointer((void**)&c->spec_host_dev, c->spec_host, 0));
       HIPCHK(c, hipEventCreateWithFlags(&c->spec_event, hipEventDisableTiming));
     }
+    // Phase timing: by the step's own kernels (the 100 MHz wall clock written at the three boundaries: no event records, each of
+    // which leaves ~6 us of idle stream) when the walk's preparation is the one fused kernel; by events otherwise.
+    const bool fused_scan = n <= std::min<int64_t>(kWalkFusedScanMaxTargets, env_int("NBODY_WALK_FUSED_SCAN_MAX", (int)kWalkFusedScanMaxTargets));
+    const bool stamps = fused_scan && env_int("NBODY_PHASE_STAMPS", 1) != 0;
     PhaseEvents ph;
-    int rc = phase_begin(c, &ph, chain->e[3] ? chain : nullptr);
+    int rc = NBODY_OK;
+    unsigned long long* stamp = nullptr;  // this step's slot
+    unsigned long long* stamp_prev_end = nullptr;
+    int slot = -1;
+    if (stamps) {
+      if (!c->stamp_dev) {
+        HIPCHK(c, hipMalloc((void**)&c->stamp_dev, (size_t)kStampSlots * 4 * sizeof(unsigned long long)));
+        HIPCHK(c, hipMemsetAsync(c->stamp_dev, 0, (size_t)kStampSlots * 4 * sizeof(unsigned long long), c->stream));
+      }
+      slot = c->stamp_next;
+      c->stamp_next = (c->stamp_next + 1) % kStampSlots;
+      stamp = c->stamp_dev + 4 * (size_t)slot;
+      if (c->stamp_open >= 0) stamp_prev_end = c->stamp_dev + 4 * (size_t)c->stamp_open + 3;  // bvh_init closes the step before
+      c->stamp_open = -1;
+    } else {
+      rc = phase_begin(c, &ph, chain->e[3] ? chain : nullptr);
+    }
     *chain = PhaseEvents{};
     if (rc) return rc;
     auto& in = s.set[s.cur];
@@ -1204,7 +1252,7 @@ template <class T> int bvh_step_ahead(nbody_ctx* c, State<T>& s, T delta, PhaseE
     if (lv_end > kBvhKeyDepth + 1) lv_end = kBvhKeyDepth + 1;
     const bool flags_clean = s.bb_flags_clean;
     s.bb_flags_clean = false;
-    HIPCHK(c, bvh_build_begin(c->stream, in.pos, n, s.bb_scratch, L, flags_clean));
+    HIPCHK(c, bvh_build_begin(c->stream, in.pos, n, s.bb_scratch, L, flags_clean, stamp, stamp_prev_end));
     if (lv_end > 0) HIPCHK(c, bvh_build_levels(c->stream, n, leaf, 0, lv_end, s.bb_scratch, L));
     HIPCHK(c, bvh_build_finish(c->stream, in.weight, n, leaf, 0, s.bb_scratch, L, nullptr, s.geom0, s.geom1, s.link, s.node_depth,
                                s.node_mass, s.node_size));
@@ -1221,7 +1269,7 @@ template <class T> int bvh_step_ahead(nbody_ctx* c, State<T>& s, T delta, PhaseE
     g.weight_out = out.weight;
     g.ids_in = in.ids; g.ids_out = out.ids;
     HIPCHK(c, launch_gather<T>(c->stream, g));
-    rc = phase_mark(c, ph, 1);
+    if (!stamps) rc = phase_mark(c, ph, 1);
     if (rc) return rc;
     // ---- walk (rows as after the build: `out` is the permuted set, `in` the snapshot)
     WalkArgs<T> w{};
@@ -1258,7 +1306,8 @@ template <class T> int bvh_step_ahead(nbody_ctx* c, State<T>& s, T delta, PhaseE
     tail.clear_words = (int)((L.zero_end - L.flags) / sizeof(int));
     tail.info_zeroed = true;
     // (one kernel instead of three: 17 us against 32 at 151 405 targets, 31 against 67 at a million; NBODY_WALK_FUSED_SCAN_MAX=0: the three)
-    tail.fused_scan = n <= std::min<int64_t>(kWalkFusedScanMaxTargets, env_int("NBODY_WALK_FUSED_SCAN_MAX", (int)kWalkFusedScanMaxTargets));
+    tail.fused_scan = fused_scan;
+    tail.stamp = stamps ? stamp + 1 : nullptr;
     HIPCHK(c, launch_tree_walk_tile_prep<T>(c->stream, w, s.ws_scratch, WL, tgt_ids, s.wt_hist, 1, shift, &waves, &tail));
     s.bb_flags_clean = true;
     int* h = c->spec_host;
@@ -1267,7 +1316,7 @@ template <class T> int bvh_step_ahead(nbody_ctx* c, State<T>& s, T delta, PhaseE
       TimerScope ts(c->timer, c->stream);
       HIPCHK(c, launch_tree_walk_tile_main<T>(c->stream, w, s.ws_scratch, WL, tgt_ids, s.wt_hist, waves));
     }
-    rc = phase_mark(c, ph, 2);
+    if (!stamps) rc = phase_mark(c, ph, 2);
     if (rc) return rc;
     // ---- the step's one wait: for the event in front of the walk kernel
     HIPCHK(c, hipEventSynchronize(c->spec_event));
@@ -1286,7 +1335,7 @@ template <class T> int bvh_step_ahead(nbody_ctx* c, State<T>& s, T delta, PhaseE
       s.wt_hist_n = -1;  // (the walk returned at once and left zeros in the history)
       s.bvh_levels_hint = 0;
       s.bvh_levels_stable = 0;
-      (void)phase_mark(c, ph, 3);
+      if (!stamps) (void)phase_mark(c, ph, 3);  // (a stamped slot is simply not booked: the plain sequence that follows books the step)
       return 1;
     }
     // the build stands: what bvh_build_device records
@@ -1314,7 +1363,13 @@ template <class T> int bvh_step_ahead(nbody_ctx* c, State<T>& s, T delta, PhaseE
     carry.carry_src = walk_info;
     carry.carry_dst = c->spec_host_dev + 2 + 128 + 8;
     carry.carry_words = 8;
+    carry.stamp = stamps ? stamp + 2 : nullptr;
     HIPCHK(c, launch_integrate<T>(c->stream, s.set[s.cur].pos, s.set[s.cur].vel, s.acc, s.n, delta, carry));
+    if (stamps) {
+      c->stamp_open = slot;  // its end: the next stamped step's first kernel, or close_open_stamp
+      c->stamp_pending.push_back(slot);
+      return NBODY_OK;
+    }
     rc = phase_mark(c, ph, 3);
     if (!rc) *chain = ph;  // the next step starts where this one ends
     return rc;
@@ -1341,7 +1396,7 @@ template <class T> int update_tree(nbody_ctx* c, int kind, T delta, int n_steps,
   };
   PhaseEvents chain;  // the step before, when the next one follows it directly on the stream
   for (int step = 0; step < n_steps; ++step) {
-    if (c->ph_pending.size() >= 64) {
+    if (c->ph_pending.size() >= 64 || c->stamp_pending.size() >= 64) {
       int rc = phase_drain(c);
       if (rc) return done(rc);
       chain = PhaseEvents{};
@@ -1595,6 +1650,7 @@ void nbody::ctx_destroy_single(nbody_ctx* c) {
   free_dev(c->frame_work);
   free_dev(c->frame_rgba);
   free_dev(c->spec_dev);
+  free_dev(c->stamp_dev);
   if (c->spec_host) (void)hipHostFree(c->spec_host);
   if (c->spec_event) (void)hipEventDestroy(c->spec_event);
   for (auto& p : c->ph_pending)

@@ -177,6 +177,13 @@ struct nbody_ctx {
   uint32_t frame_px = 0;
   unsigned long long last_stats[3] = {0, 0, 0};
   bool want_stats = false;
+  // Phase clock of the steps enqueued ahead (capi.hip, bvh_step_ahead): instead of three event records per step (each ~6 us of idle
+  // stream) the step's own kernels write the 100 MHz wall clock at the phase boundaries: slot = {build begins, walk begins,
+  // integration begins, step ends}; read back when the phases are drained.
+  unsigned long long* stamp_dev = nullptr;               // [kStampSlots][4]
+  std::vector<int> stamp_pending;                        // slots of finished steps not yet read
+  int stamp_next = 0;
+  int stamp_open = -1;                                   // slot whose end is still to be written (by the next step's first kernel, or a stamp kernel)
   std::vector<nbody::PhaseEvents> ph_pending;           // recorded phase events
   std::vector<hipEvent_t> ph_free;                       // reusable events
   nbody_counting* ph_counter = nullptr;                // the caller's counter of the call in progress

@@ -47,7 +47,9 @@ struct Gate {
   const int* carry_src = nullptr;
   int* carry_dst = nullptr;
   int carry_words = 0;
+  unsigned long long* stamp = nullptr;  // the kernel's first thread writes the 100 MHz wall clock here (phase timing without event records)
 };
+hipError_t launch_stamp(hipStream_t s, unsigned long long* stamp);  // a one-thread kernel that does only that
 
 template <class T> struct GatherArgs {
   const uint32_t* perm;

@@ -423,6 +423,7 @@ __global__ __launch_bounds__(256) void integrate_inplace(void* pos, void* vel, c
   if ((gate.nonzero && *gate.nonzero == 0) || (gate.zero && *gate.zero != 0)) return;
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i < gate.carry_words) gate.carry_dst[i] = gate.carry_src[i];
+  if (i == 0 && gate.stamp) *gate.stamp = (unsigned long long)wall_clock64();
   if (i >= n) return;
   T2 v = reinterpret_cast<T2*>(vel)[i];
   T2 p = reinterpret_cast<T2*>(pos)[i];
@@ -544,6 +545,11 @@ __global__ __launch_bounds__(256) void div_pair_selftest(const float* __restrict
 hipError_t launch_div_pair_selftest(hipStream_t s, const float* nx, const float* ny, const float* den, int64_t n, float* qx, float* qy) {
   if (n <= 0) return hipSuccess;
   hipLaunchKernelGGL(div_pair_selftest, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, nx, ny, den, n, qx, qy);
+  return hipGetLastError();
+}
+__global__ void stamp_now(unsigned long long* __restrict__ stamp) { *stamp = (unsigned long long)wall_clock64(); }
+hipError_t launch_stamp(hipStream_t s, unsigned long long* stamp) {
+  hipLaunchKernelGGL(stamp_now, dim3(1), dim3(1), 0, s, stamp);
   return hipGetLastError();
 }
 template <class T> hipError_t launch_gather(hipStream_t s, const GatherArgs<T>& a) {

@@ -49,6 +49,7 @@ struct TileTail {
   int* clear = nullptr;           // zeroed once packed
   int clear_words = 0;
   bool info_zeroed = false;       // info is zero already (an earlier kernel of the stream did it)
+  unsigned long long* stamp = nullptr;  // fused scan only: the kernel's first thread writes the 100 MHz wall clock here (the walk phase begins)
   // The estimate's scan, its overflow check and the duties above as ONE kernel (walk_scan_est_tail: a single-pass scan with
   // decoupled look-back) instead of the library scan's two launches + the check's.  The caller has zeroed
   // scratch + L.scan_state (L.scan_state_bytes) once, when it allocated the scratch; the kernel keeps its own books there.

@@ -1178,6 +1178,7 @@ __global__ __launch_bounds__(256) void walk_scan_est_tail(EstimateOf est, uint32
   __shared__ unsigned s_b, s_epoch;
   __shared__ unsigned long long s_wave[4], s_excl;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0 && blockIdx.x == 0 && tail.stamp) *tail.stamp = (unsigned long long)wall_clock64();
   if (tid == 0) {
     s_epoch = (unsigned)__hip_atomic_load(&st[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (before the ticket: see above)
     s_b = atomicAdd((unsigned*)&st[0], 1u);
