@@ -332,7 +332,8 @@ int direct_prep(nbody_ctx* c, hipStream_t stream, int64_t n_src, const void* pos
   if (!pos_all || !mass_all) return fail(c, NBODY_ERR_INVALID, "direct_step: null pos_all/mass_all");
   int* flags = (int*)ws;
   HIPCHK(c, hipMemsetAsync(flags, 0, kFlagBytes, stream));
-  if (p.use_hazard) HIPCHK(c, launch_hazard_scan(stream, (const float*)pos_all, 2 * n_src, flags));
+  if (p.use_hazard && !(p.nearfar && n_src > 0))  // (with the split on, nf_insert checks the positions as it reads them)
+    HIPCHK(c, launch_hazard_scan(stream, (const float*)pos_all, 2 * n_src, flags));
   if (p.nearfar) {
     char* nf_scratch = (char*)ws + kFlagBytes + p.partial_bytes;
     NearFarLayout L = nearfar_layout(n_src);

@@ -50,6 +50,8 @@ NearFarLayout nearfar_layout(int64_t n_src);
 // slots of pad_slots hold no body and receive the far-away point.  The far copy then has n + n_pad_slots entries.
 constexpr int64_t kMaxMassClasses = 32;
 constexpr int64_t kDirectTile = 1024;
+constexpr float kFastBig = 1152921504606846976.0f;   // 2^60: FAST's domain (direct_kernels.hip, direct_hazard_scan)
+constexpr float kFastTiny = 2.384185791015625e-07f;  // 2^-22
 constexpr int kFarPad = 16;  // a far copy in couples is padded with far-away points to a multiple of this many sources
 __host__ __device__ inline int64_t far_padded(int64_t n_slots) { return (n_slots + kFarPad - 1) / kFarPad * kFarPad; }
 hipError_t launch_nearfar(hipStream_t s, const float2* pos, const float* mass, float heavy_base, int n, float clamp, int use_hazard,

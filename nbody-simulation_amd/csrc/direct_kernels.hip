@@ -31,8 +31,8 @@
 namespace nbody {
 
 static constexpr float kDenBias = 8.0779356694631609e-28f;  // 2^-90
-static constexpr float kBig = 1152921504606846976.0f;       // 2^60
-static constexpr float kTiny = 2.384185791015625e-07f;      // 2^-22
+static constexpr float kBig = kFastBig;    // 2^60
+static constexpr float kTiny = kFastTiny;  // 2^-22
 
 __device__ __forceinline__ int wave_id_uniform() {
   return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));

@@ -65,12 +65,19 @@ __device__ __forceinline__ bool cell_of(float2 p, double inv_h, uint32_t* cx, ui
 }
 
 // Every body enters its cell's bit in its super-cell's slot; the second body to arrive in a super-cell sets the "multi" bit.
+// `hazard`: the FAST domain check of direct_hazard_scan rides along (the same positions, one pass: a launch fewer per step).
 __global__ __launch_bounds__(256) void nf_insert(const float2* __restrict__ pos, int n, double inv_h, uint32_t* __restrict__ table,
-                                                 uint32_t tmask, int* __restrict__ flags) {
+                                                 uint32_t tmask, int* __restrict__ flags, int hazard) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   uint32_t cx, cy;
-  if (!cell_of(pos[i], inv_h, &cx, &cy)) atomicOr(&flags[kFlagFallback], 1);
+  const float2 p = pos[i];
+  if (hazard) {
+    const float vx = __builtin_fabsf(p.x), vy = __builtin_fabsf(p.y);
+    const bool bad = !(vx < kFastBig) || (vx != 0.f && vx < kFastTiny) || !(vy < kFastBig) || (vy != 0.f && vy < kFastTiny);
+    if (__builtin_amdgcn_ballot_w64(bad) != 0 && (threadIdx.x & 63) == (unsigned)__builtin_ctzll(__builtin_amdgcn_ballot_w64(bad))) atomicOr(&flags[kFlagHazard], 1);
+  }
+  if (!cell_of(p, inv_h, &cx, &cy)) atomicOr(&flags[kFlagFallback], 1);
   const SuperCell sc = super_of(cx >> 1, cy >> 1, tmask);
   const uint32_t bit = 1u << ((cx & 1) * 2 + (cy & 1));
   uint32_t h = sc.slot;
@@ -141,12 +148,21 @@ __device__ __forceinline__ void far_store(float2* __restrict__ pos_far, uint32_t
     pos_far[slot] = p;
   }
 }
+// The thread of the last body also decides (nf_decide's rule: everything it reads was written by the kernels before this one).
 template <bool COUPLES>
 __global__ __launch_bounds__(256) void nf_compact(const float2* __restrict__ pos, const uint32_t* __restrict__ is_near,
                                                   const uint32_t* __restrict__ scan, int n, float2* __restrict__ pos_far,
                                                   uint32_t* __restrict__ near_list, const uint32_t* __restrict__ rank,
-                                                  const uint32_t* __restrict__ pad_slots, int n_pad_slots, int n_slots) {
+                                                  const uint32_t* __restrict__ pad_slots, int n_pad_slots, int n_slots, int max_near,
+                                                  int use_hazard, int* __restrict__ flags) {
   const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i == n - 1) {  // state: 0 = near/far split (no clamp in the main pass), 1 = single clamped pass, 2 = EXACT kernel
+    const int m = (int)(scan[n - 1] + is_near[n - 1]);
+    flags[kFlagNearCount] = m;
+    int state = (flags[kFlagFallback] != 0 || m > max_near) ? 1 : 0;
+    if (use_hazard && flags[kFlagHazard] != 0) state = 2;
+    flags[kFlagState] = state;
+  }
   if (i >= n) {
     const int k = i - n;
     if (k < n_pad_slots) far_store<COUPLES>(pos_far, pad_slots[k], make_float2(1e30f, 1e30f));
@@ -159,17 +175,6 @@ __global__ __launch_bounds__(256) void nf_compact(const float2* __restrict__ pos
     p = make_float2(1e30f, 1e30f);
   }
   far_store<COUPLES>(pos_far, rank ? rank[i] : (uint32_t)i, p);
-}
-
-// state: 0 = near/far split (no clamp in the main pass), 1 = single clamped pass, 2 = EXACT kernel.
-__global__ void nf_decide(const uint32_t* __restrict__ is_near, const uint32_t* __restrict__ scan, int n, int max_near,
-                          int use_hazard, int* __restrict__ flags) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  int m = n > 0 ? (int)(scan[n - 1] + is_near[n - 1]) : 0;
-  flags[kFlagNearCount] = m;
-  int state = (flags[kFlagFallback] != 0 || m > max_near) ? 1 : 0;
-  if (use_hazard && flags[kFlagHazard] != 0) state = 2;
-  flags[kFlagState] = state;
 }
 
 __global__ void nf_decide_simple(int use_hazard, int* __restrict__ flags) {
@@ -224,7 +229,7 @@ hipError_t launch_nearfar(hipStream_t s, const float2* pos, const float* mass, f
   const uint32_t tmask = table_slots(n) - 1;
   hipError_t e = hipMemsetAsync(table, 0xFF, L.table_bytes, s);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(nf_insert, dim3(blocks), dim3(256), 0, s, pos, n, 1.0 / h, table, tmask, flags);
+  hipLaunchKernelGGL(nf_insert, dim3(blocks), dim3(256), 0, s, pos, n, 1.0 / h, table, tmask, flags, use_hazard);
   hipLaunchKernelGGL(nf_mark, dim3(blocks), dim3(256), 0, s, pos, n, 1.0 / h, (const uint32_t*)table, tmask, mass, heavy_base, is_near);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
@@ -236,10 +241,11 @@ hipError_t launch_nearfar(hipStream_t s, const float2* pos, const float* mass, f
   const int n_slots = n + n_pad;  // (mass classes: the padded class order; otherwise the bodies themselves)
   const unsigned cblocks = (unsigned)((n + n_pad + (couples ? kFarPad : 0) + 255) / 256);
   if (couples)
-    hipLaunchKernelGGL(nf_compact<true>, dim3(cblocks), dim3(256), 0, s, pos, is_near, scan, n, far, list, rank, pad_slots, n_pad, n_slots);
+    hipLaunchKernelGGL(nf_compact<true>, dim3(cblocks), dim3(256), 0, s, pos, is_near, scan, n, far, list, rank, pad_slots, n_pad, n_slots, n / 64,
+                       use_hazard, flags);
   else
-    hipLaunchKernelGGL(nf_compact<false>, dim3(cblocks), dim3(256), 0, s, pos, is_near, scan, n, far, list, rank, pad_slots, n_pad, n_slots);
-  hipLaunchKernelGGL(nf_decide, dim3(1), dim3(1), 0, s, is_near, scan, n, n / 64, use_hazard, flags);
+    hipLaunchKernelGGL(nf_compact<false>, dim3(cblocks), dim3(256), 0, s, pos, is_near, scan, n, far, list, rank, pad_slots, n_pad, n_slots,
+                       n / 64, use_hazard, flags);
   return hipGetLastError();
 }
 
