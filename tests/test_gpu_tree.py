@@ -778,3 +778,52 @@ def test_async_updates_equal_synchronous_ones(nb, orc):
         b.wait()
     rp, rv, _, rids, _ = orc.update_bvh(pos, vel, w, delta=0.1, theta=50.0, mode=orc.AS_WRITTEN, nsteps=7, nthreads=16)
     assert np.array_equal(snaps[3], rids) and np.array_equal(snaps[0], rp) and np.array_equal(snaps[1], rv)
+
+
+# ------------------------------------------------------------------ second half of round 3: phase clock, record fetches
+def test_phase_stamps_and_event_records_time_the_same_phases(nb, monkeypatch):
+    """Steps enqueued ahead time their phases by the kernels' own 100 MHz clock (bvh_init / walk_scan_est_tail /
+    integrate_inplace write it at the three boundaries) instead of three event records per step; NBODY_PHASE_STAMPS=0 keeps
+    the events.  Same intervals: the two Counting splits agree, sum to about the wall time, and the rows are the same."""
+    import time
+    C = nb._capi
+    pos, vel, w = nb.scenes.galaxy()
+    out = {}
+    for stamps in ("1", "0"):
+        monkeypatch.setenv("NBODY_PHASE_STAMPS", stamps)
+        with C.Context(0) as c:
+            c.upload(pos, vel, w)
+            c.update_tree(C.TREE_BVH, 0.1, 5)
+            cnt = C.Counting()
+            t0 = time.perf_counter()
+            c.update_tree(C.TREE_BVH, 0.1, 100, cnt)
+            wall = time.perf_counter() - t0
+            c.update_tree(C.TREE_QUAD, 0.1, 1, cnt)            # a plain step after stamped ones: the open slot is closed first
+            c.update_tree(C.TREE_BVH, 0.1, 3, cnt)             # ... and stamped steps after a plain one
+            out[stamps] = (cnt.build_bvh, cnt.sum_gravity, cnt.post_calculations, wall, c.download())
+    for s in out.values():
+        assert s[0] > 0 and s[1] > 0 and s[2] > 0
+    a, b = out["1"], out["0"]
+    assert abs(a[0] - b[0]) <= 0.15 * b[0] and abs(a[1] - b[1]) <= 0.15 * b[1], (a[:3], b[:3])
+    assert a[2] <= b[2] * 1.5 + 1e-3                            # (the events' gaps sat in the last phase)
+    assert all(np.array_equal(x, y) for x, y in zip(a[4], b[4]))
+
+
+def test_node_record_fetch_variants_walk_the_same_walk(nb, monkeypatch):
+    """Node records arrive by scalar loads through the constant address space (exact walk: always; FAST: from 400 000 targets) or
+    by vector loads of one address; FAST can also pin / not pin them (NBODY_WALK_FAST_REC 0 / 1 / 3).  Where they come from
+    changes no bit."""
+    C = nb._capi
+    pos, vel, w = nb.scenes.plummer(200000, seed=61)
+    for arith in (C.ARITH_AUTO, C.ARITH_FAST):
+        got = []
+        for srec, frec in (("1", "0"), ("0", "1"), ("1", "3")):
+            monkeypatch.setenv("NBODY_WALK_SCALAR_REC", srec)
+            monkeypatch.setenv("NBODY_WALK_FAST_REC", frec)
+            with C.Context(0) as c:
+                c.set_params(theta=50.0, arith=arith, order=C.ORDER_AS_WRITTEN)
+                c.upload(pos, vel, w)
+                c.update_tree(C.TREE_BVH, 0.1, 3)
+                got.append(c.download())
+        for other in got[1:]:
+            assert all(np.array_equal(x, y) for x, y in zip(got[0], other))
