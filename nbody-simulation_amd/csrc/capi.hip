@@ -1430,6 +1430,8 @@ template <class T> int update_tree(nbody_ctx* c, int kind, T delta, int n_steps,
     ++c->steps_done;
   }
   if (async) {  // the phase events and the last walk's term count are collected by nbody_wait or the next synchronous call
+    // (a stamped step's end is written now: whatever the caller does before its next step is not this step's integration)
+    if (int rc = close_open_stamp(c)) return rc;
     c->ph_counter = nullptr;
     return NBODY_OK;
   }
