@@ -5,21 +5,22 @@
 //   v_i += a_i*dt ; x_i += v_i*dt                        reference integrate   src/main.rs:419-423
 //
 // Two arithmetic flavours (include/nbody_hip.h, nbody_arith):
-//   FAST   direct_fast: one thread per target, sources staged as a tile in LDS and read back with broadcast
-//          ds_read_b128, 8 (7 without the clamp) VALU instructions + one v_rcp_f32 per pair.  The
-//          coincident-pair skip of main.rs:241-243 costs nothing: den = fma(sum, d2c, 2^-90) keeps the
-//          reciprocal finite, so a zero diff contributes exactly 0.  Valid when no position is non-finite,
-//          >= 2^60, or non-zero below 2^-22 (then every non-zero |dx|+|dy| is >= 2^-46 and the bias is below half
-//          an ulp of den); direct_hazard_scan checks exactly that, per call.
+//   FAST   direct_stream / direct_fast: one thread per target, 6 issue slots per pair.  The coincident-pair skip of
+//          main.rs:241-243 costs nothing: den = fma(sum, d2c, 2^-90) keeps the reciprocal finite, so a zero diff contributes
+//          exactly 0.  Valid when no position is non-finite, >= 2^60, or non-zero below 2^-22 (then every non-zero |dx|+|dy| is
+//          >= 2^-46 and the bias is below half an ulp of den); direct_hazard_scan (or nf_insert) checks exactly that, per call.
 //   EXACT  direct_exact: every operation as the reference writes it: IEEE subtract/multiply/add/divide, no
 //          contraction, the is_normal() skip, one sequential ascending-j chain per target.  Bit-identical to
 //          the oracle.
 //
-// Measured instruction costs that shape FAST (tools/valu_microbench*.hip, tools/mb/*):
-//   an SGPR operand halves the issue rate (so sources come through LDS into VGPRs, not through scalar loads),
-//   v_max_f32 is half rate (so the clamp is skipped for sources that nearfar.hip proves far from every body),
-//   v_rcp_f32 is quarter rate, v_pk_* cost two plain ops, and the 8-instruction pair body sustains 34.5-35.6
-//   cycles per pair per SIMD whatever the order of its instructions.
+// The measured issue model that shapes FAST (tools/valu_microbench*.hip, tools/mb/*):
+//   a wave issues one VALU instruction per 4-cycle slot, and so does its SIMD — except that two PLAIN f32 ops of two different
+//   waves can share a slot, which the arbiter only arranges when it has nothing else to issue; a packed op (v_pk_*_f32) fills its
+//   slot alone with two values per lane, v_max / compares / SGPR-operand ops with one, v_rcp_f32 takes two slots.  So: every
+//   multiply-add is packed over TWO pairs (sources as couples {xA, xB, yA, yB}), the far sources stream through SGPRs (a packed op
+//   takes an SGPR pair at no cost: no LDS, no barrier), and the few plain ops that remain (|dx| + |dy|) run at a lower wave priority
+//   so that they pair: 12 slots per couple = 24 cycles per pair.  The round-1/2 kernels (USE_ASM 0 / 1: a pair per instruction, four
+//   plain ops per pair at a slot each) are kept for A/B runs.
 //
 // This translation unit is compiled with -ffp-contract=off: nothing fuses unless written as fmaf().
 #include <hip/hip_runtime.h>
