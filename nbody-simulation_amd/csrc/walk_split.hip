@@ -406,6 +406,32 @@ __global__ __launch_bounds__(256) void walk_sum(const WalkArgs<float> a, const u
 // targets' particles (by id: the build permutes the rows) had in the PREVIOUS walk or, when there is none, of a
 // counting traversal.  A bad estimate costs balance, never correctness: each target's additions are the fused
 // walk's, in its order.  f32 and f64 (rows of 16-byte terms: half as many waves stay resident).
+// Which targets are wave w's: those with g(t) = off[t] / budget + t / 64 == w (g is non-decreasing): [t0, t1).  A 64-ARY search —
+// every lane probes one point of the range, a ballot finds the first that has reached w — narrows 64-fold per round trip: three
+// rounds for 151 405 targets and ONE for the second bound (t1 <= t0 + 64), instead of the forty dependent probes of two binary
+// searches (16 us of every wave's start, on the scalar side; 125 us as vector loads with a division each before that).
+__device__ __forceinline__ void wave_targets(const uint32_t* __restrict__ off, const int n_tgt, const int wave, const int bshift, const int lane,
+                                             int& t0, int& t1) {
+  int lo = 0, hi = n_tgt;  // the first t with g(t) >= wave lies in [lo, hi] (hi = "none below hi")
+  while (lo < hi) {
+    const int step = (hi - lo + 63) >> 6;
+    const int idx = lo + lane * step;
+    const bool reached = idx >= hi || (int)(off[idx] >> bshift) + (idx >> 6) >= wave;
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(reached);
+    const int first = m ? __builtin_ctzll(m) : 64;  // (lane 0 probes lo itself)
+    if (first == 0) { hi = lo; break; }
+    const int below = lo + (first - 1) * step;      // the last probe that has not reached `wave`
+    if (first < 64) hi = min(hi, lo + first * step);
+    lo = below + 1;
+  }
+  t0 = lo;
+  const int idx = t0 + lane;                        // the first t with g(t) > wave: at most 64 further on
+  const bool past = idx >= n_tgt || (int)(off[idx] >> bshift) + (idx >> 6) > wave;
+  const unsigned long long m = __builtin_amdgcn_ballot_w64(past);
+  t1 = t0 + (m ? __builtin_ctzll(m) : 64);
+  if (t1 > n_tgt) t1 = n_tgt;
+}
+
 // A node's three records by SCALAR loads: the index is wave-uniform, but the compiler only picks s_load for memory it can prove
 // unwritten during the kernel, which it cannot here (the kernels store accelerations and history) — so plain loads become
 // vector loads of one address (a round trip through the vector L1 and 64 lanes' worth of return data for 48 bytes).  The tree was
@@ -438,19 +464,9 @@ __global__ __launch_bounds__(256) void walk_tile(const WalkArgs<T> a, const uint
   // first t with g(t) >= wave, g(t) = off[t] / budget + t / 64 (see walk_pass), then the first with g(t) > wave: all on the
   // scalar side (`off` through the constant address space; the budget is a power of two, tile_total)
   const int bshift = 31 - __builtin_clz((unsigned)__builtin_amdgcn_readfirstlane(info[3]));
-  const uint32_t __attribute__((address_space(4)))* offc = (const uint32_t __attribute__((address_space(4)))*)off;
-  const int n_tgt = (int)a.n_tgt;  // (the scan is 32 bits wide)
-  int lo = 0, hi = n_tgt;
-  while (lo < hi) {
-    const int mid = (int)(((unsigned)lo + (unsigned)hi) >> 1);
-    if ((int)(offc[mid] >> bshift) + (mid >> 6) < wave) lo = mid + 1; else hi = mid;
-  }
-  const int t0 = lo;
-  hi = t0 + 64 < n_tgt ? t0 + 64 : n_tgt;
-  while (lo < hi) {
-    const int mid = (int)(((unsigned)lo + (unsigned)hi) >> 1);
-    if ((int)(offc[mid] >> bshift) + (mid >> 6) <= wave) lo = mid + 1; else hi = mid;
-  }
+  const int n_tgt = (int)a.n_tgt;  // (the scan, hence the walk, is 32 bits wide)
+  int t0, lo;
+  wave_targets(off, n_tgt, wave, bshift, lane, t0, lo);
   if (lo == t0) return;
   const int64_t t = (int64_t)t0 + lane;
   const bool live = t < lo;
@@ -797,19 +813,9 @@ __global__ __launch_bounds__(256) void walk_tile_fast(const WalkArgs<T> a, const
   // quotient is a shift — forty dependent steps that cost a wave 125 us as vector loads and a 32-bit division each, on
   // SIMDs whose vector pipes the other waves keep busy (profiles/r03_walk_wave_log.txt).
   const int bshift = 31 - __builtin_clz((unsigned)__builtin_amdgcn_readfirstlane(info[3]));
-  const uint32_t __attribute__((address_space(4)))* offc = (const uint32_t __attribute__((address_space(4)))*)off;
   const int n_tgt = (int)a.n_tgt;  // (the scan, hence the walk, is 32 bits wide)
-  int lo = 0, hi = n_tgt;
-  while (lo < hi) {  // first t with g(t) >= wave
-    const int mid = (int)(((unsigned)lo + (unsigned)hi) >> 1);
-    if ((int)(offc[mid] >> bshift) + (mid >> 6) < wave) lo = mid + 1; else hi = mid;
-  }
-  const int t0 = lo;
-  hi = t0 + 64 < n_tgt ? t0 + 64 : n_tgt;
-  while (lo < hi) {  // first t with g(t) > wave
-    const int mid = (int)(((unsigned)lo + (unsigned)hi) >> 1);
-    if ((int)(offc[mid] >> bshift) + (mid >> 6) <= wave) lo = mid + 1; else hi = mid;
-  }
+  int t0, lo;
+  wave_targets(off, n_tgt, wave, bshift, lane, t0, lo);
   if (lo == t0) return;
   const int64_t t = (int64_t)t0 + lane;
   const bool live = t < lo;
