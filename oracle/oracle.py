@@ -39,7 +39,9 @@ def lib(native: bool = False) -> C.CDLL:
 
 
 # The clamp is the f32 constant `0.001f32` upstream (main.rs:247-248); f64 runs widen that f32 value, exactly as the
-# product's `float clamp` parameter does, so every wrapper passes nt(np.float32(clamp)).
+# product's `float clamp` parameter does, so every wrapper passes nt(np.float32(clamp)).  THETA is an f32 constant too
+# (main.rs:35) and `float theta` in nbody_params: nt(np.float32(theta)) — for 0.5 and 50 nothing changes; for a theta like 0.7 an
+# f64 run that used the double 0.7 decided one borderline node in 65 121 targets differently (found by the extended fuzz, round 3).
 def _p(a, ct):
     return None if a is None else a.ctypes.data_as(C.POINTER(ct))
 
@@ -136,7 +138,7 @@ def update_bvh(pos, vel, weight, delta=0.1, theta=50.0, clamp=0.001, leaf_size=6
     f.argtypes = [C.c_int64, C.POINTER(ct), C.POINTER(ct), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), ct, ct,
                   ct, C.c_int64, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
     rc = f(pos.shape[0], _p(pos, ct), _p(vel, ct), _p(w, C.c_uint32), _p(ids, C.c_uint32), ct(nt(delta)),
-           ct(nt(theta)), ct(nt(np.float32(clamp))), int(leaf_size), int(mode), int(nsteps), int(nthreads),
+           ct(nt(np.float32(theta))), ct(nt(np.float32(clamp))), int(leaf_size), int(mode), int(nsteps), int(nthreads),
            _p(cnt, C.c_double))
     if rc:
         raise RuntimeError(f"oracle update_bvh rc={rc} (degenerate input: recursion depth cap)")
@@ -155,7 +157,7 @@ def update_quad(pos, vel, weight, delta=0.1, theta=50.0, clamp=0.001, root=(0.0,
     f.restype = C.c_int
     f.argtypes = [C.c_int64, C.POINTER(ct), C.POINTER(ct), C.POINTER(C.c_uint32), ct, ct, ct, ct, ct, ct,
                   C.c_int, C.c_int, C.POINTER(C.c_double)]
-    rc = f(pos.shape[0], _p(pos, ct), _p(vel, ct), _p(w, C.c_uint32), ct(nt(delta)), ct(nt(theta)),
+    rc = f(pos.shape[0], _p(pos, ct), _p(vel, ct), _p(w, C.c_uint32), ct(nt(delta)), ct(nt(np.float32(theta))),
            ct(nt(np.float32(clamp))), ct(nt(root[0])), ct(nt(root[1])), ct(nt(root[2])), int(nsteps), int(nthreads),
            _p(cnt, C.c_double))
     if rc:
@@ -254,7 +256,7 @@ class BVH:
         f = getattr(self._L, f"orc_bvh_walk_{self.sfx}")
         f.restype = None
         f.argtypes = [C.c_void_p, C.c_int64, C.POINTER(ct), ct, ct, C.c_int, C.POINTER(ct), C.POINTER(C.c_uint64)]
-        f(self.h, tg.shape[0], _p(tg, ct), ct(self.nt(theta)), ct(self.nt(np.float32(clamp))), int(nthreads), _p(acc, ct),
+        f(self.h, tg.shape[0], _p(tg, ct), ct(self.nt(np.float32(theta))), ct(self.nt(np.float32(clamp))), int(nthreads), _p(acc, ct),
           _p(st, C.c_uint64))
         return (acc, st) if stats else acc
 
@@ -268,7 +270,7 @@ class BVH:
         f = getattr(self._L, f"orc_bvh_walk_ref_{self.sfx}")
         f.restype = None
         f.argtypes = [C.c_void_p, C.c_int64, C.POINTER(ct), ct, ct, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
-        f(self.h, tg.shape[0], _p(tg, ct), ct(self.nt(theta)), ct(self.nt(np.float32(clamp))), int(nthreads),
+        f(self.h, tg.shape[0], _p(tg, ct), ct(self.nt(np.float32(theta))), ct(self.nt(np.float32(clamp))), int(nthreads),
           _p(acc, C.c_double), _p(norm, C.c_double))
         return acc, norm
 
@@ -353,7 +355,7 @@ class Quad:
         f = getattr(self._L, f"orc_quad_walk_{self.sfx}")
         f.restype = None
         f.argtypes = [C.c_void_p, C.c_int64, C.POINTER(ct), ct, ct, C.c_int, C.POINTER(ct), C.POINTER(C.c_uint64)]
-        f(self.h, tg.shape[0], _p(tg, ct), ct(self.nt(theta)), ct(self.nt(np.float32(clamp))), int(nthreads), _p(acc, ct),
+        f(self.h, tg.shape[0], _p(tg, ct), ct(self.nt(np.float32(theta))), ct(self.nt(np.float32(clamp))), int(nthreads), _p(acc, ct),
           _p(st, C.c_uint64))
         return (acc, st) if stats else acc
 
@@ -367,6 +369,6 @@ class Quad:
         f = getattr(self._L, f"orc_quad_walk_ref_{self.sfx}")
         f.restype = None
         f.argtypes = [C.c_void_p, C.c_int64, C.POINTER(ct), ct, ct, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
-        f(self.h, tg.shape[0], _p(tg, ct), ct(self.nt(theta)), ct(self.nt(np.float32(clamp))), int(nthreads),
+        f(self.h, tg.shape[0], _p(tg, ct), ct(self.nt(np.float32(theta))), ct(self.nt(np.float32(clamp))), int(nthreads),
           _p(acc, C.c_double), _p(norm, C.c_double))
         return acc, norm

@@ -5,11 +5,16 @@ the CPU restatement of bvh_tree.rs:56-158 / quad_tree.rs:153-270).  Needs an MI3
 Every case: a random size (1 ... 2e5), leaf size and distribution; the device-built tree equals the oracle's node for node
 (ranges, skip links, u32 masses, boxes and centres of gravity bit for bit, NaN for empty leaves) and so does the row
 permutation; then two whole steps equal the oracle's World::update, row for row."""
+import os
+
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
 F32 = np.float32
+# Longer runs by hand (not the driver's): NBODY_FUZZ_CASES=200 NBODY_FUZZ_SEED=7 python -m pytest tests/test_gpu_fuzz.py
+CASES = int(os.environ.get("NBODY_FUZZ_CASES", "0"))
+SEED = int(os.environ.get("NBODY_FUZZ_SEED", "0"))
 
 
 def _scene(rng, kind, n, dtype, nb):
@@ -36,9 +41,9 @@ def ctx(nb):
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_bvh_builds_equal_the_oracle_on_random_cases(nb, orc, ctx, dtype):
     C = nb._capi
-    rng = np.random.default_rng(20261004 + (1 if dtype == np.float64 else 0))
+    rng = np.random.default_rng(20261004 + (1 if dtype == np.float64 else 0) + 1000 * SEED)
     done = on_device = 0
-    for case in range(16 if dtype == np.float32 else 10):
+    for case in range(CASES or (16 if dtype == np.float32 else 10)):
         n = int(10 ** rng.uniform(0.0, 5.3))
         leaf = int(rng.choice([1, 4, 16, 64, 64, 64, 200, 1000]))
         kind = int(rng.integers(0, 6))
@@ -77,9 +82,9 @@ def test_bvh_builds_equal_the_oracle_on_random_cases(nb, orc, ctx, dtype):
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_quad_builds_equal_the_oracle_on_random_cases(nb, orc, ctx, dtype):
     C = nb._capi
-    rng = np.random.default_rng(20261005 + (1 if dtype == np.float64 else 0))
+    rng = np.random.default_rng(20261005 + (1 if dtype == np.float64 else 0) + 1000 * SEED)
     done = 0
-    for case in range(14 if dtype == np.float32 else 8):
+    for case in range(CASES or (14 if dtype == np.float32 else 8)):
         n = int(10 ** rng.uniform(0.0, 5.3))
         kind = int(rng.choice([0, 1, 3, 4, 5, 5]))                          # (kind 1 and 3 put points outside the root cell too)
         pos = _scene(rng, kind, n, dtype, nb)

@@ -827,3 +827,25 @@ def test_node_record_fetch_variants_walk_the_same_walk(nb, monkeypatch):
                 got.append(c.download())
         for other in got[1:]:
             assert all(np.array_equal(x, y) for x, y in zip(got[0], other))
+
+
+def test_f64_walks_take_theta_as_the_f32_parameter_it_is(nb, orc, ctx):
+    """THETA is an f32 constant upstream (main.rs:35) and `float theta` in nbody_params; an f64 walk widens that f32 value.  For
+    0.5 and 50 the widening is exact; for 0.7 the double 0.7 and the widened 0.7f decide ONE borderline node of this scene's
+    65 121 targets differently (row 43333: found by the extended fuzz, NBODY_FUZZ_CASES=60 NBODY_FUZZ_SEED=1).  The oracle's
+    wrapper rounds theta to f32 like the clamp; with it every row agrees bit for bit, and with the double 0.7 that row does not."""
+    C = nb._capi
+    rng = np.random.default_rng(20261005 + 1 + 1000)        # the fuzz's stream: its second case
+    n0 = int(10 ** rng.uniform(0.0, 5.3)); k0 = int(rng.integers(0, 6))
+    assert (n0, k0) == (27123, 2)
+    rng.random((n0, 2)); rng.integers(1, 9, n0); rng.standard_normal((n0, 2))
+    n = int(10 ** rng.uniform(0.0, 5.3)); kind = int(rng.integers(0, 6))
+    assert (n, kind) == (65121, 0)
+    pos = (rng.random((n, 2)) * 1e5).astype(np.float64)
+    w = rng.integers(1, 9, n).astype(np.uint32)
+    ctx.set_params(theta=0.7, order=C.ORDER_CONSISTENT, arith=C.ARITH_AUTO)
+    ctx.upload(pos, np.zeros_like(pos), w)
+    acc = ctx.accel_tree(C.TREE_QUAD, pos)
+    quad = orc.Quad(pos, w)
+    assert np.array_equal(acc, quad.walk(pos, theta=0.7, nthreads=16))
+    ctx.set_params(theta=50.0, order=C.ORDER_AS_WRITTEN)
