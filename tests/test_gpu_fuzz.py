@@ -115,3 +115,44 @@ def test_quad_builds_equal_the_oracle_on_random_cases(nb, orc, ctx, dtype):
         assert np.array_equal(ids, np.arange(n)) and np.array_equal(p, rp, equal_nan=True) and np.array_equal(v, rv, equal_nan=True), tag
         done += 1
     assert done >= 5, done
+
+
+def test_direct_main_pass_on_random_cases(nb, orc, ctx, monkeypatch):
+    """The direct step's packed / streamed main pass (NBODY_DIRECT_ASM 2 / 3) on random sizes (the near/far split on), random mass
+    patterns (equal, a few classes, a few heavy bodies, all different) and positions with coincident bodies and pairs inside the
+    clamp radius: within the oracle's tolerance on sampled targets, bitwise reproducible, and 2 and 3 give the same bits."""
+    from tests._tol import check_fast
+    C = nb._capi
+    rng = np.random.default_rng(20261006 + 1000 * SEED)
+    for case in range(CASES // 10 or 3):
+        n = int(rng.integers(65536, 180000))
+        kind = int(rng.integers(0, 3))
+        pos = _scene(rng, (0, 1, 5)[kind], n, np.float32, nb)
+        dup = rng.integers(0, n, 8)
+        pos[dup[:4]] = pos[dup[4:]]                                       # coincident bodies
+        near = rng.integers(0, n, 16)
+        pos[near[:8]] = pos[near[8:]] + F32(0.0078125)                   # inside the clamp radius
+        mk = int(rng.integers(0, 4))
+        if mk == 0:
+            w = np.full(n, int(rng.integers(1, 1000)), np.uint32)
+        elif mk == 1:
+            w = rng.integers(1, 6, n).astype(np.uint32)
+        elif mk == 2:
+            w = np.ones(n, np.uint32)
+            w[rng.integers(0, n, 5)] = rng.integers(1000, 1 << 26, 5)
+        else:
+            w = rng.integers(1, 1 << 20, n).astype(np.uint32)
+        vel = np.zeros_like(pos)
+        tg = rng.integers(0, n, 1024)
+        ref64, norm = orc.direct_accel(pos, w, targets=tg, accum="f64", nthreads=16)
+        cpu32, _ = orc.direct_accel(pos, w, targets=tg, nthreads=16)
+        got = {}
+        for mode in ("2", "3"):
+            monkeypatch.setenv("NBODY_DIRECT_ASM", mode)
+            ctx.set_params(arith=C.ARITH_AUTO, clamp=0.001, theta=50.0, leaf_size=64)
+            ctx.upload(pos, vel, w)
+            got[mode] = ctx.accel_direct()
+            check_fast(got[mode][tg], ref64, norm, cpu32, label=f" case {case}: n {n} scene {kind} masses {mk} NBODY_DIRECT_ASM={mode}")
+            ctx.upload(pos, vel, w)
+            assert np.array_equal(ctx.accel_direct(), got[mode])
+        assert np.array_equal(got["2"], got["3"]), f"case {case}: n {n} scene {kind} masses {mk}"
