@@ -830,7 +830,21 @@ __global__ __launch_bounds__(256) void walk_tile_fast(const WalkArgs<T> a, const
   const int n_nodes = a.n_nodes_dev ? __builtin_amdgcn_readfirstlane(*a.n_nodes_dev) : a.n_nodes;
   int resume = live ? 0 : n_nodes;
   uint32_t n_terms = 0;
-  T ax = 0, ay = 0;
+  // Two-level summation, as in the direct kernel: the terms go to a block sum (bx, by) that joins the running total after every fourth
+  // leaf step.  A target's list can be a large part of all particles (small theta on the BVH's needle boxes; all-negative
+  // coordinates, whose boxes stretch to the origin: bvh_tree.rs:42) and a plain f32 chain of N additions drifts by ~sqrt(N)
+  // half-ulps of the sum of magnitudes: 2.2e-5 ... 4.9e-5 of it on lists of 2 x 10^4 ... 10^5 terms (found by the extended fuzz;
+  // the contract is 2e-5).
+  T ax = 0, ay = 0, bx = 0, by = 0;
+  int leaf_steps = 0;
+  auto flush_if_due = [&]() {
+    if (++leaf_steps == 4) {
+      ax = ax + bx;
+      ay = ay + by;
+      bx = by = 0;
+      leaf_steps = 0;
+    }
+  };
   int i = 0;
   unsigned log_nodes = 0, log_leaves = 0, log_rounds = 0;
   // A node's three records (link, box, centre of gravity | mass | s^2), fetched together: one latency per step.  REC = 1
@@ -885,8 +899,8 @@ __global__ __launch_bounds__(256) void walk_tile_fast(const WalkArgs<T> a, const
               if (act) {
                 const T dx = qx - p.x, dy = qy - p.y;
                 const T sc = fast_scale(dx, dy, qm, clamp);
-                ax = fma_t(dx, sc, ax);
-                ay = fma_t(dy, sc, ay);
+                bx = fma_t(dx, sc, bx);
+                by = fma_t(dy, sc, by);
               }
             }
             continue;
@@ -953,8 +967,8 @@ __global__ __launch_bounds__(256) void walk_tile_fast(const WalkArgs<T> a, const
               took = 1;
             }
             if (k >= 0 && k < took) {
-              ax = ax + gx;
-              ay = ay + gy;
+              bx = bx + gx;
+              by = by + gy;
             }
             batch0 += took;
           }
@@ -971,7 +985,10 @@ __global__ __launch_bounds__(256) void walk_tile_fast(const WalkArgs<T> a, const
     int next;
     if (l.w) {  // Leaf arm
       const unsigned long long mask = __builtin_amdgcn_ballot_w64(act);
-      if (mask) rounds(mask, act, l.y, l.z);
+      if (mask) {
+        rounds(mask, act, l.y, l.z);
+        flush_if_due();
+      }
       if (act) {
         n_terms += (uint32_t)l.z;
         resume = l.x;
@@ -988,9 +1005,9 @@ __global__ __launch_bounds__(256) void walk_tile_fast(const WalkArgs<T> a, const
       const bool descend = act & !accept;                                            // :381-382
       const T dx = c.x - p.x, dy = c.y - p.y;                                        // :374-379
       const T sc = fast_scale(dx, dy, c.z, clamp);
-      const T nax = fma_t(dx, sc, ax), nay = fma_t(dy, sc, ay);
-      ax = accept ? nax : ax;
-      ay = accept ? nay : ay;
+      const T nbx = fma_t(dx, sc, bx), nby = fma_t(dy, sc, by);
+      bx = accept ? nbx : bx;
+      by = accept ? nby : by;
       n_terms += accept ? 1u : 0u;
       resume = accept ? l.x : (descend ? i + 1 : resume);
       const unsigned long long dmask = __builtin_amdgcn_ballot_w64(descend);
@@ -999,7 +1016,10 @@ __global__ __launch_bounds__(256) void walk_tile_fast(const WalkArgs<T> a, const
         // particles are this node's own range [first, first + count) (a node's record carries its range too).  So the two
         // leaf steps happen HERE: two records and one round trip for the particles fewer per pair of leaves, which is most of
         // what a wave waits for (the records of three leaves in four are never fetched).  Same pairs, same lanes.
-        if (dmask) rounds(dmask, descend, l.y, l.z);
+        if (dmask) {
+          rounds(dmask, descend, l.y, l.z);
+          flush_if_due();
+        }
         if (descend) {
           n_terms += (uint32_t)l.z;
           resume = l.x;
@@ -1015,6 +1035,8 @@ __global__ __launch_bounds__(256) void walk_tile_fast(const WalkArgs<T> a, const
     const Rec r = fetch(i);
     i = step(r, i);
   }
+  ax = ax + bx;
+  ay = ay + by;
   if (live) {
     reinterpret_cast<T2*>(a.acc)[row] = T2{ax, ay};
     if (hist) hist[tgt_ids[t]] = n_terms;  // by particle id: the rows are permuted by every build

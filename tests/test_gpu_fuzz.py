@@ -156,3 +156,45 @@ def test_direct_main_pass_on_random_cases(nb, orc, ctx, monkeypatch):
             ctx.upload(pos, vel, w)
             assert np.array_equal(ctx.accel_direct(), got[mode])
         assert np.array_equal(got["2"], got["3"]), f"case {case}: n {n} scene {kind} masses {mk}"
+
+
+def test_fast_walks_on_random_cases(nb, orc, ctx, monkeypatch):
+    """The tolerance-contract walks (walk_tile_fast; the FAST arm of the quad walk) on random sizes, leaf sizes, thetas and
+    distributions: every target within 2e-5 of the sum of its terms' magnitudes against the oracle's walk_ref (the walk's own
+    interaction list, terms as main.rs:252 writes them, summed in double)."""
+    from tests._tol import check_fast
+    C = nb._capi
+    monkeypatch.setenv("NBODY_WALK_SPLIT", "3")            # the one-pass walk whatever the size
+    rng = np.random.default_rng(20261007 + 1000 * SEED)
+    done = 0
+    for case in range(CASES // 4 or 6):
+        n = int(10 ** rng.uniform(3.0, 5.2))
+        leaf = int(rng.choice([16, 64, 64, 200]))
+        theta = float(rng.choice([50.0, 50.0, 5.0, 0.7]))
+        if theta < 50.0:
+            n = min(n, 20000)
+        kind = int(rng.integers(0, 6))
+        pos = _scene(rng, kind, n, np.float32, nb)
+        if kind == 4:
+            pos = pos + F32(0.25) * rng.integers(0, 3, pos.shape).astype(F32)
+        w = rng.integers(1, 9, n).astype(np.uint32)
+        vel = np.zeros_like(pos)
+        tag = f" case {case}: n {n} leaf {leaf} theta {theta} kind {kind}"
+        bvh = orc.BVH(pos, w, leaf_size=leaf)
+        flat = bvh.flat()
+        if not flat.overflow:
+            ctx.set_params(theta=theta, leaf_size=leaf, order=C.ORDER_CONSISTENT, arith=C.ARITH_FAST)
+            ctx.upload(pos, vel, w)
+            acc = ctx.accel_tree(C.TREE_BVH)
+            ref64, norm = bvh.walk_ref(flat.pos_perm, theta=theta, nthreads=16)
+            check_fast(acc, ref64, np.maximum(norm, 1e-300), label=" bvh" + tag)
+            done += 1
+        quad = orc.Quad(pos, w)
+        if not quad.flat().overflow and n <= 60000:
+            ctx.set_params(theta=min(theta, 5.0), order=C.ORDER_CONSISTENT, arith=C.ARITH_FAST)
+            ctx.upload(pos, vel, w)
+            acc = ctx.accel_tree(C.TREE_QUAD)
+            ref64, norm = quad.walk_ref(pos, theta=min(theta, 5.0), nthreads=16)
+            check_fast(acc, ref64, np.maximum(norm, 1e-300), label=" quad" + tag)
+    assert done >= 3
+    ctx.set_params(arith=C.ARITH_AUTO, leaf_size=64, theta=50.0, order=C.ORDER_AS_WRITTEN)
