@@ -164,6 +164,14 @@ __global__ __launch_bounds__(256) void tree_walk_wave(const WalkArgs<T> a) {
   const T theta = a.theta, clamp = a.clamp;
   const int n_nodes = a.n_nodes;
   T ax = 0, ay = 0;
+  // FAST in f32: two-level summation (walk_split.hip, walk_tile_fast) — the terms go to a block sum that joins the running total
+  // every 32nd leaf step, so that a long list (theta near 0: the direct sum in disguise) stays inside the 2e-5 contract.  The
+  // as-written arithmetic keeps the reference's one chain.
+  constexpr bool TWO = FAST && sizeof(T) == 4;
+  T bx_ = 0, by_ = 0;
+  T& bx = TWO ? bx_ : ax;
+  T& by = TWO ? by_ : ay;
+  int leaf_steps = 0;
   int resume = live ? 0 : n_nodes;
   unsigned long long visits = 0, accepted = 0, leaf_pairs = 0;
   if (n_nodes <= 0) {
@@ -208,7 +216,15 @@ __global__ __launch_bounds__(256) void tree_walk_wave(const WalkArgs<T> a) {
         if (act) {
 #pragma unroll
           for (int j = 0; j < LB; ++j)
-            if (k0 + j < end) walk_pair<T, FAST>(p.x, p.y, q[j].x, q[j].y, m[j], clamp, ax, ay);
+            if (k0 + j < end) walk_pair<T, FAST>(p.x, p.y, q[j].x, q[j].y, m[j], clamp, bx, by);
+        }
+      }
+      if constexpr (TWO) {
+        if (++leaf_steps == 32) {
+          ax = ax + bx_;
+          ay = ay + by_;
+          bx_ = by_ = 0;
+          leaf_steps = 0;
         }
       }
       if (act) {
@@ -226,10 +242,10 @@ __global__ __launch_bounds__(256) void tree_walk_wave(const WalkArgs<T> a) {
       const bool accept = act & !contains & (c.w < d2 * theta * theta);              // :370-372
       const bool descend = act & !accept;                                            // :381-382
       if (__builtin_amdgcn_ballot_w64(accept) != 0) {
-        T nax = ax, nay = ay;
+        T nax = bx, nay = by;
         walk_pair<T, FAST>(p.x, p.y, c.x, c.y, c.z, clamp, nax, nay);                // :374-379
-        ax = accept ? nax : ax;
-        ay = accept ? nay : ay;
+        bx = accept ? nax : bx;
+        by = accept ? nay : by;
       }
       resume = accept ? l.x : (descend ? i + 1 : resume);
       if (a.stats) {
@@ -248,6 +264,10 @@ __global__ __launch_bounds__(256) void tree_walk_wave(const WalkArgs<T> a) {
 #ifdef NB_WALK_TIMING
     { const long long te = wall_clock64(); if (was_leaf) { t_leaf += te - ts; ++n_leaf; } else { t_node += te - ts; ++n_node; } }
 #endif
+  }
+  if constexpr (TWO) {
+    ax = ax + bx_;
+    ay = ay + by_;
   }
   if (live) reinterpret_cast<T2*>(a.acc)[row] = T2{ax, ay};
 #ifdef NB_WALK_TIMING

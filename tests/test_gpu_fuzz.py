@@ -190,11 +190,12 @@ def test_fast_walks_on_random_cases(nb, orc, ctx, monkeypatch):
             check_fast(acc, ref64, np.maximum(norm, 1e-300), label=" bvh" + tag)
             done += 1
         quad = orc.Quad(pos, w)
-        if not quad.flat().overflow and n <= 60000:
-            ctx.set_params(theta=min(theta, 5.0), order=C.ORDER_CONSISTENT, arith=C.ARITH_FAST)
+        qtheta = float(rng.choice([5.0, 0.7, 0.25, 0.0]))                  # 0: the direct sum in disguise (lists of n terms)
+        if not quad.flat().overflow and n <= (60000 if qtheta >= 0.7 else 30000):
+            ctx.set_params(theta=qtheta, order=C.ORDER_CONSISTENT, arith=C.ARITH_FAST)
             ctx.upload(pos, vel, w)
             acc = ctx.accel_tree(C.TREE_QUAD)
-            ref64, norm = quad.walk_ref(pos, theta=min(theta, 5.0), nthreads=16)
-            check_fast(acc, ref64, np.maximum(norm, 1e-300), label=" quad" + tag)
+            ref64, norm = quad.walk_ref(pos, theta=qtheta, nthreads=16)
+            check_fast(acc, ref64, np.maximum(norm, 1e-300), label=f" quad theta {qtheta}" + tag)
     assert done >= 3
     ctx.set_params(arith=C.ARITH_AUTO, leaf_size=64, theta=50.0, order=C.ORDER_AS_WRITTEN)
