@@ -199,3 +199,35 @@ def test_fast_walks_on_random_cases(nb, orc, ctx, monkeypatch):
             check_fast(acc, ref64, np.maximum(norm, 1e-300), label=f" quad theta {qtheta}" + tag)
     assert done >= 3
     ctx.set_params(arith=C.ARITH_AUTO, leaf_size=64, theta=50.0, order=C.ORDER_AS_WRITTEN)
+
+
+def test_sharded_direct_steps_on_random_cases(nb, orc):
+    """Several ranks behind one handle (the one device listed several times, peer copies), random sizes with the near/far split
+    on (the streamed main pass over couples, ragged last blocks, 1-4 chunks, mass classes or equal masses): one FAST step from
+    rest gives v = fl(a dt) with a inside the frozen tolerance on sampled targets, and x = x + v dt bit for bit."""
+    from tests._tol import ACC_RTOL
+    C = nb._capi
+    rng = np.random.default_rng(20261008 + 1000 * SEED)
+    for case in range(CASES // 20 or 2):
+        n = int(rng.integers(66000, 150000))
+        ranks = int(rng.choice([2, 3, 4, 8]))
+        chunks = int(rng.choice([1, 2, 4]))
+        pos = _scene(rng, (0, 1, 5)[int(rng.integers(0, 3))], n, np.float32, nb)
+        w = np.ones(n, np.uint32) if rng.random() < 0.5 else rng.integers(1, 5, n).astype(np.uint32)
+        vel = np.zeros_like(pos)
+        tg = np.sort(rng.choice(n, 2048, replace=False))
+        ref64, norm = orc.direct_accel(pos, w, targets=tg, accum="f64", nthreads=16)
+        m = C.MultiContext([0] * ranks, C.EXCHANGE_PEER, chunks)
+        try:
+            m.set_params(arith=C.ARITH_FAST)
+            m.upload(pos, vel, w)
+            m.update_direct(0.1, 1)
+            p, v, _, ids = m.download()
+        finally:
+            m.close()
+        tag = f"case {case}: n {n} ranks {ranks} chunks {chunks}"
+        assert np.array_equal(ids, np.arange(n)), tag
+        err = np.abs(v[tg].astype(np.float64) / 0.1 - ref64).sum(axis=1)
+        slack = 4 * np.finfo(F32).eps * np.abs(ref64).sum(axis=1)
+        assert np.all(err <= ACC_RTOL * norm + slack), (tag, float(((err - slack) / norm).max()))
+        assert np.array_equal(p, (pos + v * F32(0.1)).astype(F32)), tag
