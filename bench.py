@@ -10,12 +10,16 @@ One process per GPU.  The N bodies are fixed (strong scaling): rank r owns the t
 keeps a replicated copy of all positions, runs nbody_direct_prep_dev / nbody_direct_run_dev on its blocks and
 all-gathers the new positions in place (RCCL over xGMI) once per chunk.  A step = force on every body from every
 body + semi-implicit Euler (reference: World::update, src/main.rs:388-425, with the direct sum of SURVEY a9 as the
-force phase).  Prints ONE JSON line on rank 0.
+force phase).
 
-At N = 1 the line also carries `cpu_baseline` (the oracle on the host cores, a bounded sample) and `legs`: the other
-single-GPU configurations of BASELINE.json, each with its own roofline — config 2 (65 536 direct), per-body masses and
-the reference's own scene (direct), config 4 (4 194 304 bodies, quad tree, theta 0.5, f64; the reference's arithmetic and
-the opt-in FAST one).  `--leg NAME` runs one leg alone (what the rocprofv3 passes under profiles/ were taken on).
+Output (rank 0, stdout): the HEADLINE is the LAST line, one compact JSON object (< 2 KB: metric, value, unit, n_gpus, steps,
+warmup, ms_per_step, dtype, config, `roofline`, `cpu_baseline`, and a one-number-per-leg `legs` digest).  At N = 1 it is
+preceded by one compact JSON line (< 1 KB) per leg — the other single-GPU configurations: the reference's live BVH step, the
+same on the headline's bodies, config 2 (65 536 direct), mass classes, free per-body masses, the reference's own scene
+(direct), config 4 (4 194 304 bodies, quad tree, theta 0.5, f64; the reference's arithmetic and the opt-in FAST one).  The
+explanatory notes every record used to repeat live once in profiles/README.md ("Reading a bench line").  `--full-out PATH`
+also writes the unabridged records (headline + legs) to PATH; `--leg NAME` runs one leg alone and prints its unabridged
+record (what the rocprofv3 passes under profiles/ are taken on).
 """
 import argparse
 import json
@@ -41,8 +45,8 @@ def _main_pass_kernel(uniform=True):
     """Name of the direct step's dominant kernel as the library picks it (capi.hip choose_direct_config, direct_kernels.hip
     launch_direct_fast): NBODY_DIRECT_ASM 3 (default) streams the far sources of equal masses / mass classes through SGPRs."""
     mode = int(os.environ.get("NBODY_DIRECT_ASM", "3") or 3)
-    if mode >= 3 and uniform:
-        return "nbody::direct_stream"
+    if mode >= 3:
+        return "nbody::direct_stream" if uniform else "nbody::direct_stream_m"
     return "nbody::direct_fast<1,%s,true,%d>" % ("true" if uniform else "false", min(max(mode, 0), 2))
 PEAK_F32_TFLOPS = 157.3     # MI355X_MICROARCH.md: peak FP32 vector (= FP32 matrix) rate
 PEAK_F64_TFLOPS = 78.6      # FP64 vector: half the FP32 vector rate (256 CU x 2.4 GHz x 128 flop/clk/CU; AMD's MI355X figure)
@@ -65,54 +69,26 @@ def _profile(name):
 
 def _traffic(roof, profile_name, algorithmic_bytes):
     """roofline.traffic is not measurable from inside this process (PMC counters need rocprofv3): it is read from the
-    committed summary of the same command and says so."""
-    prof, src = _profile(profile_name)
+    committed summary of the same command (this round's, else the previous round's file of the same name) and says which.
+    How the figure is corrected: profiles/README.md, "Reading a bench line"."""
     roof["algorithmic_bytes_per_launch"] = algorithmic_bytes
-    if prof and prof.get("hbm_bytes_per_launch") is not None:
-        roof["traffic"] = prof["hbm_bytes_per_launch"]
-        roof["traffic_source"] = src + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, per launch; not measured in this run)"
-        if algorithmic_bytes:
-            roof["traffic_over_algorithmic"] = prof["hbm_bytes_per_launch"] / algorithmic_bytes
-        if prof.get("traffic_note"):
-            roof["traffic_note"] = prof["traffic_note"]
-    else:
-        roof["traffic"] = None
-        roof["traffic_source"] = None
+    roof["traffic"] = None
+    roof["traffic_source"] = None
+    for cand in (profile_name, profile_name.replace("r04_", "r03_", 1)):
+        prof, src = _profile(cand)
+        if prof and prof.get("hbm_bytes_per_launch") is not None:
+            roof["traffic"] = prof["hbm_bytes_per_launch"]
+            roof["traffic_source"] = src + " (rocprofv3 --pmc, separate passes; not measured in this run)"
+            if algorithmic_bytes:
+                roof["traffic_over_algorithmic"] = prof["hbm_bytes_per_launch"] / algorithmic_bytes
+            break
     return roof
 
 
 def cpu_baseline(pos, w, n_sample_targets):
     """The oracle (CPU restatement, -march=native build made on this box) timed on a bounded sample of the same
     workload: n_sample_targets targets x all N sources, all host cores.  Reported, never the target."""
-    from oracle import oracle as orc
-    try:
-        orc.build(native=True)
-        native = True
-    except Exception:
-        native = False
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
-    try:  # a container's CPU share (cgroup v2 quota), when there is one
-        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
-        if q != "max":
-            cores = max(1, min(cores, int(float(q) / float(per) + 0.5)))
-    except Exception:
-        pass
-    n = pos.shape[0]
-    tg = np.arange(0, n, n // n_sample_targets)[:n_sample_targets]
-    orc.direct_accel(pos[:4096], w[:4096], targets=np.arange(64), nthreads=cores, native_lib=native)  # warm
-    t0 = time.perf_counter()
-    orc.direct_accel(pos, w, targets=tg, nthreads=cores, native_lib=native)
-    dt = time.perf_counter() - t0
-    pairs = float(len(tg)) * n
-    return {"value": pairs / dt, "unit": "pair-interactions/s", "cores": cores, "kind": "port",
-            "sample": f"{len(tg)} targets x {n} sources = {pairs:.3g} pairs in {dt:.1f} s "
-                      f"(oracle/nbody_oracle.cpp, g++ -O3 {'-march=native' if native else '-march=x86-64-v3'} "
-                      f"-ffp-contract=off, f32 sequential sum as main.rs:234-253 writes it)",
-            "ms_per_step_extrapolated": 1e3 * float(n) * n / (pairs / dt)}
+    return _cpu_direct_sample(pos, w, n_sample_targets)
 
 
 # ---------------------------------------------------------------------------------------------------- legs
@@ -153,8 +129,10 @@ def _cpu_direct_sample(pos, w, n_targets):
     dt = time.perf_counter() - t0
     pairs = float(len(tg)) * n
     return {"value": pairs / dt, "unit": "pair-interactions/s", "cores": cores, "kind": "port",
-            "sample": f"{len(tg)} targets x {n} sources = {pairs:.3g} pairs in {dt:.2f} s (oracle/nbody_oracle.cpp, "
-                      f"{'-march=native' if native else '-march=x86-64-v3'}, the force law as main.rs:234-253 writes it)",
+            "sample": f"{len(tg)} targets x {n} sources = {pairs:.3g} pairs in {dt:.2f} s (oracle/nbody_oracle.cpp, g++ -O3 "
+                      f"{'-march=native' if native else '-march=x86-64-v3'} -ffp-contract=off, the force law and its f32 sequential "
+                      f"sum as main.rs:234-253 writes them)",
+            "sample_short": f"{len(tg)} targets x {n} sources, {dt:.1f} s, oracle f32 as written",
             "ms_per_step_extrapolated": 1e3 * float(n) * n / (pairs / dt)}
 
 
@@ -173,10 +151,11 @@ def _cpu_tree_steps(pos, vel, w, kind_name, theta, order_mode, steps):
     return {"value": 1e3 * dt / steps, "unit": "ms/step", "cores": cores, "kind": "port",
             "build_ms": 1e3 * c3[0] / steps, "sum_gravity_ms": 1e3 * c3[1] / steps, "post_calculations_ms": 1e3 * c3[2] / steps,
             "sample": f"{steps} whole step(s) of the oracle's World::update ({kind_name} tree, theta {theta}) on the same bodies in {dt:.2f} s "
-                      f"(oracle/nbody_oracle.cpp, {'-march=native' if native else '-march=x86-64-v3'}; Counting split as main.rs:402/417/424)"}
+                      f"(oracle/nbody_oracle.cpp, {'-march=native' if native else '-march=x86-64-v3'}; Counting split as main.rs:402/417/424)",
+            "sample_short": f"{steps} whole oracle World::update step(s), {kind_name} theta {theta}, {dt:.2f} s"}
 
 
-def _direct_leg(nb, name, workload, pos, vel, w, steps, profile_name, executed=None, cpu_targets=8192, kernel=None):
+def _direct_leg(nb, name, workload, pos, vel, w, steps, profile_name, executed=None, cpu_targets=8192, kernel=None, short=None):
     """A direct-sum leg through the context path (nbody_update_direct_f32), timed like the headline."""
     C = nb._capi
     n = pos.shape[0]
@@ -203,14 +182,14 @@ def _direct_leg(nb, name, workload, pos, vel, w, steps, profile_name, executed=N
         roof["flops_executed_per_pair"] = executed
         roof["frac_executed"] = roof["frac"] * executed / FLOPS_PER_PAIR
     _traffic(roof, profile_name, 36 * n)
-    out = {"leg": name, "workload": workload, "metric": "pair-interactions/s", "value": pairs * steps / dt, "ms_per_step": 1e3 * dt / steps,
-           "steps": steps, "dtype": "f32", "roofline": roof}
+    out = {"leg": name, "workload": workload, "workload_short": short, "metric": "pair-interactions/s", "value": pairs * steps / dt,
+           "ms_per_step": 1e3 * dt / steps, "steps": steps, "dtype": "f32", "roofline": roof}
     if cpu_targets:
         out["cpu_baseline"] = _cpu_direct_sample(pos, w, cpu_targets)
     return out
 
 
-def _tree_leg(nb, name, workload, pos, vel, w, kind, theta, steps, profile_names, order=None, cpu_steps=1, default_arith="exact"):
+def _tree_leg(nb, name, workload, pos, vel, w, kind, theta, steps, profile_names, order=None, cpu_steps=1, default_arith="exact", short=None):
     """A Barnes-Hut leg: whole steps (build + walk + integrate, Counting split) with the reference's arithmetic
     (bit-identical to the oracle) and with the tolerance-contract FAST walk; roofline of the walk kernel priced in flops
     (it is VALU-bound); cpu_baseline = the oracle's World::update on the same bodies, timed in this run."""
@@ -220,7 +199,7 @@ def _tree_leg(nb, name, workload, pos, vel, w, kind, theta, steps, profile_names
     n = pos.shape[0]
     order = C.ORDER_CONSISTENT if order is None else order
     kind_name = "quad" if kind == C.TREE_QUAD else "bvh"
-    out = {"leg": name, "workload": workload, "dtype": "f64" if f64 else "f32", "steps": steps,
+    out = {"leg": name, "workload": workload, "workload_short": short, "dtype": "f64" if f64 else "f32", "steps": steps,
            "order": "as written (main.rs:398-423, SURVEY F6)" if order == C.ORDER_AS_WRITTEN else "consistent"}
     with C.Context(0) as ctx:
         ctx.set_params(theta=theta, order=order)
@@ -252,17 +231,11 @@ def _tree_leg(nb, name, workload, pos, vel, w, kind, theta, steps, profile_names
                     "achieved": ach, "peak": peak,
                     "unit": "TFLOP/s", "frac": ach / peak, "kernel_ms": kms, "launches_timed": kl,
                     "pair_evaluations_per_launch": float(leaf_pairs + accepted), "node_tests_per_launch": float(visits),
-                    "flops_per_pair": PAIR_FLOPS_AS_WRITTEN, "flops_per_node_test": NODE_TEST_FLOPS,
-                    "note": "a division counts as one flop; counts are the mean of the walks before and after the timed steps; "
-                            + ("the as-written pair function does two correctly rounded divisions, which is what holds the fraction down"
-                               if label == "exact" else "one reciprocal per pair, terms summed by lane-parallel trees (tolerance contract)")}
+                    "flops_per_pair": PAIR_FLOPS_AS_WRITTEN, "flops_per_node_test": NODE_TEST_FLOPS}
             # node records and leaf particles reach a wave by scalar loads, shared by its 64 targets: per-target counts / 64 is
             # the lower bound (every lane on the same path); plus the targets read and the accelerations written
             node_b, pair_b = (144, 24) if f64 else (80, 12)
             _traffic(roof, profile_names.get(label, "-"), int(visits * node_b / 64 + leaf_pairs * pair_b / 64 + n * (32 if f64 else 16)))
-            roof["algorithmic_bytes_note"] = ("bytes the waves request if all 64 targets of a wave share their path (wave-uniform scalar loads: "
-                                              "per-target node and leaf bytes / 64) plus targets in, accelerations out; the L2 absorbs part of it, "
-                                              "so the HBM counter can read lower")
             out[label] = {"ms_per_step": 1e3 * dt / steps, "bodies_per_s": n * steps / dt, "build_ms": 1e3 * cnt.build_bvh / steps,
                           "walk_phase_ms": 1e3 * cnt.sum_gravity / steps, "integrate_ms": 1e3 * cnt.post_calculations / steps,
                           "interactions_per_s": (leaf_pairs + accepted) / (kms * 1e-3) if kms > 0 else None, "roofline": roof,
@@ -279,7 +252,19 @@ def _tree_leg(nb, name, workload, pos, vel, w, kind, theta, steps, profile_names
     return out
 
 
-LEGS = ("reference_scene_bvh", "plummer1m_bvh", "config2", "per_body_masses", "reference_scene_direct", "config4")
+# the order they print in: the driver keeps the tail of stdout, so the reference's live path and the BASELINE configs go last
+LEGS = ("plummer1m_bvh", "reference_scene_direct", "mass_classes", "config2", "free_masses", "config4", "reference_scene_bvh")
+
+
+def free_weights(n, seed=SEED):
+    """Free per-body masses for the `free_masses` leg: u32 weights 1 .. 100 000 from splitmix64(seed ^ index) — far more
+    than 32 distinct values, so neither the equal-mass hoist nor the mass classes apply (main.rs:193-198: `weight: u32` per
+    particle, used as `weight as f32`, :360)."""
+    z = (np.arange(n, dtype=np.uint64) ^ np.uint64(seed)) + np.uint64(0x9E3779B97F4A7C15)
+    z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    z = z ^ (z >> np.uint64(31))
+    return (z % np.uint64(100000) + np.uint64(1)).astype(np.uint32)
 
 
 def run_leg(nb, name, cpu=True):
@@ -290,37 +275,165 @@ def run_leg(nb, name, cpu=True):
         pos, vel, w = nb.scenes.galaxy()
         return _tree_leg(nb, name, f"the reference's live path: World::update, BVH, theta 50, leaf 64, on World::new's scene ({pos.shape[0]} bodies, "
                                    "masses 1 but for 75 000 000 and 750 000), f32, NBODY_ORDER_AS_WRITTEN", pos, vel, w, C.TREE_BVH, 50.0, 300,
-                         {"exact": "r03_leg_reference_scene_bvh_pmc.json", "fast": "r03_leg_reference_scene_bvh_fast_pmc.json"},
-                         order=C.ORDER_AS_WRITTEN, cpu_steps=10 if cpu else 0)
+                         {"exact": "r04_leg_reference_scene_bvh_pmc.json", "fast": "r04_leg_reference_scene_bvh_fast_pmc.json"},
+                         order=C.ORDER_AS_WRITTEN, cpu_steps=10 if cpu else 0,
+                         short=f"reference's live path: World::update BVH theta 50 leaf 64, World::new scene, {pos.shape[0]} bodies, f32")
     if name == "plummer1m_bvh":
         pos, vel, w = nb.scenes.plummer(N_BODIES, seed=SEED)
         return _tree_leg(nb, name, "World::update, BVH, theta 50, leaf 64, on the headline's bodies (1 048 576, seeded Plummer, masses 1), f32, "
                                    "NBODY_ORDER_AS_WRITTEN", pos, vel, w, C.TREE_BVH, 50.0, 20,
-                         {"exact": "r03_leg_plummer1m_bvh_pmc.json", "fast": "r03_leg_plummer1m_bvh_fast_pmc.json"},
-                         order=C.ORDER_AS_WRITTEN, cpu_steps=2 if cpu else 0)
+                         {"exact": "r04_leg_plummer1m_bvh_pmc.json", "fast": "r04_leg_plummer1m_bvh_fast_pmc.json"},
+                         order=C.ORDER_AS_WRITTEN, cpu_steps=2 if cpu else 0,
+                         short="World::update BVH theta 50 leaf 64, the headline's 1048576 Plummer bodies, f32")
     if name == "config2":
         pos, vel, w = nb.scenes.plummer(65536, seed=0x5EED0002)
         return _direct_leg(nb, name, "BASELINE.json configs[1]: 65 536 bodies direct O(N^2) f32, Plummer, masses 1", pos, vel, w, 200,
-                           "r03_leg_config2_pmc.json", executed=FLOPS_EXECUTED_PER_PAIR, cpu_targets=65536 if cpu else 0)   # (from 2^32 pairs on the
-                                                                                   # near/far split runs: the same instantiation as the headline; the CPU leg is one whole step)
-    if name == "per_body_masses":
+                           "r04_leg_config2_pmc.json", executed=FLOPS_EXECUTED_PER_PAIR, cpu_targets=65536 if cpu else 0,   # (from 2^32 pairs on the
+                           short="BASELINE configs[1]: 65536 bodies direct f32, Plummer, masses 1")   # near/far split runs: the headline's instantiation; the CPU leg is one whole step)
+    if name == "mass_classes":
         pos, vel, _ = nb.scenes.plummer(N_BODIES, seed=SEED)
         w = (np.arange(N_BODIES) % 5 + 1).astype(np.uint32)
         return _direct_leg(nb, name, "1 048 576 bodies direct f32, Plummer, per-body masses 1..5 (five mass classes: sources in class order, "
                                      "the equal-mass kernel tile by tile)", pos, vel, w, 3,
-                           "r03_leg_per_body_masses_pmc.json", executed=FLOPS_EXECUTED_PER_PAIR, cpu_targets=16384 if cpu else 0)
+                           "r04_leg_mass_classes_pmc.json", executed=FLOPS_EXECUTED_PER_PAIR, cpu_targets=16384 if cpu else 0,
+                           short="1048576 bodies direct f32, Plummer, masses 1..5 (five mass classes)")
+    if name == "free_masses":
+        pos, vel, _ = nb.scenes.plummer(N_BODIES, seed=SEED)
+        w = free_weights(N_BODIES)
+        return _direct_leg(nb, name, f"1 048 576 bodies direct f32, Plummer, free per-body u32 weights 1..100 000 ({len(np.unique(w))} distinct values: "
+                                     "no classes; inverse masses streamed beside the couples, one packed multiply per couple more than the headline)",
+                           pos, vel, w, 3, "r04_leg_free_masses_pmc.json", executed=FLOPS_EXECUTED_PER_PAIR + 1, cpu_targets=16384 if cpu else 0,
+                           kernel=_main_pass_kernel(uniform=False),
+                           short=f"1048576 bodies direct f32, Plummer, free u32 weights 1..100000 ({len(np.unique(w))} distinct)")
     if name == "reference_scene_direct":
         pos, vel, w = nb.scenes.galaxy()
         return _direct_leg(nb, name, f"the reference's own scene (World::new, main.rs:276-346, seeded): {pos.shape[0]} bodies, masses 1 but for "
                                      "75 000 000 and 750 000 — the two ride with the near list, the main pass runs at the equal-mass rate",
-                           pos, vel, w, 50, "r02_leg_reference_scene_direct_pmc.json", executed=FLOPS_EXECUTED_PER_PAIR,
-                           cpu_targets=32768 if cpu else 0)
+                           pos, vel, w, 50, "r04_leg_reference_scene_direct_pmc.json", executed=FLOPS_EXECUTED_PER_PAIR,
+                           cpu_targets=32768 if cpu else 0, short=f"World::new scene direct f32, {pos.shape[0]} bodies, two heavy bodies in the near list")
     if name == "config4":
         pos, vel, w = nb.scenes.plummer(1 << 22, seed=0x5EED0004, dtype=np.float64)
         return _tree_leg(nb, name, "BASELINE.json configs[3]: 4 194 304 bodies Barnes-Hut theta 0.5, linearised quad tree, f64", pos, vel, w,
-                         C.TREE_QUAD, 0.5, 5, {"exact": "r03_leg_config4_pmc.json", "fast": "r03_leg_config4_fast_pmc.json"},
-                         cpu_steps=1 if cpu else 0)
+                         C.TREE_QUAD, 0.5, 5, {"exact": "r04_leg_config4_pmc.json", "fast": "r04_leg_config4_fast_pmc.json"},
+                         cpu_steps=1 if cpu else 0, short="BASELINE configs[3]: 4194304 bodies Barnes-Hut theta 0.5, quad tree, f64")
     raise SystemExit(f"bench.py: unknown leg {name!r} (one of {LEGS})")
+
+
+# ---------------------------------------------------------------------------------------------------- compact lines
+# The driver keeps only the tail of stdout and parses the last line: the printed records are digests (numbers, kernel
+# names, the profile file a traffic figure came from); the prose lives in profiles/README.md, the unabridged records
+# in --full-out.
+HEADLINE_MAX_BYTES = 1900
+LEG_MAX_BYTES = 1000
+
+
+def _r(x, sig=6):
+    """Round a float to `sig` significant digits (bench lines are read by people and by a tail-limited parser)."""
+    if isinstance(x, bool) or not isinstance(x, float):
+        return x
+    if x == 0.0 or x != x or x in (float("inf"), float("-inf")):
+        return x
+    return float(f"{x:.{sig}g}")
+
+
+def _short_source(src):
+    """'profiles/r04_x_pmc.json (rocprofv3 ...)' -> 'profiles/r04_x_pmc.json'"""
+    return src.split(" ")[0] if src else None
+
+
+def _compact_roofline(roof):
+    keep = ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_executed", "kernel_ms", "launches_timed", "traffic")
+    out = {k: _r(roof[k]) for k in keep if k in roof}
+    out["traffic_source"] = _short_source(roof.get("traffic_source"))
+    if roof.get("algorithmic_bytes_per_launch") is not None:
+        out["algorithmic_bytes"] = roof["algorithmic_bytes_per_launch"]
+    return out
+
+
+def _compact_cpu(cpu):
+    if not cpu:
+        return None
+    out = {k: _r(cpu[k]) for k in ("value", "unit", "cores", "kind") if k in cpu}
+    out["sample"] = cpu.get("sample_short") or cpu.get("sample", "")[:120]
+    return out
+
+
+def compact_leg(full):
+    """One leg's digest: < LEG_MAX_BYTES."""
+    if "error" in full:
+        return {"leg": full["leg"], "error": full["error"][:300]}
+    out = {"leg": full["leg"], "workload": full.get("workload_short") or full["workload"][:110], "metric": full["metric"],
+           "value": _r(full["value"]), "ms_per_step": _r(full.get("ms_per_step", full["value"])), "steps": full["steps"],
+           "dtype": full["dtype"]}
+    if "exact" in full:                                    # a tree leg: both arithmetics, the walk kernel's fraction each
+        for label in ("exact", "fast"):
+            a = full[label]
+            rf = a["roofline"]
+            out[label] = {"ms_per_step": _r(a["ms_per_step"], 5), "build_ms": _r(a["build_ms"], 4), "walk_ms": _r(a["walk_phase_ms"], 4),
+                          "kernel": rf["kernel"], "kernel_ms": _r(rf["kernel_ms"], 5), "tflops": _r(rf["achieved"], 4),
+                          "frac": _r(rf["frac"], 4), "traffic": _r(rf.get("traffic"))}
+        out["peak_tflops"] = full["roofline"]["peak"]
+    else:
+        out["roofline"] = _compact_roofline(full["roofline"])
+    cpu = _compact_cpu(full.get("cpu_baseline"))
+    if cpu:
+        out["cpu_baseline"] = cpu
+    return out
+
+
+def _leg_digest(full):
+    """What the headline line says about a leg: ms/step and the dominant kernel's fraction of its roofline."""
+    if "error" in full:
+        return "error"
+    return [_r(full.get("ms_per_step", full["value"]), 5), _r(full["roofline"]["frac"], 4)]
+
+
+def compact_headline(full, legs_full=()):
+    """The driver's line: < HEADLINE_MAX_BYTES, everything the contract names and nothing explanatory."""
+    out = {k: _r(full[k]) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                    "scaling", "vs_baseline", "dtype", "data")}
+    cfg = full["config"]
+    out["config"] = {k: cfg[k] for k in ("workload", "n_bodies", "targets_per_gpu", "chunks_per_step", "n_ranks", "exchange", "arith")
+                     if k in cfg}
+    out["roofline"] = _compact_roofline(full["roofline"])
+    out["roofline"]["flops_per_pair"] = full["roofline"].get("flops_per_pair")
+    if full.get("cpu_baseline"):
+        out["cpu_baseline"] = _compact_cpu(full["cpu_baseline"])
+    if legs_full:
+        out["legs"] = {l["leg"]: _leg_digest(l) for l in legs_full}     # [ms/step, roofline frac]; full lines precede this one
+    return out
+
+
+def dumps_line(obj, limit):
+    """json.dumps with the size contract enforced: a line the driver cannot read is worth nothing, so trim rather than
+    exceed (drop the optional members, last resort the strings)."""
+    line = json.dumps(obj, separators=(", ", ": "))
+    for key in ("legs", "cpu_baseline.sample", "roofline.traffic_source", "config.exchange", "workload", "config.workload"):
+        if len(line) < limit:
+            break
+        tgt, k = obj, key
+        if "." in key:
+            head, k = key.split(".")
+            tgt = obj.get(head) or {}
+        if k in tgt:
+            if isinstance(tgt[k], str) and len(tgt[k]) > 40:
+                tgt[k] = tgt[k][:40]
+            else:
+                del tgt[k]
+        line = json.dumps(obj, separators=(", ", ": "))
+    return line
+
+
+def emit_headline(full, legs_full, full_out=None):
+    """The LAST line of stdout: the compact headline.  The unabridged records go to `full_out` when asked for."""
+    if full_out:
+        try:
+            os.makedirs(os.path.dirname(os.path.abspath(full_out)), exist_ok=True)
+            with open(full_out, "w") as f:
+                json.dump(dict(full, legs=list(legs_full)), f)
+        except OSError as e:
+            print(f"bench.py: could not write {full_out}: {e}", file=sys.stderr)
+    print(dumps_line(compact_headline(full, legs_full), HEADLINE_MAX_BYTES), flush=True)
 
 
 def _headline_roofline(n, n_tgt, kern_ms, kern_launches, steps, single_gpu_full):
@@ -331,14 +444,9 @@ def _headline_roofline(n, n_tgt, kern_ms, kern_launches, steps, single_gpu_full)
             "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_TFLOPS,
             "flops_per_pair": FLOPS_PER_PAIR, "flops_executed_per_pair": FLOPS_EXECUTED_PER_PAIR,
             "frac_executed": achieved / PEAK_F32_TFLOPS * FLOPS_EXECUTED_PER_PAIR / FLOPS_PER_PAIR,
-            "frac_note": "frac prices the 14 ALGORITHMIC flops of a pair; the timed instantiation executes 13 (mass multiply hoisted "
-                         "for equal masses, clamp dropped for far sources, one bias add extra): frac_executed = frac * 13/14",
-            "pairs_per_launch": float(n) * n_tgt / n_launch, "kernel_ms": kern_ms, "launches_timed": kern_launches,
-            "note": "no MFMA on this path (no dense contraction); peak = f32 vector peak"}
+            "pairs_per_launch": float(n) * n_tgt / n_launch, "kernel_ms": kern_ms, "launches_timed": kern_launches}
     if single_gpu_full:
-        _traffic(roof, "r03_direct_pmc.json", 36 * n)
-        if roof["traffic"] is None:
-            _traffic(roof, "r02_direct_pmc.json", 36 * n)
+        _traffic(roof, "r04_direct_pmc.json", 36 * n)
     else:
         roof["traffic"] = None
         roof["traffic_source"] = None
@@ -396,7 +504,7 @@ def run_in_library(args):
                                        else "hipMemcpyPeerAsync of every block to every peer")})
     if g == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(pos, w, args.cpu_sample_targets)
-    print(json.dumps(out), flush=True)
+    emit_headline(out, [], args.full_out)
 
 
 def main():
@@ -407,7 +515,8 @@ def main():
     ap.add_argument("--bodies", dest="n", type=int, default=N_BODIES, help="total bodies (default: the BASELINE config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="skip the non-headline single-GPU configurations")
-    ap.add_argument("--leg", default=None, help=f"run ONE leg alone and print it (for profiling): {', '.join(LEGS)}")
+    ap.add_argument("--leg", default=None, help=f"run ONE leg alone and print its unabridged record (for profiling): {', '.join(LEGS)}")
+    ap.add_argument("--full-out", default=None, help="also write the unabridged records (headline + legs) to this file")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
                                                       "several ranks on one GPU)")
     ap.add_argument("--cpu-sample-targets", type=int, default=131072)
@@ -494,17 +603,18 @@ def main():
                                           + (" (RCCL over xGMI)" if args.backend == "nccl" else " (rehearsal)")})
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pos, w, args.cpu_sample_targets)
+        legs = []
         if world == 1 and not args.no_legs and n == N_BODIES:
             del stepper
             torch.cuda.empty_cache()
-            legs = []
             for name in LEGS:
                 try:
-                    legs.append(run_leg(nb, name, cpu=not args.no_cpu_baseline))
+                    leg = run_leg(nb, name, cpu=not args.no_cpu_baseline)
                 except Exception as e:  # a leg must not cost the headline line
-                    legs.append({"leg": name, "error": repr(e)})
-            out["legs"] = legs
-        print(json.dumps(out), flush=True)
+                    leg = {"leg": name, "error": repr(e)}
+                legs.append(leg)
+                print(dumps_line(compact_leg(leg), LEG_MAX_BYTES), flush=True)
+        emit_headline(out, legs, args.full_out)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

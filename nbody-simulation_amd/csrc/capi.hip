@@ -207,6 +207,10 @@ int ensure_mass_classes(nbody_ctx* c) {
   State<float>& s = c->sf;
   auto& mc = s.classes;
   if (mc.epoch == s.row_epoch) return NBODY_OK;
+  // A captured direct step (DirectGraph) has the class arrays' addresses baked into its kernel arguments: they are about to be
+  // freed and rebuilt for the new row order, so the graph goes with them (an even number of tree steps permutes the
+  // rows and leaves every pointer of the graph's key where it was).
+  c->direct_graph.reset();
   mc.epoch = s.row_epoch;
   mc.usable = false;
   const int64_t n = s.n;
@@ -2019,9 +2023,11 @@ NB_API int nbody_update_direct_f32(nbody_ctx* c, float delta, int n_steps, nbody
     auto& st = s.set[s.cur];
     DirectGraph& g = c->direct_graph;
     const std::string sig = direct_env_signature();
+    const auto& mc = s.classes;
     const bool stale = !g.exec || g.n != s.n || g.pos_a != st.pos || g.pos_b != s.pos_next || g.vel != st.vel ||
                        g.mass != st.mass || g.ws != c->workspace || g.delta != delta || g.clamp != c->params.clamp ||
-                       g.uniform != direct_mass_hint(s) || g.arith != c->params.arith || g.env != sig;
+                       g.uniform != direct_mass_hint(s) || g.arith != c->params.arith || g.env != sig || g.row_epoch != s.row_epoch ||
+                       g.cls_usable != mc.usable || g.cls_rank != (const void*)mc.rank || g.cls_tile_mass != (const void*)mc.tile_mass;
     if (stale) {
       g.reset();
       hipGraph_t graph = nullptr;
@@ -2043,6 +2049,7 @@ NB_API int nbody_update_direct_f32(nbody_ctx* c, float delta, int n_steps, nbody
       } else {
         g.n = s.n; g.pos_a = st.pos; g.pos_b = s.pos_next; g.vel = st.vel; g.mass = st.mass; g.ws = c->workspace;
         g.delta = delta; g.clamp = c->params.clamp; g.uniform = direct_mass_hint(s); g.arith = c->params.arith; g.env = sig;
+        g.row_epoch = s.row_epoch; g.cls_usable = mc.usable; g.cls_rank = mc.rank; g.cls_tile_mass = mc.tile_mass;
       }
     }
     if (g.exec) {

@@ -100,6 +100,10 @@ struct DirectGraph {
   const void *pos_a = nullptr, *pos_b = nullptr, *vel = nullptr, *mass = nullptr, *ws = nullptr;
   float delta = 0.f, clamp = 0.f, uniform = 0.f;
   int arith = -1;
+  // what the step derives from the row order: the mass classes' arrays (their addresses are kernel arguments of the capture)
+  uint64_t row_epoch = ~0ull;
+  bool cls_usable = false;
+  const void *cls_rank = nullptr, *cls_tile_mass = nullptr;
   std::string env;  // the NBODY_DIRECT_* switches read at capture time
   void reset() {
     if (exec) (void)hipGraphExecDestroy(exec);
@@ -109,7 +113,8 @@ struct DirectGraph {
 };
 inline std::string direct_env_signature() {
   std::string sig;
-  for (const char* k : {"NBODY_DIRECT_ASM", "NBODY_DIRECT_NEARFAR", "NBODY_DIRECT_TPT", "NBODY_DIRECT_GSPLIT", "NBODY_DIRECT_NO_UNIFORM"}) {
+  for (const char* k : {"NBODY_DIRECT_ASM", "NBODY_DIRECT_NEARFAR", "NBODY_DIRECT_TPT", "NBODY_DIRECT_GSPLIT", "NBODY_DIRECT_NO_UNIFORM",
+                        "NBODY_DIRECT_NO_CLASSES", "NBODY_DIRECT_NO_SPARSE"}) {
     const char* v = getenv(k);
     sig += v ? v : "-";
     sig += ';';

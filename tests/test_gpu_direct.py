@@ -475,6 +475,48 @@ def test_mass_classes_follow_the_rows_through_a_tree_build(nb, orc, ctx, monkeyp
     assert np.abs(pa[0].astype(np.float64) - pb[0]).max() <= 1e-3 and np.abs(pa[1].astype(np.float64) - pb[1]).max() <= 1e-3
 
 
+def test_captured_direct_graph_is_rebuilt_when_a_tree_step_permutes_the_rows(nb, orc, ctx):
+    """ADVICE r03 (capi.hip DirectGraph): four direct steps at 65 536 <= n <= 131 072 capture the step as a hipGraph with the mass
+    classes' device arrays baked in.  TWO tree steps permute the rows and put every buffer of the graph's key back where it was
+    while ensure_mass_classes frees and rebuilds rank / pad_slots / tile_mass: the next four direct steps must not replay the old
+    capture.  Checked against the same call sequence on a fresh context that never captured before the build (eager first), and
+    against the oracle's accelerations for the final rows."""
+    C = nb._capi
+    n = 70000
+    pos, vel, _ = nb.scenes.plummer(n, seed=148)
+    w = (np.arange(n) % 4 * 3 + 1).astype(np.uint32)
+
+    def run(c, first_direct_steps):
+        c.set_params(arith=C.ARITH_AUTO, theta=50.0, order=C.ORDER_CONSISTENT)
+        c.upload(pos, vel, w)
+        c.update_direct(0.1, first_direct_steps)              # >= 4: captured and replayed
+        c.update_tree(C.TREE_BVH, 0.1, 2)                     # rows permuted twice, buffers back in place
+        mid = c.download()
+        c.update_direct(0.1, 4)                               # replay candidates again
+        return mid, c.download()
+
+    mid_a, end_a = run(ctx, 4)
+    assert not np.array_equal(mid_a[3], np.arange(n))        # the builds did permute the rows
+    with C.Context(0) as fresh:                               # same physics, but the first direct call is too short to capture:
+        fresh.set_params(arith=C.ARITH_AUTO, theta=50.0, order=C.ORDER_CONSISTENT)
+        fresh.upload(pos, vel, w)
+        for _ in range(4):
+            fresh.update_direct(0.1, 1)                       # eager steps (n_steps < 4 never captures)
+        fresh.update_tree(C.TREE_BVH, 0.1, 2)
+        mid_b = fresh.download()
+        fresh.update_direct(0.1, 4)                           # the first capture this context makes: after the permutation
+        end_b = fresh.download()
+    for a, b in zip(mid_a, mid_b):
+        assert np.array_equal(a, b)                           # graph replay and eager steps give the same bits
+    for a, b in zip(end_a, end_b):
+        assert np.array_equal(a, b)                           # ... also after the rows moved under the first graph
+    # and the final state is right in absolute terms: accelerations of the final rows against the oracle
+    p, v, w2, ids = end_a
+    acc = ctx.accel_direct()
+    tg = np.arange(0, n, 31)
+    check_fast(acc[tg], *_refs(orc, p, w2, targets=tg)[:2], label=" after graph, builds, graph")
+
+
 # ------------------------------------------------------------------ the main pass's variants (NBODY_DIRECT_ASM)
 @pytest.mark.parametrize("n", [65536 + 16 * 5 + 3, 131072, 200003])
 def test_packed_and_streamed_main_pass_agree(nb, orc, ctx, monkeypatch, n):
