@@ -256,17 +256,6 @@ def _tree_leg(nb, name, workload, pos, vel, w, kind, theta, steps, profile_names
 LEGS = ("plummer1m_bvh", "reference_scene_direct", "mass_classes", "config2", "free_masses", "config4", "reference_scene_bvh")
 
 
-def free_weights(n, seed=SEED):
-    """Free per-body masses for the `free_masses` leg: u32 weights 1 .. 100 000 from splitmix64(seed ^ index) — far more
-    than 32 distinct values, so neither the equal-mass hoist nor the mass classes apply (main.rs:193-198: `weight: u32` per
-    particle, used as `weight as f32`, :360)."""
-    z = (np.arange(n, dtype=np.uint64) ^ np.uint64(seed)) + np.uint64(0x9E3779B97F4A7C15)
-    z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
-    z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
-    z = z ^ (z >> np.uint64(31))
-    return (z % np.uint64(100000) + np.uint64(1)).astype(np.uint32)
-
-
 def run_leg(nb, name, cpu=True):
     C = nb._capi
     if name == "reference_scene_bvh":
@@ -299,7 +288,7 @@ def run_leg(nb, name, cpu=True):
                            short="1048576 bodies direct f32, Plummer, masses 1..5 (five mass classes)")
     if name == "free_masses":
         pos, vel, _ = nb.scenes.plummer(N_BODIES, seed=SEED)
-        w = free_weights(N_BODIES)
+        w = nb.scenes.free_weights(N_BODIES, seed=SEED)
         return _direct_leg(nb, name, f"1 048 576 bodies direct f32, Plummer, free per-body u32 weights 1..100 000 ({len(np.unique(w))} distinct values: "
                                      "no classes; inverse masses streamed beside the couples, one packed multiply per couple more than the headline)",
                            pos, vel, w, 3, "r04_leg_free_masses_pmc.json", executed=FLOPS_EXECUTED_PER_PAIR + 1, cpu_targets=16384 if cpu else 0,
@@ -393,7 +382,7 @@ def compact_headline(full, legs_full=()):
     out = {k: _r(full[k]) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
                                     "scaling", "vs_baseline", "dtype", "data")}
     cfg = full["config"]
-    out["config"] = {k: cfg[k] for k in ("workload", "n_bodies", "targets_per_gpu", "chunks_per_step", "n_ranks", "exchange", "arith")
+    out["config"] = {k: cfg[k] for k in ("workload", "n_bodies", "targets_per_gpu", "chunks_per_step", "n_ranks", "entry", "exchange", "arith")
                      if k in cfg}
     out["roofline"] = _compact_roofline(full["roofline"])
     out["roofline"]["flops_per_pair"] = full["roofline"].get("flops_per_pair")
@@ -408,7 +397,7 @@ def dumps_line(obj, limit):
     """json.dumps with the size contract enforced: a line the driver cannot read is worth nothing, so trim rather than
     exceed (drop the optional members, last resort the strings)."""
     line = json.dumps(obj, separators=(", ", ": "))
-    for key in ("legs", "cpu_baseline.sample", "roofline.traffic_source", "config.exchange", "workload", "config.workload"):
+    for key in ("legs", "cpu_baseline.sample", "roofline.traffic_source", "config.entry", "config.exchange", "workload", "config.workload"):
         if len(line) < limit:
             break
         tgt, k = obj, key
@@ -597,7 +586,7 @@ def main():
         roof = _headline_roofline(n, n_tgt, kern_ms, kern_launches, args.steps, world == 1 and n == N_BODIES)
         out = _headline_line(args, n, world, elapsed, roof,
                              {"targets_per_gpu": n_tgt, "chunks_per_step": stepper.chunks,
-                              "entry": "one process per GPU (sharding.py over nbody_direct_prep_dev / nbody_direct_run_dev)",
+                              "entry": "one process per GPU (sharding.py over nbody_direct_{prep,run}_dev)",
                               "n_ranks": dist.get_world_size() if world > 1 else 1,
                               "exchange": "none" if world == 1 else f"{args.backend} in-place all-gather of float2 positions per chunk"
                                           + (" (RCCL over xGMI)" if args.backend == "nccl" else " (rehearsal)")})

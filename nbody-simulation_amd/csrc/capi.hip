@@ -296,6 +296,7 @@ struct DirectPlan {
   const State<float>::MassClasses* classes = nullptr;  // masses in a few classes: the far copy in class order, equal-mass arithmetic per tile
   bool nearfar = false;
   bool couples = false;  // the far copy in couples {xA, xB, yA, yB}, padded to whole 16-source iterations (the packed kernels)
+  bool stream_m = false; // free per-body masses through the streamed main pass: the far copy carries 1 / mass in slot order
   int use_hazard = 0;
   size_t partial_bytes = 0;
 };
@@ -320,6 +321,7 @@ int direct_plan(nbody_ctx* c, int64_t n_src, const void* mass_all, float uniform
   if (uniform_mass < 0.f && p.nearfar && env_int("NBODY_DIRECT_NO_UNIFORM", 0) == 0 && env_int("NBODY_DIRECT_NO_SPARSE", 0) == 0)
     p.sparse_base = -uniform_mass;
   if (!p.uni && p.sparse_base == 0.f && p.nearfar) p.classes = classes_for(c, n_src, mass_all);
+  p.stream_m = !p.uni && p.sparse_base == 0.f && !p.classes && p.couples && env_int("NBODY_DIRECT_ASM", 3) >= 3;
   p.use_hazard = arith == NBODY_ARITH_AUTO;
   p.partial_bytes = direct_partial_bytes(n_src, n_tgt_max);
   *out = p;
@@ -343,9 +345,11 @@ int direct_prep(nbody_ctx* c, hipStream_t stream, int64_t n_src, const void* pos
     NearFarLayout L = nearfar_layout(n_src);
     const float2* pos_far = nullptr;
     const uint32_t* near_list = nullptr;
+    const float* minv_far = nullptr;
     HIPCHK(c, launch_nearfar(stream, (const float2*)pos_all, (const float*)mass_all, p.sparse_base, (int)n_src, clamp, p.use_hazard, flags,
                              nf_scratch, L, &pos_far, &near_list, p.classes ? p.classes->rank : nullptr,
-                             p.classes ? p.classes->pad_slots : nullptr, p.classes ? p.classes->n_pad_slots : 0, p.couples));
+                             p.classes ? p.classes->pad_slots : nullptr, p.classes ? p.classes->n_pad_slots : 0, p.couples,
+                             p.stream_m ? &minv_far : nullptr));
   } else {
     HIPCHK(c, launch_decide_simple(stream, p.use_hazard, flags));
   }
@@ -397,11 +401,13 @@ int direct_run(nbody_ctx* c, hipStream_t stream, int64_t n_src, const void* pos_
   }
   const float2* pos_far = nullptr;
   const uint32_t* near_list = nullptr;
+  const float* minv_far = nullptr;
   if (cfg.nearfar) {
     char* nf_scratch = (char*)ws + kFlagBytes + p.partial_bytes;
     NearFarLayout L = nearfar_layout(n_src);
     pos_far = (const float2*)(nf_scratch + L.pos_far);
     near_list = (const uint32_t*)(nf_scratch + L.near_list);
+    if (p.stream_m) minv_far = (const float*)(nf_scratch + L.minv_far);
   }
   {
     TimerScope ts(timer, stream);
@@ -409,6 +415,7 @@ int direct_run(nbody_ctx* c, hipStream_t stream, int64_t n_src, const void* pos_
       DirectArgs a0 = a;
       a0.src_pos = pos_far;
       a0.src_couples = p.couples ? 1 : 0;
+      a0.src_minv = minv_far;
       if (p.couples) a0.n_src = (int)far_padded(n_src);
       a0.near_list = near_list;
       a0.to_partial = 1;

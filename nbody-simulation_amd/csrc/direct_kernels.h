@@ -29,6 +29,7 @@ struct DirectArgs {
   int run_state;       // the kernel runs only when flags[kFlagState] == run_state; < 0: always
   const uint32_t* near_list;  // near sources (ascending body index), count in flags[kFlagNearCount]
   int src_couples;            // src_pos is in couples {xA, xB, yA, yB} (nearfar.hip, far_store<true>), n_src a multiple of kFarPad
+  const float* src_minv;      // free per-body masses, streamed main pass: 1 / mass in the far copy's slot order (nearfar.hip); null otherwise
   const float* tile_mass;     // mass classes (capi.hip): src_pos is ordered by mass class, every 1024-source tile holds ONE class
                               // (classes padded with far-away points) and tile_mass[tile] is its mass; null otherwise
 };
@@ -42,7 +43,7 @@ struct DirectConfig {
 };
 
 struct NearFarLayout {
-  size_t table_keys, table_bytes, is_near, scan, near_list, pos_far, cub_temp, cub_temp_bytes, total;
+  size_t table_keys, table_bytes, is_near, scan, near_list, pos_far, minv_far, cub_temp, cub_temp_bytes, total;
 };
 NearFarLayout nearfar_layout(int64_t n_src);
 // heavy_base > 0: bodies whose mass differs from it join the near list (sparse-heavy scenes; `mass` is then read)
@@ -56,7 +57,10 @@ constexpr int kFarPad = 16;  // a far copy in couples is padded with far-away po
 __host__ __device__ inline int64_t far_padded(int64_t n_slots) { return (n_slots + kFarPad - 1) / kFarPad * kFarPad; }
 hipError_t launch_nearfar(hipStream_t s, const float2* pos, const float* mass, float heavy_base, int n, float clamp, int use_hazard,
                           int* flags, char* scratch, const NearFarLayout& L, const float2** pos_far, const uint32_t** near_list,
-                          const uint32_t* rank = nullptr, const uint32_t* pad_slots = nullptr, int n_pad_slots = 0, bool couples = false);
+                          const uint32_t* rank = nullptr, const uint32_t* pad_slots = nullptr, int n_pad_slots = 0, bool couples = false,
+                          const float** minv_far = nullptr);
+// minv_far (optional, couples without classes): receives the far copy's second array, 1 / mass in slot order — the streamed
+// per-body-mass main pass reads it (direct_stream_m)
 hipError_t launch_decide_simple(hipStream_t s, int use_hazard, int* flags);
 
 hipError_t launch_direct_fast(hipStream_t s, const DirectArgs& a, const DirectConfig& c, bool noclamp);

@@ -523,6 +523,66 @@ __device__ __forceinline__ void stream_chunk(v2f t, unsigned long long bias2, co
         "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60",
         "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "scc", "memory");
 }
+// The same loop for FREE per-body masses (more than 32 distinct u32 weights: neither the equal-mass hoist nor the mass classes
+// apply — main.rs:193-198 gives every particle its own `weight`, :360 uses it as f32).  The inverse masses of a block's eight
+// sources arrive beside its couples by one s_load_dwordx8 from the far copy's second array (nearfar.hip writes 1/m in slot order:
+// couple k's pair is {1/mA, 1/mB}, adjacent), and scale the denominators before the reciprocal — s = 1 / (den / m), one packed
+// multiply on an SGPR pair per couple: 13 slots per couple against the equal-mass loop's 12.  1/0 = inf keeps a zero-mass source
+// at exactly 0.  Same arithmetic and order of additions as direct_fast<1, false, true, 2> (fast_block8p's NB_MINVS): the same bits.
+#define NB_S_COUPLE_D(Q, S) "v_pk_fma_f32 v[" S "], v[" S "], v[" Q "], %[b]\n\t"
+#define NB_S_COUPLE_M(S, M) "v_pk_mul_f32 v[" S "], v[" S "], s[" M "]\n\t"
+#define NB_S_COUPLE_R(SL, SH) "v_rcp_f32 v" SL ", v" SL "\n\tv_rcp_f32 v" SH ", v" SH "\n\t"
+#define NB_S_BLOCK_M(S0, S1, S2, S3, S4, S5, S6, S7, M0, M1, M2, M3)                                                                     \
+  NB_S_SUBX("24:25", S0) NB_S_SUBY("26:27", S1) NB_S_SUBX("28:29", S2) NB_S_SUBY("30:31", S3) NB_S_SUBX("32:33", S4) NB_S_SUBY("34:35", S5) \
+  NB_S_SUBX("36:37", S6) NB_S_SUBY("38:39", S7)                                                                                          \
+  NB_S_COUPLE_A("24:25", "26:27", "40:41") NB_S_COUPLE_A("28:29", "30:31", "44:45") NB_S_COUPLE_A("32:33", "34:35", "48:49") NB_S_COUPLE_A("36:37", "38:39", "52:53") \
+  "s_setprio 0\n\t"                                                                                                                    \
+  NB_S_COUPLE_S("24", "25", "26", "27", "42", "43") NB_S_COUPLE_S("28", "29", "30", "31", "46", "47")                                    \
+  NB_S_COUPLE_S("32", "33", "34", "35", "50", "51") NB_S_COUPLE_S("36", "37", "38", "39", "54", "55")                                    \
+  "s_setprio 1\n\t"                                                                                                                    \
+  NB_S_COUPLE_D("40:41", "42:43") NB_S_COUPLE_D("44:45", "46:47") NB_S_COUPLE_D("48:49", "50:51") NB_S_COUPLE_D("52:53", "54:55")         \
+  NB_S_COUPLE_M("42:43", M0) NB_S_COUPLE_R("42", "43") NB_S_COUPLE_M("46:47", M1) NB_S_COUPLE_R("46", "47")                             \
+  NB_S_COUPLE_M("50:51", M2) NB_S_COUPLE_R("50", "51") NB_S_COUPLE_M("54:55", M3) NB_S_COUPLE_R("54", "55")                             \
+  NB_S_COUPLE_C("24:25", "26:27", "42:43") NB_S_COUPLE_C("28:29", "30:31", "46:47") NB_S_COUPLE_C("32:33", "34:35", "50:51") NB_S_COUPLE_C("36:37", "38:39", "54:55")
+// n16 >= 1 iterations of 16 sources: couples from `src` (64-byte aligned), inverse masses from `minv` (32-byte aligned), both
+// wave-uniform; both arrays carry one block of slack past the range (the last prefetch is issued and drained, never used)
+__device__ __forceinline__ void stream_chunk_m(v2f t, unsigned long long bias2, const void* src, const void* minv, int n16, v2f& accx,
+                                               v2f& accy) {
+  asm volatile(
+      "s_mov_b64 s[68:69], %[p]\n\t"
+      "s_mov_b64 s[88:89], %[q]\n\t"
+      "s_mov_b32 s70, %[n]\n\t"
+      "s_load_dwordx16 s[36:51], s[68:69], 0x0\n\t"
+      "s_load_dwordx8 s[72:79], s[88:89], 0x0\n"
+      ".Lnb_stream_m_%=:\n\t"
+      "s_waitcnt lgkmcnt(0)\n\t"
+      "s_load_dwordx16 s[52:67], s[68:69], 0x40\n\t"
+      "s_load_dwordx8 s[80:87], s[88:89], 0x20\n\t"
+      NB_S_BLOCK_M("36:37", "38:39", "40:41", "42:43", "44:45", "46:47", "48:49", "50:51", "72:73", "74:75", "76:77", "78:79")
+      "s_add_u32 s68, s68, 0x80\n\t"
+      "s_addc_u32 s69, s69, 0\n\t"
+      "s_add_u32 s88, s88, 0x40\n\t"
+      "s_addc_u32 s89, s89, 0\n\t"
+      "s_waitcnt lgkmcnt(0)\n\t"
+      "s_load_dwordx16 s[36:51], s[68:69], 0x0\n\t"
+      "s_load_dwordx8 s[72:79], s[88:89], 0x0\n\t"
+      NB_S_BLOCK_M("52:53", "54:55", "56:57", "58:59", "60:61", "62:63", "64:65", "66:67", "80:81", "82:83", "84:85", "86:87")
+      "s_sub_u32 s70, s70, 1\n\t"
+      "s_cmp_lg_u32 s70, 0\n\t"
+      "s_cbranch_scc1 .Lnb_stream_m_%=\n\t"
+      "s_waitcnt lgkmcnt(0)\n\t"
+      : [ax] "+v"(accx), [ay] "+v"(accy)
+      : [t] "v"(t), [b] "s"(bias2), [p] "s"(src), [q] "s"(minv), [n] "s"(n16)
+      : "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42",
+        "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "s36", "s37", "s38", "s39", "s40", "s41",
+        "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60",
+        "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80",
+        "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "scc", "memory");
+}
+#undef NB_S_COUPLE_D
+#undef NB_S_COUPLE_M
+#undef NB_S_COUPLE_R
+#undef NB_S_BLOCK_M
 #undef NB_S_SUBX
 #undef NB_S_SUBY
 #undef NB_S_COUPLE_A
@@ -532,9 +592,10 @@ __device__ __forceinline__ void stream_chunk(v2f t, unsigned long long bias2, co
 #undef NB_S_BLOCK
 
 // Block = 4 waves sharing 64 targets; wave w takes sources [256 w, 256 w + 256) of every 1024-source tile of its grid split —
-// the assignment and the two-level summation of direct_fast, so the sums are the same.
-__global__ __launch_bounds__(256) void direct_stream(const DirectArgs a) {
-  if (!gate_open(a)) return;
+// the assignment and the two-level summation of direct_fast, so the sums are the same.  PER_MASS: direct_stream_m, the inverse
+// masses streamed beside the couples (a.src_minv, slot order).
+template <bool PER_MASS>
+__device__ __forceinline__ void direct_stream_body(const DirectArgs& a) {
   constexpr int TILE = 1024, SHARE = 256;
   const int lane = threadIdx.x & 63;
   const int ws = wave_id_uniform();
@@ -544,7 +605,7 @@ __global__ __launch_bounds__(256) void direct_stream(const DirectArgs a) {
   float ax = 0.f, ay = 0.f;
   int gchunk = (a.n_src + (int)gridDim.y - 1) / (int)gridDim.y;
   gchunk = (gchunk + 31) & ~31;
-  const float* __restrict__ class_mass = a.tile_mass;
+  const float* __restrict__ class_mass = PER_MASS ? nullptr : a.tile_mass;
   if (class_mass) gchunk = (gchunk + TILE - 1) & ~(TILE - 1);
   long g0l = (long)blockIdx.y * gchunk;
   const int g0 = g0l < a.n_src ? (int)g0l : a.n_src;
@@ -559,13 +620,19 @@ __global__ __launch_bounds__(256) void direct_stream(const DirectArgs a) {
     if (hi > cnt) hi = cnt > lo ? cnt : lo;
     v2f accx = {0.f, 0.f}, accy = {0.f, 0.f};
     const int n16 = __builtin_amdgcn_readfirstlane((hi - lo) >> 4);  // (n_src, hence every bound here, is a multiple of 16)
-    if (n16 > 0) stream_chunk(tgt, bias2, reinterpret_cast<const char*>(a.src_pos) + (size_t)(base + lo) * 8, n16, accx, accy);
+    if (n16 > 0) {
+      const char* couples = reinterpret_cast<const char*>(a.src_pos) + (size_t)(base + lo) * 8;
+      if constexpr (PER_MASS) stream_chunk_m(tgt, bias2, couples, reinterpret_cast<const char*>(a.src_minv) + (size_t)(base + lo) * 4, n16, accx, accy);
+      else stream_chunk(tgt, bias2, couples, n16, accx, accy);
+    }
     const float bx = accx.x + accx.y, by = accy.x + accy.y;
     ax = __builtin_fmaf(bx, tm, ax);
     ay = __builtin_fmaf(by, tm, ay);
   }
-  ax *= a.uniform_mass;
-  ay *= a.uniform_mass;
+  if constexpr (!PER_MASS) {
+    ax *= a.uniform_mass;
+    ay *= a.uniform_mass;
+  }
   __shared__ float2 red[3][64];
   if (ws > 0) red[ws - 1][lane] = make_float2(ax, ay);
   __syncthreads();
@@ -579,6 +646,14 @@ __global__ __launch_bounds__(256) void direct_stream(const DirectArgs a) {
   if (t >= a.n_tgt) return;
   if (a.to_partial) a.partial[(size_t)blockIdx.y * a.n_tgt + t] = make_float2(ax, ay);
   else integrate_store(a, t, ax, ay);
+}
+__global__ __launch_bounds__(256) void direct_stream(const DirectArgs a) {
+  if (!gate_open(a)) return;
+  direct_stream_body<false>(a);
+}
+__global__ __launch_bounds__(256) void direct_stream_m(const DirectArgs a) {
+  if (!gate_open(a)) return;
+  direct_stream_body<true>(a);
 }
 
 // Completes a step whose main pass wrote partial sums: adds the grid-split partials in ascending split order,
@@ -675,8 +750,10 @@ hipError_t launch_direct_fast(hipStream_t s, const DirectArgs& a, const DirectCo
   const int tpt = c.tpt == 2 ? 2 : 1;
   const int use_asm = tpt == 1 ? c.use_asm : 0;
   if (a.src_couples && (use_asm < 2 || (a.n_src % kFarPad) != 0)) return hipErrorInvalidValue;  // only the packed kernels read couples
-  if (use_asm == 3 && uni && noclamp && a.src_couples) {
-    hipLaunchKernelGGL(direct_stream, dim3((unsigned)((a.n_tgt + 63) / 64), (unsigned)c.gsplit), dim3(256), 0, s, a);
+  if (use_asm == 3 && noclamp && a.src_couples && (uni || a.src_minv)) {
+    const dim3 grid((unsigned)((a.n_tgt + 63) / 64), (unsigned)c.gsplit);
+    if (uni) hipLaunchKernelGGL(direct_stream, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(direct_stream_m, grid, dim3(256), 0, s, a);
     return hipGetLastError();
   }
 #define NB_GO(T, U, N, A) launch_fast_k<T, U, N, A>(s, a, c.gsplit)

@@ -154,7 +154,8 @@ __global__ __launch_bounds__(256) void nf_compact(const float2* __restrict__ pos
                                                   const uint32_t* __restrict__ scan, int n, float2* __restrict__ pos_far,
                                                   uint32_t* __restrict__ near_list, const uint32_t* __restrict__ rank,
                                                   const uint32_t* __restrict__ pad_slots, int n_pad_slots, int n_slots, int max_near,
-                                                  int use_hazard, int* __restrict__ flags) {
+                                                  int use_hazard, int* __restrict__ flags, const float* __restrict__ mass,
+                                                  float* __restrict__ minv_far) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i == n - 1) {  // state: 0 = near/far split (no clamp in the main pass), 1 = single clamped pass, 2 = EXACT kernel
     const int m = (int)(scan[n - 1] + is_near[n - 1]);
@@ -166,7 +167,10 @@ __global__ __launch_bounds__(256) void nf_compact(const float2* __restrict__ pos
   if (i >= n) {
     const int k = i - n;
     if (k < n_pad_slots) far_store<COUPLES>(pos_far, pad_slots[k], make_float2(1e30f, 1e30f));
-    else if (COUPLES && k - n_pad_slots < (int)far_padded(n_slots) - n_slots) far_store<COUPLES>(pos_far, (uint32_t)(n_slots + k - n_pad_slots), make_float2(1e30f, 1e30f));
+    else if (COUPLES && k - n_pad_slots < (int)far_padded(n_slots) - n_slots) {
+      far_store<COUPLES>(pos_far, (uint32_t)(n_slots + k - n_pad_slots), make_float2(1e30f, 1e30f));
+      if (minv_far) minv_far[n_slots + k - n_pad_slots] = 1.0f;  // (any finite value: the far-away point contributes 0)
+    }
     return;
   }
   float2 p = pos[i];
@@ -175,6 +179,9 @@ __global__ __launch_bounds__(256) void nf_compact(const float2* __restrict__ pos
     p = make_float2(1e30f, 1e30f);
   }
   far_store<COUPLES>(pos_far, rank ? rank[i] : (uint32_t)i, p);
+  // free per-body masses (no classes: slot = body): the inverse mass the streamed main pass multiplies the denominator by.
+  // IEEE division, as direct_fast's tile_minv; 1/0 = inf: a zero-mass source contributes exactly 0
+  if (minv_far) minv_far[i] = 1.0f / mass[i];
 }
 
 __global__ void nf_decide_simple(int use_hazard, int* __restrict__ flags) {
@@ -204,6 +211,7 @@ NearFarLayout nearfar_layout(int64_t n_src) {
   L.scan = off; off += align_up(n * 4);
   L.near_list = off; off += align_up(n * 4);
   L.pos_far = off; off += align_up((n + (size_t)(kMaxMassClasses + 1) * (size_t)kDirectTile + 2 * kFarPad) * 8);  // (room for the mass classes' padding, the couples' padding and one iteration read ahead)
+  L.minv_far = off; off += align_up((n + 4 * (size_t)kFarPad) * 4);  // (free masses, no classes: slot = body; the couples' padding and one iteration read ahead)
   L.cub_temp = off;
   size_t need_scan = 0;
   (void)hipcub::DeviceScan::ExclusiveSum(nullptr, need_scan, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)n, (hipStream_t) nullptr);
@@ -216,7 +224,7 @@ NearFarLayout nearfar_layout(int64_t n_src) {
 // Enqueues the split.  On return flags[kFlagState] is (will be) valid on the stream.
 hipError_t launch_nearfar(hipStream_t s, const float2* pos, const float* mass, float heavy_base, int n, float clamp, int use_hazard,
                           int* flags, char* scratch, const NearFarLayout& L, const float2** pos_far, const uint32_t** near_list,
-                          const uint32_t* rank, const uint32_t* pad_slots, int n_pad_slots, bool couples) {
+                          const uint32_t* rank, const uint32_t* pad_slots, int n_pad_slots, bool couples, const float** minv_far) {
   uint32_t* table = (uint32_t*)(scratch + L.table_keys);
   uint32_t* is_near = (uint32_t*)(scratch + L.is_near);
   uint32_t* scan = (uint32_t*)(scratch + L.scan);
@@ -224,6 +232,12 @@ hipError_t launch_nearfar(hipStream_t s, const float2* pos, const float* mass, f
   float2* far = (float2*)(scratch + L.pos_far);
   *pos_far = far;
   *near_list = list;
+  float* minv = nullptr;
+  if (minv_far) {
+    if (!couples || rank || !mass) return hipErrorInvalidValue;  // slot order = body order only without classes
+    minv = (float*)(scratch + L.minv_far);
+    *minv_far = minv;
+  }
   const double h = sqrt((double)clamp) * 1.001;  // pitch strictly above sqrt(clamp), margin >> f32 rounding of d2
   const unsigned blocks = (unsigned)((n + 255) / 256);
   const uint32_t tmask = table_slots(n) - 1;
@@ -242,10 +256,10 @@ hipError_t launch_nearfar(hipStream_t s, const float2* pos, const float* mass, f
   const unsigned cblocks = (unsigned)((n + n_pad + (couples ? kFarPad : 0) + 255) / 256);
   if (couples)
     hipLaunchKernelGGL(nf_compact<true>, dim3(cblocks), dim3(256), 0, s, pos, is_near, scan, n, far, list, rank, pad_slots, n_pad, n_slots, n / 64,
-                       use_hazard, flags);
+                       use_hazard, flags, mass, minv);
   else
     hipLaunchKernelGGL(nf_compact<false>, dim3(cblocks), dim3(256), 0, s, pos, is_near, scan, n, far, list, rank, pad_slots, n_pad, n_slots,
-                       n / 64, use_hazard, flags);
+                       n / 64, use_hazard, flags, mass, (float*)nullptr);
   return hipGetLastError();
 }
 

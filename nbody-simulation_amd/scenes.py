@@ -70,6 +70,16 @@ def plummer(n: int, seed: int = 0x5EED0000, *, scale: float = 5000.0, clip: floa
     return pos, vel, np.ones(n, np.uint32)
 
 
+def free_weights(n: int, seed: int = 0x5EED0003, top: int = 100_000, start: int = 0) -> np.ndarray:
+    """Free per-body masses: u32 weights 1 .. `top` from splitmix64(seed ^ index) — far more than 32 distinct values, so
+    neither the equal-mass hoist nor the mass classes of the direct step apply (main.rs:193-198: every particle carries its
+    own `weight: u32`, used as `weight as f32`, :360).  bench.py's `free_masses` leg and its parity test use these."""
+    idx = np.arange(start, start + n, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        z = splitmix64(idx ^ np.uint64(seed))
+    return (z % np.uint64(top) + np.uint64(1)).astype(np.uint32)
+
+
 def galaxy(seed: int = 0xC0FFEE, dtype=np.float32):
     """The scene of World::new (main.rs:276-346), seeded.  N ~ 151 000 (2 + ~51 k lattice + 100 000)."""
     height = 100_000

@@ -111,9 +111,13 @@ def test_emit_headline_prints_it_last_and_writes_the_full_record(bench, canned, 
 
 
 def test_free_weights_leg_has_no_mass_classes(bench):
-    w = bench.free_weights(1 << 20)
+    import sys
     import numpy as np
+    sys.path.insert(0, ROOT)
+    from nbody_simulation_amd import scenes
+    w = scenes.free_weights(1 << 20, seed=bench.SEED)
     assert w.dtype == np.uint32 and w.min() >= 1 and w.max() <= 100000
     assert len(np.unique(w)) > 1000                  # > 32 distinct values: neither the equal-mass hoist nor the classes apply
-    assert np.array_equal(w, bench.free_weights(1 << 20))
+    assert np.array_equal(w, scenes.free_weights(1 << 20, seed=bench.SEED))
+    assert np.array_equal(w[1000:2000], scenes.free_weights(1000, seed=bench.SEED, start=1000))
     assert "free_masses" in bench.LEGS and "mass_classes" in bench.LEGS

@@ -168,6 +168,29 @@ def test_config3_1M_sampled_targets_and_properties(nb, orc, ctx):
     assert np.array_equal(p1, pos + v_exp * dt)
 
 
+def test_free_masses_1M_streamed_sampled_and_properties(nb, orc, ctx):
+    """free per-body masses (main.rs:193-198, `weight as f32` at :360) at the headline's size through the
+    streamed main pass (direct_stream_m: inverse masses beside the couples).  bench.py's `free_masses` leg: the same bodies and
+    weights.  4 096 sampled targets against the oracle; determinism; one full step integrates as the reference writes it;
+    a different kernel from the equal-mass one really ran (the accelerations differ from the masses-1 ones)."""
+    n = 1 << 20
+    pos, vel, _ = nb.scenes.plummer(n, seed=0x5EED0003)
+    w = nb.scenes.free_weights(n, seed=0x5EED0003)
+    assert len(np.unique(w)) > 1000
+    ctx.set_params(arith=nb._capi.ARITH_AUTO)
+    ctx.upload(pos, vel, w)
+    acc = ctx.accel_direct()
+    tg = np.arange(0, n, 256)
+    rg, rc = check_fast(acc[tg], *_refs(orc, pos, w, targets=tg), label=" free masses 1M")
+    print(f"1M free masses sampled: max err/norm gpu {rg:.3e}, cpu f32 sequential {rc:.3e}")
+    assert np.array_equal(acc, ctx.accel_direct())        # bitwise deterministic
+    ctx.update_direct(0.1, 1)
+    p1, v1, w1, _ = ctx.download()
+    dt = F32(0.1)
+    v_exp = vel + acc * dt
+    assert np.array_equal(v1, v_exp) and np.array_equal(p1, pos + v_exp * dt) and np.array_equal(w1, w)
+
+
 def test_fast_trajectory_1024x100(nb, orc, ctx):
     pos, vel, w = nb.scenes.plummer(1024, seed=0x5EED0001)
     ctx.set_params(arith=nb._capi.ARITH_FAST)
@@ -529,7 +552,9 @@ def test_packed_and_streamed_main_pass_agree(nb, orc, ctx, monkeypatch, n):
     pos[100] = pos[200]                                      # coincident: contributes nothing
     pos[300] = pos[400] + F32(0.0078125)                     # inside the clamp radius: near bodies
     tg = np.arange(0, n, 41)
-    for w in (w1, (1 + np.arange(n) % 5).astype(np.uint32)):
+    wfree = np.random.default_rng(n).integers(1, 1 << 20, n).astype(np.uint32)   # free masses: > 32 values, direct_stream_m
+    wfree[5], wfree[6], wfree[7] = 0, 4_000_000_000, 75_000_000                  # a massless body (1/0 = inf: exactly 0), huge ones
+    for w in (w1, (1 + np.arange(n) % 5).astype(np.uint32), wfree):
         ref64, norm, cpu32 = _refs(orc, pos, w, targets=tg)
         got = {}
         for mode in ("0", "1", "2", "3"):
