@@ -1187,9 +1187,9 @@ __global__ __launch_bounds__(256) void walk_check_est_tail(EstimateOf est, const
 // spent three on them: the library scan's two kernels and walk_check_est_tail, 32 us of a 1.1 ms step).  A single-pass scan
 // with decoupled look-back: a work-group takes a ticket (arrival order, so every predecessor is running or done), scans its
 // 1 024 estimates, publishes its aggregate, looks back over its predecessors' states until it meets an inclusive prefix, and
-// publishes its own.  States are 64-bit words {epoch : 30 | flag : 2 | value : 32} read and written whole; the epoch (kept
-// beside the ticket, advanced by the work-group with the last ticket, which also puts the ticket back to zero: by then every
-// group has read both) makes last launch's states invisible, so the host clears the area once, when it allocates it, and
+// publishes its own.  States are 64-bit words {epoch : 30 | flag : 2 | value : 32} read and written whole; the epoch (the high
+// half of the ticket word st[0], drawn with the ticket by one 64-bit atomicAdd; the work-group with the last ticket stores
+// {epoch + 1, ticket 0}: by then every group has drawn) makes last launch's states invisible, so the host clears the area once, when it allocates it, and
 // keeps no books.  Values saturate at 2^31: a total that large is the overflow the walk must not run with (the old check's
 // wrapped 32-bit sums), and offsets are not needed then.  A look-back that waits absurdly long gives up with a saturated
 // prefix: the walk is then skipped and the host walks the plain way — never a hang.  The work-group with the last ticket
@@ -1208,8 +1208,12 @@ __global__ __launch_bounds__(256) void walk_scan_est_tail(EstimateOf est, uint32
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (tid == 0 && blockIdx.x == 0 && tail.stamp) *tail.stamp = (unsigned long long)wall_clock64();
   if (tid == 0) {
-    s_epoch = (unsigned)__hip_atomic_load(&st[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (before the ticket: see above)
-    s_b = atomicAdd((unsigned*)&st[0], 1u);
+    // ticket (low word) and epoch (high word) come out of ONE 64-bit atomic: two separate relaxed accesses to two addresses are not
+    // ordered by the memory model, and a group that took an early ticket but read the epoch the last group had already advanced
+    // would publish and wait under the wrong epoch
+    const unsigned long long te = atomicAdd(&st[0], 1ull);
+    s_b = (unsigned)te;
+    s_epoch = (unsigned)(te >> 32) & 0x3FFFFFFFu;
   }
   __syncthreads();
   const unsigned b = s_b, epoch = s_epoch;
@@ -1276,10 +1280,8 @@ __global__ __launch_bounds__(256) void walk_scan_est_tail(EstimateOf est, uint32
     run += e[k];
   }
   if (b + 1 != gridDim.x) return;
-  if (tid == 0) {  // every group holds its ticket and has read the epoch: both may move on
-    __hip_atomic_store(&st[1], (unsigned long long)((epoch + 1u) & 0x3FFFFFFFu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&st[0], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
+  if (tid == 0)  // every group holds its ticket and, with it, the epoch: the word moves on to {epoch + 1, ticket 0} in one store
+    __hip_atomic_store(&st[0], (unsigned long long)((epoch + 1u) & 0x3FFFFFFFu) << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   unsigned long long total = excl + block_total;
   if (total > kScanSat) total = kScanSat;
   const int wrapped = total > 0x7fffffffull ? 1 : 0;

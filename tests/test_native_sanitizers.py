@@ -37,6 +37,19 @@ def test_delta_decoder_asan_ubsan_on_damaged_streams(tmp_path):
                    src=os.path.join(ROOT, "tests", "native", "delta_decoder_sanitize.cpp"))
 
 
+def test_multi_device_barrier_and_pool_tsan(tmp_path):
+    """csrc/multi_sync.hpp (the barrier in front of every collective, the one-worker-per-device pool) under TSan: votes,
+    a rank failing before a barrier, and a rank failing right after the final barrier while the others still wake from it
+    (a completed barrier must read `true` for everyone who took part)."""
+    _build_and_run(tmp_path, ["-fsanitize=thread"], {"TSAN_OPTIONS": "halt_on_error=1"},
+                   src=os.path.join(ROOT, "tests", "native", "multi_sync_tsan.cpp"))
+
+
+def test_multi_device_barrier_and_pool_asan(tmp_path):
+    _build_and_run(tmp_path, ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"],
+                   src=os.path.join(ROOT, "tests", "native", "multi_sync_tsan.cpp"))
+
+
 def test_oracle_asan_ubsan(tmp_path):
     """The oracle's own ASan build, driven through ctypes in a child process with libasan preloaded."""
     subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "asan"], check=True, stdout=subprocess.DEVNULL)

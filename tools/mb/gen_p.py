@@ -26,10 +26,11 @@ def current(npairs=8):
     return P + M + F2 + A + K + R + F
 
 
-def packed(npairs=8, order="phase", bias="v", adds="add", rcp="rcp", prio=None):
+def packed(npairs=8, order="phase", bias="v", adds="add", rcp="rcp", prio=None, minv=False):
     """Two pairs per packed op.  Couple c: SX = (xA, xB) = v[18+4c:19+4c], SY = (yA, yB) = v[20+4c:21+4c] (differences in
     place), Q = v[34+2c:35+2c], S = v[42+2c:43+2c]; accumulators v[8:9] (x of even | odd sources), v[10:11] (y)."""
     PX, PY, M, F2, A, K, R, FX, FY = [], [], [], [], [], [], [], [], []
+    R1, R2, R3 = [], [], []
     b = "v[14:15]" if bias == "v" else "s[20:21]"
     for c in range(npairs // 2):
         sx = 18 + 4 * c
@@ -49,11 +50,23 @@ def packed(npairs=8, order="phase", bias="v", adds="add", rcp="rcp", prio=None):
         elif adds == "pk":   # (not the arithmetic: no abs)
             A.append(f"v_pk_add_f32 v[{s}:{s+1}], v[{sx}:{sx+1}], v[{sy}:{sy+1}]")
         K.append(f"v_pk_fma_f32 v[{s}:{s+1}], v[{s}:{s+1}], v[{q}:{q+1}], {b}")
+        if minv:  # round 4, direct_stream_m: the denominators scaled by the couple's inverse masses (an SGPR pair) before the reciprocals
+            R.append(f"v_pk_mul_f32 v[{s}:{s+1}], v[{s}:{s+1}], s[22:23]")
         if rcp == "rcp":
             R.append(f"v_rcp_f32_e32 v{s}, v{s}")
             R.append(f"v_rcp_f32_e32 v{s+1}, v{s+1}")
+        elif rcp in ("one", "one_lowprio"):
+            # round 4: ONE reciprocal per couple — P = denA * denB, R = 1 / P, (rA, rB) = (denB, denA) * R.
+            # P lives in the couple's Q pair (the squares are dead once the denominators exist).
+            R1.append(f"v_mul_f32_e32 v{q}, v{s}, v{s+1}")
+            R2.append(f"v_rcp_f32_e32 v{q}, v{q}")
+            R3.append(f"v_pk_mul_f32 v[{s}:{s+1}], v[{s}:{s+1}], v[{q}:{q+1}] op_sel:[1,0] op_sel_hi:[0,0]")
         FX.append(f"v_pk_fma_f32 v[8:9], v[{sx}:{sx+1}], v[{s}:{s+1}], v[8:9]")
         FY.append(f"v_pk_fma_f32 v[10:11], v[{sy}:{sy+1}], v[{s}:{s+1}], v[10:11]")
+    if rcp == "one":
+        R = R + R1 + R2 + R3
+    elif rcp == "one_lowprio" and prio is not None:  # the plain products pair up like the adds do
+        R = R + [f"s_setprio {prio[0]}"] + R1 + [f"s_setprio {prio[1]}"] + R2 + R3
     if order == "phase" and prio is not None:  # the adds at another priority than the rest
         return PX + PY + M + F2 + [f"s_setprio {prio[0]}"] + A + [f"s_setprio {prio[1]}"] + K + R + FX + FY
     if order == "adds_first" and prio is not None:  # the NEXT block's adds cannot move up; the adds open the block
@@ -90,11 +103,16 @@ V["P4 packed, no rcp (model probe)"] = packed(rcp="none")
 V["Q1 packed, adds at LOW priority (1 elsewhere)"] = packed(bias="s", prio=(0, 1))
 V["Q2 packed, adds at HIGH priority (0 elsewhere)"] = packed(bias="s", prio=(1, 0))
 V["Q3 packed, adds at prio 0, rest at 3"] = packed(bias="s", prio=(0, 3))
+# round 4
+V["M1 = Q1 + inverse masses (direct_stream_m)"] = packed(bias="s", prio=(0, 1), minv=True)
+V["R1 = Q1, ONE rcp per couple"] = packed(bias="s", prio=(0, 1), rcp="one")
+V["R2 = R1, the products at LOW priority too"] = packed(bias="s", prio=(0, 1), rcp="one_lowprio")
+V["R0 = P1s, ONE rcp per couple (no priorities)"] = packed(bias="s", rcp="one")
 
 regs = list(range(6, 12)) + [14, 15] + list(range(18, 58))
-CLOB = ",".join(f'"v{r}"' for r in regs) + ',"s20","s21"'
+CLOB = ",".join(f'"v{r}"' for r in regs) + ',"s20","s21","s22","s23"'
 init = ["v_mov_b32 v6, %1", "v_mov_b32 v7, %1", "v_mov_b32 v8, 0", "v_mov_b32 v9, 0", "v_mov_b32 v10, 0", "v_mov_b32 v11, 0",
-        "v_mov_b32 v14, 0x12800000", "v_mov_b32 v15, 0x12800000", "s_mov_b32 s20, 0x12800000", "s_mov_b32 s21, 0x12800000", "v_mov_b32 v18, %0"]
+        "v_mov_b32 v14, 0x12800000", "v_mov_b32 v15, 0x12800000", "s_mov_b32 s20, 0x12800000", "s_mov_b32 s21, 0x12800000", "s_mov_b32 s22, 1.0", "s_mov_b32 s23, 1.0", "v_mov_b32 v18, %0"]
 for r in range(19, 34):
     init.append(f"v_add_f32 v{r}, {['1.0', '2.0', '4.0', '0.5'][r % 4]}, v{r-1}")
 for r in range(34, 58):
