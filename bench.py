@@ -42,12 +42,11 @@ FLOPS_EXECUTED_PER_PAIR = 13
 
 
 def _main_pass_kernel(uniform=True):
-    """Name of the direct step's dominant kernel as the library picks it (capi.hip choose_direct_config, direct_kernels.hip
-    launch_direct_fast): NBODY_DIRECT_ASM 3 (default) streams the far sources of equal masses / mass classes through SGPRs."""
-    mode = int(os.environ.get("NBODY_DIRECT_ASM", "3") or 3)
-    if mode >= 3:
-        return "nbody::direct_stream" if uniform else "nbody::direct_stream_m"
-    return "nbody::direct_fast<1,%s,true,%d>" % ("true" if uniform else "false", min(max(mode, 0), 2))
+    """Name of the direct step's dominant kernel (direct_kernels.hip launch_direct_fast): the far sources of equal masses / mass
+    classes stream through SGPRs (direct_stream); free per-body masses bring their inverse masses along (direct_stream_m)."""
+    return "nbody::direct_stream" if uniform else "nbody::direct_stream_m"
+
+
 PEAK_F32_TFLOPS = 157.3     # MI355X_MICROARCH.md: peak FP32 vector (= FP32 matrix) rate
 PEAK_F64_TFLOPS = 78.6      # FP64 vector: half the FP32 vector rate (256 CU x 2.4 GHz x 128 flop/clk/CU; AMD's MI355X figure)
 DT = 0.1                    # STEP_SIZE, main.rs:34

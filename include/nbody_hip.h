@@ -23,6 +23,20 @@
  *     over xGMI, RCCL) inside the library, so the host keeps its single `world.update` call (main.rs:120).
  *     A host that runs one process per GPU instead uses the *_dev / *_shard calls and its own collective.
  *   - There is no CPU fallback: without a gfx950 device nbody_create fails with NBODY_ERR_NO_DEVICE.
+ *
+ * Environment.  libnbody_hip.so reads these nine variables and no others (tests/test_capi_host.py checks the binary against
+ * this list); results are the same bits whatever they are set to — they choose between equivalent ways of getting them:
+ *   NBODY_TRACE=1             one line per tree build / walk / direct-step decision on stderr
+ *   NBODY_BUILD_THREADS=k     threads of the host-side tree builder (default: the host's cores, at most 16)
+ *   NBODY_TREE_BUILD_HOST=1   build every tree with the host builder instead of the device kernels
+ *   NBODY_DIRECT_GRAPH=0      direct steps of small problems as plain launches instead of a replayed hipGraph
+ *   NBODY_DIRECT_NEARFAR=0|1|2  near/far split of the direct step's sources: never | by size (default) | always
+ *   NBODY_STEP_AHEAD=0        f32 BVH steps phase by phase instead of enqueued whole ahead of the host
+ *   NBODY_WALK_SPLIT=0|1|3    big-leaf BVH walk: the fused walk only | one pass through LDS when it pays (default) | whenever possible
+ *   NBODY_MULTI_EXCHANGE=peer nbody_create_multi: peer copies instead of RCCL (what nbody_create_multi_ex takes as `exchange`)
+ *   NBODY_MULTI_CHUNKS=c      nbody_create_multi: chunks per direct step (default by size; nbody_create_multi_ex's `chunks`)
+ * The A/B variants and test hooks the measurements under profiles/ switch between (NBODY_DIRECT_ASM, NBODY_WALK_TILE_*, ...)
+ * exist only in the laboratory build, libnbody_hip_lab.so (csrc/env.h, `make lab`); this library ignores them.
  */
 #ifndef NBODY_HIP_H
 #define NBODY_HIP_H
@@ -343,8 +357,7 @@ int nbody_selftest_div_pair(int device, const float* nx, const float* ny, const 
 /* Restarts of that scan during the last device BVH build of this context (diagnostic; 0 after a host build). */
 int nbody_bvh_build_restarts(const nbody_ctx* ctx);
 /* 1 if the last tree build of this context ran on the device, 0 if the host builder did it (the device builders
- * decline what they cannot express, e.g. NaN positions or very deep trees; NBODY_BVH_BUILD_HOST=1 /
- * NBODY_QUAD_BUILD_HOST=1 force the host). */
+ * decline what they cannot express, e.g. NaN positions or very deep trees; NBODY_TREE_BUILD_HOST=1 forces the host). */
 int nbody_last_build_on_device(const nbody_ctx* ctx);
 
 /* ---- kernel timing (bench.py's roofline leg) -------------------------------------------------------- */

@@ -135,15 +135,18 @@ template <> bool has_state<float>(const nbody_ctx* c) { return c->has_f32; }
 template <> bool has_state<double>(const nbody_ctx* c) { return c->has_f64; }
 
 // -------------------------------------------------------------------------------------------- direct config
-int env_int(const char* name, int dflt) {
-  const char* v = getenv(name);
-  return (v && *v) ? atoi(v) : dflt;
+
+// NBODY_WALK_SPLIT (big-leaf BVH walk): 0 the fused walk only, 1 one pass through LDS when it pays (default), 3 one pass whenever
+// possible; the laboratory build also knows 4 / 2, the three-pass design of round 1 (when it pays / whenever possible).
+int walk_split_mode() {
+  const int mode = env_int("NBODY_WALK_SPLIT", 1);
+  return (!kLabBuild && (mode == 2 || mode == 4)) ? 1 : mode;
 }
 
 // How the direct kernel covers (n_tgt x n_src): enough waves to fill 256 CUs x 4 SIMDs x 8 waves.
 DirectConfig choose_direct_config(int64_t n_src, int64_t n_tgt, bool uniform = true) {
   DirectConfig c;
-  c.use_asm = env_int("NBODY_DIRECT_ASM", 3);
+  c.use_asm = lab_int("NBODY_DIRECT_ASM", 3);
   // near/far split: 0.05 ms (65 536 bodies) to 0.16 ms (1 M) of preparation per step against 10 % of the pair work: it pays
   // from 65 536 x 65 536 pairs on (profiles/r03_nearfar_hash_grid.txt; the sort-based split of rounds 1-2 broke even at
   // twice that).  NBODY_DIRECT_NEARFAR: 0 never, 1 by size (default), 2 always.
@@ -152,7 +155,7 @@ DirectConfig choose_direct_config(int64_t n_src, int64_t n_tgt, bool uniform = t
   // measured at N = 1M (profiles/r01_direct_mass_variants.txt): 1 target/thread with the hand-ordered block wins for
   // equal masses (44.0 %) and for per-body masses (39.8 % vs 36.1 % for 2 targets/thread)
   (void)uniform;
-  c.tpt = env_int("NBODY_DIRECT_TPT", 1);
+  c.tpt = lab_int("NBODY_DIRECT_TPT", 1);
   if (c.tpt != 1 && c.tpt != 2) c.tpt = 1;
   // 256 CUs x 32 wave slots hold 8192 waves; several rounds of waves balance the tail, so the sources are split
   // over blockIdx.y until there are ~16 rounds (measured, profiles/r01_direct_gsplit_sweep.txt: 131072 targets
@@ -167,7 +170,7 @@ DirectConfig choose_direct_config(int64_t n_src, int64_t n_tgt, bool uniform = t
   // from HBM by waves that have drifted apart (N = 1 M: 2 -> 4 splits, FETCH_SIZE 524 -> 82 MB per launch, the same 173.1 ms)
   const int64_t g_l2 = (n_src + 262143) / 262144;
   if (g_l2 <= 16 && g < g_l2) g = g_l2;
-  g = env_int("NBODY_DIRECT_GSPLIT", (int)g);
+  g = lab_int("NBODY_DIRECT_GSPLIT", (int)g);
   if (g < 1) g = 1;
   if (g > 64) g = 64;
   while (g > 1 && n_src / g < 2048) g /= 2;  // a split should still hold a couple of tiles
@@ -214,7 +217,7 @@ int ensure_mass_classes(nbody_ctx* c) {
   mc.epoch = s.row_epoch;
   mc.usable = false;
   const int64_t n = s.n;
-  if (env_int("NBODY_DIRECT_NO_CLASSES", 0) != 0 || s.uniform_mass > 0.f || s.sparse_base > 0.f || n < 32768) return NBODY_OK;
+  if (lab_int("NBODY_DIRECT_NO_CLASSES", 0) != 0 || s.uniform_mass > 0.f || s.sparse_base > 0.f || n < 32768) return NBODY_OK;
   if (s.h_weight_stale) {
     s.h_weight.resize((size_t)n);
     HIPCHK(c, hipMemcpyAsync(s.h_weight.data(), s.set[s.cur].weight, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
@@ -310,7 +313,7 @@ int direct_plan(nbody_ctx* c, int64_t n_src, const void* mass_all, float uniform
   if (arith != NBODY_ARITH_EXACT && !(clamp >= 1.9073486328125e-06f)) arith = NBODY_ARITH_EXACT;
   DirectPlan p;
   p.arith = arith;
-  p.uni = uniform_mass > 0.f && env_int("NBODY_DIRECT_NO_UNIFORM", 0) == 0;
+  p.uni = uniform_mass > 0.f && lab_int("NBODY_DIRECT_NO_UNIFORM", 0) == 0;
   {
     const DirectConfig c0 = choose_direct_config(n_src, n_tgt_total, p.uni);
     p.nearfar = c0.nearfar;
@@ -318,10 +321,10 @@ int direct_plan(nbody_ctx* c, int64_t n_src, const void* mass_all, float uniform
   }
   // uniform_mass < 0: every mass is -uniform_mass except a sparse set; the split hands those to direct_finish, so the
   // main pass runs at the equal-mass rate.  Without the split (small problems) the per-body-mass kernel is used.
-  if (uniform_mass < 0.f && p.nearfar && env_int("NBODY_DIRECT_NO_UNIFORM", 0) == 0 && env_int("NBODY_DIRECT_NO_SPARSE", 0) == 0)
+  if (uniform_mass < 0.f && p.nearfar && lab_int("NBODY_DIRECT_NO_UNIFORM", 0) == 0 && lab_int("NBODY_DIRECT_NO_SPARSE", 0) == 0)
     p.sparse_base = -uniform_mass;
   if (!p.uni && p.sparse_base == 0.f && p.nearfar) p.classes = classes_for(c, n_src, mass_all);
-  p.stream_m = !p.uni && p.sparse_base == 0.f && !p.classes && p.couples && env_int("NBODY_DIRECT_ASM", 3) >= 3;
+  p.stream_m = !p.uni && p.sparse_base == 0.f && !p.classes && p.couples && lab_int("NBODY_DIRECT_ASM", 3) >= 3;
   p.use_hazard = arith == NBODY_ARITH_AUTO;
   p.partial_bytes = direct_partial_bytes(n_src, n_tgt_max);
   *out = p;
@@ -624,7 +627,7 @@ int bvh_build_device64(nbody_ctx* c, State<double>& s) {
   // the levels a balanced tree has, plus a margin (the mean split is not the median: real trees run a few levels deeper);
   // a tree that is deeper still goes on four levels at a time
   int lv_end = std::min(bvh64_first_levels(n, leaf) + 4, kB64Levels);
-  lv_end = std::max(1, std::min(env_int("NBODY_BVH_BLIND_LEVELS", lv_end), kB64Levels));  // tests force the long way
+  lv_end = std::max(1, std::min(lab_int("NBODY_BVH_BLIND_LEVELS", lv_end), kB64Levels));  // tests force the long way
   int hostf[kB64FlagWords + kB64Levels + 2];
   auto finish_and_ask = [&]() -> int {
     HIPCHK(c, bvh64_finish(c->stream, in.weight, n, lv_end, s.bb_scratch, L, s.order_dev, s.geom0, s.geom1, s.link, s.node_depth, s.node_mass,
@@ -674,7 +677,7 @@ int bvh_build_device64(nbody_ctx* c, State<double>& s) {
 
 template <class T> int bvh_build_device(nbody_ctx* c, State<T>& s) {
   if constexpr (!std::is_same<T, float>::value) {
-    return env_int("NBODY_BVH64_BUILD_HOST", 0) != 0 ? 1 : bvh_build_device64(c, s);
+    return env_int("NBODY_TREE_BUILD_HOST", 0) != 0 ? 1 : bvh_build_device64(c, s);
   } else {
     const int n = (int)s.n;
     const int leaf = c->params.leaf_size;
@@ -699,7 +702,7 @@ template <class T> int bvh_build_device(nbody_ctx* c, State<T>& s) {
     // until none is left, then the tail once more for the subtrees that were not there the first time.
     const int first_levels = bvh_build_first_levels(n);
     int lv_end = first_levels > 0 ? first_levels + 2 : 0;
-    if (lv_end > 0) lv_end = std::max(1, env_int("NBODY_BVH_BLIND_LEVELS", lv_end));  // tests force the lopsided path
+    if (lv_end > 0) lv_end = std::max(1, lab_int("NBODY_BVH_BLIND_LEVELS", lv_end));  // tests force the lopsided path
     if (lv_end > kBvhKeyDepth + 1) lv_end = kBvhKeyDepth + 1;
     int hostf[kBvhFlagWords + kBvhLevels];
     auto tail = [&](int sub_start) -> int {
@@ -960,11 +963,11 @@ template <class T> int tree_build_phase(nbody_ctx* c, State<T>& s, int kind) {
   s.tree_host_stale = false;
   c->last_build_device = true;
   c->bvh_stops = 0;
-  if (kind == NBODY_TREE_QUAD && n > 0 && env_int("NBODY_QUAD_BUILD_HOST", 0) == 0) {
+  if (kind == NBODY_TREE_QUAD && n > 0 && env_int("NBODY_TREE_BUILD_HOST", 0) == 0) {
     int rc = quad_build_device<T>(c, s);
     if (rc != 1) return rc;  // 1 = the device build declined (too deep for its key / sizes): host builder below
   }
-  if (kind == NBODY_TREE_BVH && n > 0 && c->params.leaf_size >= 1 && env_int("NBODY_BVH_BUILD_HOST", 0) == 0) {
+  if (kind == NBODY_TREE_BVH && n > 0 && c->params.leaf_size >= 1 && env_int("NBODY_TREE_BUILD_HOST", 0) == 0) {
     int rc = bvh_build_device<T>(c, s);
     if (rc != 1) return rc;
   }
@@ -1067,10 +1070,11 @@ int tree_walk_phase(nbody_ctx* c, State<T>& s, int kind, const void* tgt_pos, in
   {
     // Big leaves: a leaf's terms are evaluated lane = particle (walk_split.hip): in one pass with the terms handed over
     // through LDS (walk_tile), or in three passes through a term array.  NBODY_WALK_SPLIT: 0 never (fused walk), 1 one pass
-    // when it pays (default), 3 one pass whenever possible, 4 / 2 three passes when it pays / whenever possible.
-    const int mode = env_int("NBODY_WALK_SPLIT", 1);
+    // when it pays (default), 3 one pass whenever possible; laboratory build only: 4 / 2 three passes when it pays / whenever
+    // possible (the round-1 design the one-pass walk replaced; the product treats them as 1).
+    const int mode = walk_split_mode();
     const bool tile_mode = mode == 3 || (mode == 1 && w.n_tgt >= 4096);
-    const bool eligible = w.big_leaves && !w.stats && w.n_tgt > 0 && w.n_nodes > 0 && env_int("NBODY_WALK_PER_THREAD", 0) == 0;
+    const bool eligible = w.big_leaves && !w.stats && w.n_tgt > 0 && w.n_nodes > 0 && lab_int("NBODY_WALK_PER_THREAD", 0) == 0;
     if (eligible && tile_mode && (mode == 3 || s.ws_backoff == 0)) {  // one pass, terms through LDS (walk_tile)
       const WalkSplitLayout L = walk_split_layout(w.n_tgt);
       if (s.ws_scratch_bytes < L.total) {
@@ -1090,10 +1094,10 @@ int tree_walk_phase(nbody_ctx* c, State<T>& s, int kind, const void* tgt_pos, in
       // the targets' particle ids (the snapshot's rows under AS_WRITTEN, the permuted rows otherwise)
       const uint32_t* tgt_ids = !self ? nullptr
                                 : ((c->params.order == NBODY_ORDER_AS_WRITTEN) ? s.set[1 - s.cur].ids : s.set[s.cur].ids) + (slice_count >= 0 ? slice_begin : 0);
-      const bool hist = self && s.wt_hist_n == w.n_tgt && s.wt_hist_begin == slice_begin && env_int("NBODY_WALK_TILE_COUNT", 0) == 0;
+      const bool hist = self && s.wt_hist_n == w.n_tgt && s.wt_hist_begin == slice_begin && lab_int("NBODY_WALK_TILE_COUNT", 0) == 0;
       int shift = 0;
       while (hist && (s.wt_total >> shift) >= (1ull << 31)) ++shift;
-      if (hist && env_int("NBODY_WALK_TILE_POISON", 0) != 0)  // test hook: a history whose scan wraps must be noticed
+      if (hist && lab_int("NBODY_WALK_TILE_POISON", 0) != 0)  // test hook: a history whose scan wraps must be noticed
         HIPCHK(c, hipMemsetAsync(s.wt_hist, 0xFF, (size_t)s.n * 4, c->stream));
       int info[8] = {0, 0, 0, 0, 0, 0, 0, 0};
       unsigned long long total = 0;
@@ -1120,6 +1124,7 @@ int tree_walk_phase(nbody_ctx* c, State<T>& s, int kind, const void* tgt_pos, in
       // the direct sum: every lane wants every leaf and the fused walk's lane = target is the cheaper arrangement; look
       // again in 64 walks
       if (mode != 3 && (double)total > (double)w.n_tgt * (double)s.n / 16.0) s.ws_backoff = 64;
+#ifdef NBODY_LAB
     } else if (std::is_same<T, float>::value && eligible && (mode == 2 || (mode == 4 && w.n_tgt >= 4096 && s.ws_backoff == 0))) {
       s.wt_hist_n = -1;
       const int64_t hard_cap = ((int64_t)1 << 31) - 65536;  // terms (16 GB; the offsets are 32 bits wide); past that the fused walk
@@ -1162,13 +1167,14 @@ int tree_walk_phase(nbody_ctx* c, State<T>& s, int kind, const void* tgt_pos, in
           s.ws_capacity = want;
         }
       }
+#endif
     } else if (s.ws_backoff > 0 && eligible) {
       --s.ws_backoff;
     }
   }
   if (!done) {
     TimerScope ts(c->timer, c->stream);
-    HIPCHK(c, launch_tree_walk<T>(c->stream, w, env_int("NBODY_WALK_PER_THREAD", 0) == 0));
+    HIPCHK(c, launch_tree_walk<T>(c->stream, w, lab_int("NBODY_WALK_PER_THREAD", 0) == 0));
   }
   if (w.stats) {
     HIPCHK(c, hipMemcpyAsync(c->last_stats, c->stats_dev, sizeof(c->last_stats), hipMemcpyDeviceToHost, c->stream));
@@ -1208,11 +1214,11 @@ template <class T> int bvh_step_ahead(nbody_ctx* c, State<T>& s, T delta, PhaseE
   } else {
     const int n = (int)s.n;
     const int leaf = c->params.leaf_size;
-    const int mode = env_int("NBODY_WALK_SPLIT", 1);
+    const int mode = walk_split_mode();
     if (n < 4096 || leaf < 16 || mode != 1 || c->want_stats || s.ws_backoff != 0) return 1;
     if (!s.wt_hist || s.wt_hist_n != n || s.wt_hist_begin != 0) return 1;  // no walk of these targets to estimate from yet
-    if (env_int("NBODY_STEP_AHEAD", 1) == 0 || env_int("NBODY_BVH_BUILD_HOST", 0) != 0 || env_int("NBODY_WALK_PER_THREAD", 0) != 0 ||
-        env_int("NBODY_WALK_TILE_COUNT", 0) != 0)
+    if (env_int("NBODY_STEP_AHEAD", 1) == 0 || env_int("NBODY_TREE_BUILD_HOST", 0) != 0 || lab_int("NBODY_WALK_PER_THREAD", 0) != 0 ||
+        lab_int("NBODY_WALK_TILE_COUNT", 0) != 0)
       return 1;
     const BvhBuildLayout L = bvh_build_layout(n, leaf);
     const WalkSplitLayout WL = walk_split_layout(n);
@@ -1228,8 +1234,8 @@ template <class T> int bvh_step_ahead(nbody_ctx* c, State<T>& s, T delta, PhaseE
     }
     // Phase timing: by the step's own kernels (the 100 MHz wall clock written at the three boundaries: no event records, each of
     // which leaves ~6 us of idle stream) when the walk's preparation is the one fused kernel; by events otherwise.
-    const bool fused_scan = n <= std::min<int64_t>(kWalkFusedScanMaxTargets, env_int("NBODY_WALK_FUSED_SCAN_MAX", (int)kWalkFusedScanMaxTargets));
-    const bool stamps = fused_scan && env_int("NBODY_PHASE_STAMPS", 1) != 0;
+    const bool fused_scan = n <= std::min<int64_t>(kWalkFusedScanMaxTargets, lab_int("NBODY_WALK_FUSED_SCAN_MAX", (int)kWalkFusedScanMaxTargets));
+    const bool stamps = fused_scan && lab_int("NBODY_PHASE_STAMPS", 1) != 0;
     PhaseEvents ph;
     int rc = NBODY_OK;
     unsigned long long* stamp = nullptr;  // this step's slot
@@ -1259,8 +1265,8 @@ template <class T> int bvh_step_ahead(nbody_ctx* c, State<T>& s, T delta, PhaseE
     // 1.1 ms step): once the count has stood for eight builds it is dropped — the verdict still checks that no long node is
     // left (bigcount[lv_end] == 0), and a tree that grows a level then costs ONE repeated step and brings the spare back.
     if (lv_end > 0 && s.bvh_levels_hint > 0)
-      lv_end = s.bvh_levels_hint + ((s.bvh_levels_stable >= 8 && env_int("NBODY_BVH_SPARE_LEVEL", 0) == 0) ? 0 : 1);
-    if (lv_end > 0) lv_end = std::max(1, env_int("NBODY_BVH_BLIND_LEVELS", lv_end));  // tests: too few levels, the verdict fails
+      lv_end = s.bvh_levels_hint + ((s.bvh_levels_stable >= 8 && lab_int("NBODY_BVH_SPARE_LEVEL", 0) == 0) ? 0 : 1);
+    if (lv_end > 0) lv_end = std::max(1, lab_int("NBODY_BVH_BLIND_LEVELS", lv_end));  // tests: too few levels, the verdict fails
     if (lv_end > kBvhKeyDepth + 1) lv_end = kBvhKeyDepth + 1;
     const bool flags_clean = s.bb_flags_clean;
     s.bb_flags_clean = false;
@@ -1301,7 +1307,7 @@ template <class T> int bvh_step_ahead(nbody_ctx* c, State<T>& s, T delta, PhaseE
     const uint32_t* tgt_ids = as_written ? in.ids : out.ids;
     int shift = 0;
     while ((s.wt_total >> shift) >= (1ull << 31)) ++shift;
-    if (env_int("NBODY_WALK_TILE_POISON", 0) != 0)  // test hook: a history whose scan wraps must be noticed
+    if (lab_int("NBODY_WALK_TILE_POISON", 0) != 0)  // test hook: a history whose scan wraps must be noticed
       HIPCHK(c, hipMemsetAsync(s.wt_hist, 0xFF, (size_t)s.n * 4, c->stream));
     int64_t waves = 0;
     // The estimate check's last work-group concludes on the build (the verdict the walk kernel reads), packs verdict, build

@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "common.h"
+#include "env.h"
 #include "tree_build.hpp"
 
 namespace nbody {
@@ -113,9 +114,12 @@ struct DirectGraph {
 };
 inline std::string direct_env_signature() {
   std::string sig;
-  for (const char* k : {"NBODY_DIRECT_ASM", "NBODY_DIRECT_NEARFAR", "NBODY_DIRECT_TPT", "NBODY_DIRECT_GSPLIT", "NBODY_DIRECT_NO_UNIFORM",
-                        "NBODY_DIRECT_NO_CLASSES", "NBODY_DIRECT_NO_SPARSE"}) {
-    const char* v = getenv(k);
+  const char* nf = getenv("NBODY_DIRECT_NEARFAR");
+  sig += nf ? nf : "-";
+  sig += ';';
+  for (const char* k : {"NBODY_DIRECT_ASM", "NBODY_DIRECT_TPT", "NBODY_DIRECT_GSPLIT", "NBODY_DIRECT_NO_UNIFORM", "NBODY_DIRECT_NO_CLASSES",
+                        "NBODY_DIRECT_NO_SPARSE"}) {  // (laboratory build only)
+    const char* v = lab_str(k);
     sig += v ? v : "-";
     sig += ';';
   }

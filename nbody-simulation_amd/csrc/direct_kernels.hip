@@ -59,6 +59,9 @@ __device__ __forceinline__ void fast_pair(float xi, float yi, float xj, float yj
   ay = __builtin_fmaf(dy, s, ay);
 }
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+#ifdef NBODY_LAB  // the round-2 block (NBODY_DIRECT_ASM=1)
 // Eight FAST pairs for one target as one hand-ordered instruction block: the same operations as fast_pair,
 // issued in phases (8 x v_pk_add | the 32-bit ops | 8 x v_rcp | 8 x v_pk_fma).  With per-body masses m0..m7 are the
 // INVERSE masses and scale the denominator before the reciprocal (s = 1/(den/m) instead of m * (1/den)).  p0..p7 come in as source
@@ -68,8 +71,6 @@ __device__ __forceinline__ void fast_pair(float xi, float yi, float xj, float yj
 // trans forwarding hazard of gfx940+ needs 1).  Worth 2 % over hipcc's schedule of the same instructions.
 // Operands are native 2-vectors (HIP's float2 is a struct: as an asm operand it is coerced through an i64 and costs
 // shift/or/move instructions around every block).
-typedef float v2f __attribute__((ext_vector_type(2)));
-typedef float v4f __attribute__((ext_vector_type(4)));
 template <bool UNIFORM, bool NOCLAMP>
 __device__ __forceinline__ void fast_block8(v2f t, float clamp, v2f& p0, v2f& p1, v2f& p2, v2f& p3, v2f& p4, v2f& p5,
                                             v2f& p6, v2f& p7, float m0, float m1, float m2, float m3, float m4,
@@ -149,6 +150,7 @@ __device__ __forceinline__ void fast_block8(v2f t, float clamp, v2f& p0, v2f& p1
         : "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55");
   }
 }
+#endif  // NBODY_LAB
 
 // Eight FAST pairs for one target with EVERY multiply-add packed over two pairs (round 3; USE_ASM = 2, the default).
 // Measured (profiles/r01_valu_microbench_wallclock.txt, r03_pair_body_packed.txt): a wave issues one VALU instruction per
@@ -368,6 +370,7 @@ __global__ __launch_bounds__(256) void direct_fast(const DirectArgs a) {
       }
       ax[0] = __builtin_fmaf(bx, tm, ax[0]);
       ay[0] = __builtin_fmaf(by, tm, ay[0]);
+#ifdef NBODY_LAB
     } else if constexpr (USE_ASM == 1) {
       static_assert(TPT == 1, "the hand-ordered block handles one target per thread");
       // the wave's share of the tile, 8 sources per block, summed on its own (two-level summation); everything the
@@ -394,6 +397,7 @@ __global__ __launch_bounds__(256) void direct_fast(const DirectArgs a) {
       }
       ax[0] = __builtin_fmaf(bx, tm, ax[0]);
       ay[0] = __builtin_fmaf(by, tm, ay[0]);
+#endif
     } else {
       float bx[TPT], by[TPT];
 #pragma unroll
@@ -757,21 +761,28 @@ hipError_t launch_direct_fast(hipStream_t s, const DirectArgs& a, const DirectCo
     return hipGetLastError();
   }
 #define NB_GO(T, U, N, A) launch_fast_k<T, U, N, A>(s, a, c.gsplit)
-  if (tpt == 1) {
-    if (use_asm >= 2) {
-      if (uni) { if (noclamp) NB_GO(1, true, true, 2); else NB_GO(1, true, false, 2); }
-      else     { if (noclamp) NB_GO(1, false, true, 2); else NB_GO(1, false, false, 2); }
-    } else if (use_asm == 1) {
-      if (uni) { if (noclamp) NB_GO(1, true, true, 1); else NB_GO(1, true, false, 1); }
-      else     { if (noclamp) NB_GO(1, false, true, 1); else NB_GO(1, false, false, 1); }
-    } else {
-      if (uni) { if (noclamp) NB_GO(1, true, true, 0); else NB_GO(1, true, false, 0); }
-      else     { if (noclamp) NB_GO(1, false, true, 0); else NB_GO(1, false, false, 0); }
-    }
-  } else {
+#ifdef NBODY_LAB  // the rounds 1-2 main passes (NBODY_DIRECT_ASM 0 / 1, NBODY_DIRECT_TPT 2): A/B runs only
+  if (tpt == 2) {
     if (uni) { if (noclamp) NB_GO(2, true, true, 0); else NB_GO(2, true, false, 0); }
     else     { if (noclamp) NB_GO(2, false, true, 0); else NB_GO(2, false, false, 0); }
+    return hipGetLastError();
   }
+  if (use_asm == 1) {
+    if (uni) { if (noclamp) NB_GO(1, true, true, 1); else NB_GO(1, true, false, 1); }
+    else     { if (noclamp) NB_GO(1, false, true, 1); else NB_GO(1, false, false, 1); }
+    return hipGetLastError();
+  }
+  if (use_asm == 0) {
+    if (uni) { if (noclamp) NB_GO(1, true, true, 0); else NB_GO(1, true, false, 0); }
+    else     { if (noclamp) NB_GO(1, false, true, 0); else NB_GO(1, false, false, 0); }
+    return hipGetLastError();
+  }
+#else
+  if (tpt != 1 || use_asm < 2) return hipErrorInvalidValue;  // (choose_direct_config cannot ask for them in this build)
+#endif
+  // packed couples through LDS: the clamped single pass (small problems, fallbacks) and whatever the streamed kernels do not take
+  if (uni) { if (noclamp) NB_GO(1, true, true, 2); else NB_GO(1, true, false, 2); }
+  else     { if (noclamp) NB_GO(1, false, true, 2); else NB_GO(1, false, false, 2); }
 #undef NB_GO
   return hipGetLastError();
 }

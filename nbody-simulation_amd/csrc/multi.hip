@@ -49,10 +49,6 @@ namespace {
 
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
-int env_int(const char* name, int dflt) {
-  const char* v = getenv(name);
-  return (v && *v) ? atoi(v) : dflt;
-}
 
 struct Rccl {
   void* handle = nullptr;
@@ -516,7 +512,7 @@ int multi_update_tree(nbody_ctx* front, bool f64, int kind, double delta, int n_
   nbody_ctx* p = nullptr;
   int rc = multi_primary(front, &p);  // whole rows on every device before the trees are built
   if (rc) return rc;
-  if (M.G == 1 && env_int("NBODY_MULTI_FORCE_EXCHANGE", 0) == 0) {
+  if (M.G == 1 && lab_int("NBODY_MULTI_FORCE_EXCHANGE", 0) == 0) {
     // one device: nothing to shard or exchange — the single-device step driver, steps ahead of the host and all (the
     // tests set NBODY_MULTI_FORCE_EXCHANGE=1 to push a lone rank through the sliced step and its one-rank all-gather)
     nbody_counting c1{};

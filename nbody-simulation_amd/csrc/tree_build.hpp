@@ -23,6 +23,7 @@
 #include <thread>
 #include <utility>
 #include <vector>
+#include "env.h"
 
 namespace nbody {
 
@@ -80,11 +81,11 @@ template <class T> struct SubTree {
 
 // subtrees at least kParallelMinLen big get their own thread, down to depth kParallelMaxDepth
 inline int64_t par_min_len() {
-  static const int64_t v = [] { const char* e = std::getenv("NBODY_BUILD_PAR_MINLEN"); return e ? std::atoll(e) : 8192LL; }();  // tuned on the GPU box, N = 151k
+  static const int64_t v = lab_int("NBODY_BUILD_PAR_MINLEN", 8192);  // tuned on the GPU box, N = 151k
   return v;
 }
 inline int par_max_depth() {
-  static const int v = [] { const char* e = std::getenv("NBODY_BUILD_PAR_DEPTH"); return e ? std::atoi(e) : 4; }();
+  static const int v = lab_int("NBODY_BUILD_PAR_DEPTH", 4);
   return v;
 }
 #define kParallelMinLen par_min_len()

@@ -13,6 +13,7 @@
 #include <stdlib.h>
 
 #include "div_pair.h"
+#include "env.h"
 #include "tree_kernels.h"
 
 namespace nbody {
@@ -86,6 +87,7 @@ __device__ __forceinline__ void walk_pair(T px, T py, T qx, T qy, T force, T cla
   else pair_as_written<T>(px, py, qx, qy, force, clamp, ax, ay);
 }
 
+#ifdef NBODY_LAB  // the per-thread walk (NBODY_WALK_PER_THREAD): the baseline the wave-uniform walks are measured against
 // One thread per target.  tgt_index (optional) maps thread t to the target's row: targets are visited in tree
 // order so the lanes of a wave share most of their path, and results are scattered back to acc[row].
 template <class T>
@@ -138,6 +140,7 @@ __global__ __launch_bounds__(256) void tree_walk(const WalkArgs<T> a) {
     atomicAdd(&a.stats[2], leaf_pairs);
   }
 }
+#endif  // NBODY_LAB
 
 // Wave-uniform walk: the 64 targets of a wave traverse the tree TOGETHER, in pre-order, with one node index held in
 // an SGPR; each lane carries `resume`, the pre-order index at which it takes part again (a lane that accepted a node
@@ -529,12 +532,17 @@ NB_INST(double)
 template <class T> hipError_t launch_tree_walk(hipStream_t s, const WalkArgs<T>& a, bool wave_uniform) {
   if (a.n_tgt <= 0) return hipSuccess;
   const dim3 grid((unsigned)((a.n_tgt + 255) / 256));
+#ifdef NBODY_LAB
   if (!wave_uniform) {
     hipLaunchKernelGGL((tree_walk<T>), grid, dim3(256), 0, s, a);
     return hipGetLastError();
   }
-  // small leaves (quad tree), as-written arithmetic: the pairs of a leaf step dealt to the lanes (tree_walk_small)
-  const int compact = getenv("NBODY_WALK_COMPACT") ? atoi(getenv("NBODY_WALK_COMPACT")) : 1;
+#else
+  (void)wave_uniform;
+#endif
+  // small leaves (quad tree), as-written arithmetic: the pairs of a leaf step dealt to the lanes (tree_walk_small).
+  // Laboratory: NBODY_WALK_COMPACT 0 off / 2, 3 other thresholds for dealing a leaf step's pairs to the lanes
+  const int compact = lab_int("NBODY_WALK_COMPACT", 1);
   if (!a.big_leaves && !a.fast && !a.stats && a.n_nodes > 0 && compact != 0) {
     hipLaunchKernelGGL((tree_walk_small<T>), grid, dim3(256), 0, s, a, compact);
     return hipGetLastError();
@@ -542,15 +550,19 @@ template <class T> hipError_t launch_tree_walk(hipStream_t s, const WalkArgs<T>&
   // leaf batch / successor prefetch, measured in profiles/r01_walk_kernels_ab.txt: big leaves (BVH, 64) want 8
   // particles per fetch, small ones (quad, <= 8) 4; prefetching node i+1 never pays (the walk is bound by the
   // IEEE divides of the as-written pair function, not by scalar-load latency)
-  const int env_lb = getenv("NBODY_WALK_LB") ? atoi(getenv("NBODY_WALK_LB")) : 0;
-  const int env_pf = getenv("NBODY_WALK_PREFETCH") ? atoi(getenv("NBODY_WALK_PREFETCH")) : -1;
-  const int lb = env_lb ? env_lb : (a.big_leaves ? 8 : 4);
-  const bool pf = env_pf >= 0 ? env_pf != 0 : false;
 #define NB_W(L, P) do { if (a.fast) hipLaunchKernelGGL((tree_walk_wave<T, L, P, true>), grid, dim3(256), 0, s, a); \
                         else hipLaunchKernelGGL((tree_walk_wave<T, L, P, false>), grid, dim3(256), 0, s, a); } while (0)
+#ifdef NBODY_LAB
+  const int env_lb = lab_int("NBODY_WALK_LB", 0);
+  const int env_pf = lab_int("NBODY_WALK_PREFETCH", -1);
+  const int lb = env_lb ? env_lb : (a.big_leaves ? 8 : 4);
+  const bool pf = env_pf >= 0 ? env_pf != 0 : false;
   if (lb >= 8) { if (pf) NB_W(8, true); else NB_W(8, false); }
   else if (lb >= 4) { if (pf) NB_W(4, true); else NB_W(4, false); }
   else { if (pf) NB_W(2, true); else NB_W(2, false); }
+#else
+  if (a.big_leaves) NB_W(8, false); else NB_W(4, false);
+#endif
 #undef NB_W
   return hipGetLastError();
 }

@@ -25,6 +25,7 @@
 
 #include "bvh_build.h"
 #include "div_pair.h"
+#include "env.h"
 #include "walk_split.h"
 
 namespace nbody {
@@ -215,6 +216,7 @@ __global__ __launch_bounds__(256) void walk_count(const WalkArgs<T> a, uint32_t*
   if (live) cnt[t] = n_terms;
 }
 
+#ifdef NBODY_LAB  // ---- the three-pass walk of round 1 (count / emit terms / sum): kept for A/B runs, laboratory build only
 // The traversal both passes share.  F: what to do with an accepted node / a leaf.
 template <bool EMIT, int kTPW, bool FAST>
 __global__ __launch_bounds__(256) void walk_pass(const WalkArgs<float> a, uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off,
@@ -343,6 +345,7 @@ __global__ void walk_total(const uint32_t* __restrict__ cnt, const uint32_t* __r
   while (budget < want && budget < (1u << 30)) budget <<= 1;
   info[3] = (int)budget;
 }
+#endif  // NBODY_LAB (walk_pass, walk_total)
 __global__ __launch_bounds__(256) void walk_check_wrap(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off, int64_t n,
                                                        int* __restrict__ info) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -352,6 +355,7 @@ __global__ __launch_bounds__(256) void walk_check_wrap(const uint32_t* __restric
   }
 }
 
+#ifdef NBODY_LAB
 template <int K> __device__ __forceinline__ void add_row_lane(float& s, float v) {
   asm volatile("v_add_f32_dpp %0, %1, %0 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(s) : "v"(v), "n"(K));
 }
@@ -396,6 +400,8 @@ __global__ __launch_bounds__(256) void walk_sum(const WalkArgs<float> a, const u
   }
 }
 
+
+#endif  // NBODY_LAB (walk_sum)
 
 // ---- the walk in ONE pass, terms through LDS (walk_tile) --------------------------------------------------------------
 // Same idea as the three passes above - a leaf's terms are evaluated lane = particle, so a leaf step costs what its
@@ -1289,19 +1295,12 @@ __global__ __launch_bounds__(256) void walk_scan_est_tail(EstimateOf est, uint32
 }
 
 inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
-inline uint32_t tile_budget_targets() {
-  const char* e = getenv("NBODY_WALK_TILE_BUDGET_TARGETS");
-  const int v = e ? atoi(e) : 0;
+inline uint32_t tile_budget_targets() {  // (laboratory: a wave's budget as this many average targets)
+  const int v = lab_int("NBODY_WALK_TILE_BUDGET_TARGETS", 0);
   return (uint32_t)(v < 1 ? 0 : (v > 4096 ? 4096 : v));
 }
-inline int tile_targets() {
-  const char* e = getenv("NBODY_WALK_TILE_TARGETS");
-  const int v = e ? atoi(e) : 8;  // 8 rows keep the tile at 4 KB per wave: eight waves per SIMD
-  return (v == 16 || v == 4) ? v : 8;
-}
-inline int tile_targets_f64() {  // rows are twice as wide: 4 rows for eight waves per SIMD, 8 for four
-  const char* e = getenv("NBODY_WALK_TILE_TARGETS");
-  const int v = e ? atoi(e) : 8;
+inline int tile_targets() {  // rows of the LDS tile: 8 keep it at 4 KB per wave, eight waves per SIMD (laboratory: 4 / 16)
+  const int v = lab_int("NBODY_WALK_TILE_TARGETS", 8);
   return (v == 16 || v == 4) ? v : 8;
 }
 
@@ -1327,6 +1326,7 @@ WalkSplitLayout walk_split_layout(int64_t n_tgt) {
   return L;
 }
 
+#ifdef NBODY_LAB
 hipError_t launch_tree_walk_split(hipStream_t s, const WalkArgs<float>& a, char* scratch, const WalkSplitLayout& L, void* terms,
                                   int64_t term_capacity) {
   if (a.n_tgt <= 0) return hipSuccess;
@@ -1349,7 +1349,7 @@ hipError_t launch_tree_walk_split(hipStream_t s, const WalkArgs<float>& a, char*
   walk_sum<<<dim3((unsigned)((sum_waves + 3) / 4)), dim3(256), 0, s>>>(a, cnt, off, (const float2*)terms, info);
   return hipGetLastError();
 }
-
+#endif  // NBODY_LAB
 
 // The walk's preparation (the estimate's scan, its wrap check, the waves' budget: info[0..3] are final afterwards) and
 // the walk proper, separately: a caller that wants to see info[1] before the long kernel has run enqueues a copy and an
@@ -1389,8 +1389,8 @@ hipError_t launch_tree_walk_tile_prep(hipStream_t s, const WalkArgs<T>& a, char*
     if (estimate == 1 && !tail)
       walk_check_wrap_est<<<dim3((unsigned)((a.n_tgt + 255) / 256)), dim3(256), 0, s>>>(EstimateOf{hist, tgt_ids, shift}, off, a.n_tgt, info);
   }
-  const char* ew = getenv("NBODY_WALK_TILE_WAVES");  // development override of kTileWaves
-  int64_t extra = (ew && atoi(ew) > 0 ? (int64_t)atoi(ew) : kTileWaves) - a.n_tgt / 64;
+  const int ew = lab_int("NBODY_WALK_TILE_WAVES", 0);  // (laboratory: override of kTileWaves)
+  int64_t extra = (ew > 0 ? (int64_t)ew : kTileWaves) - a.n_tgt / 64;
   if (extra < a.n_tgt / 256) extra = a.n_tgt / 256;
   const uint32_t bt = tile_budget_targets();  // development override: a budget of this many average targets
   if (bt) extra = a.n_tgt / bt;
@@ -1424,30 +1424,33 @@ hipError_t launch_tree_walk_tile_main(hipStream_t s, const WalkArgs<T>& a_in, ch
   const uint32_t* off = (const uint32_t*)(scratch + L.off);
   int* info = (int*)(scratch + L.info);
   unsigned long long* total_out = (unsigned long long*)(info + 6);
-  const int tt = sizeof(T) == 8 ? tile_targets_f64() : tile_targets();
+  const int tt = tile_targets();
   const dim3 grid((unsigned)((grid_waves + 3) / 4));
   // node records by scalar loads (scalar_node_rec): the exact walk always (62 instead of 72 VGPRs: eight waves per SIMD instead of seven;
   // reference scene 0.579 -> 0.567 ms, Plummer 1 M 6.07 -> 5.96); NBODY_WALK_SCALAR_REC=0: the vector loads of one address
-  static const bool srec = !(getenv("NBODY_WALK_SCALAR_REC") && atoi(getenv("NBODY_WALK_SCALAR_REC")) == 0);
-#define NB_TILE(F, R) do { if (srec) walk_tile<T, F, R, true><<<grid, dim3(256), 0, s>>>(a, off, info, tgt_ids, hist, total_out); \
-                           else walk_tile<T, F, R, false><<<grid, dim3(256), 0, s>>>(a, off, info, tgt_ids, hist, total_out); } while (0)
+  static const bool srec = lab_int("NBODY_WALK_SCALAR_REC", 1) != 0;
   // FAST: f32 takes walk_tile_fast (registers, lane-parallel sums); f64 the rows arm (walk_tile<double, true>: LDS rows + ordered adds with
   // the one-reciprocal term) — walk_tile_fast<double> moves every value as two 32-bit halves through the swaps and runs at half
-  // the occupancy: Plummer 4 M f64 205 ms against 92 (the exact walk: 124).  NBODY_WALK_FAST_ROWS=0/1 forces one or the other.
-  static const int fast_rows_env = getenv("NBODY_WALK_FAST_ROWS") ? atoi(getenv("NBODY_WALK_FAST_ROWS")) : -1;
+  // the occupancy: Plummer 4 M f64 205 ms against 92 (the exact walk: 124).  Laboratory: NBODY_WALK_FAST_ROWS=0/1 forces one or the other.
+  static const int fast_rows_env = lab_int("NBODY_WALK_FAST_ROWS", -1);
   const bool fast_rows = fast_rows_env >= 0 ? fast_rows_env != 0 : sizeof(T) == 8;
+  // FAST: scalar loads where the walk is bound by what it issues (Plummer 1 M 3.10 -> 3.03 ms), vector loads of one address where it
+  // is bound by its longest waves' chains (reference scene 0.298 against 0.322 ms: the scalar path's round trip is the longer one)
+  static const int rec_env = lab_int("NBODY_WALK_FAST_REC", -1);
+  const int rec_mode = rec_env >= 0 ? rec_env : (a_in.n_tgt >= 400000 ? 3 : 0);
+#ifdef NBODY_LAB
+  // every variant the A/B tools switch between: rows 4 / 8 / 16, node records by vector loads, the rows arm in f32, the register arm
+  // in f64, the per-wave log
+#define NB_TILE(F, R) do { if (srec) walk_tile<T, F, R, true><<<grid, dim3(256), 0, s>>>(a, off, info, tgt_ids, hist, total_out); \
+                           else walk_tile<T, F, R, false><<<grid, dim3(256), 0, s>>>(a, off, info, tgt_ids, hist, total_out); } while (0)
   unsigned long long* wave_log = nullptr;
   WalkArgs<T> a_log = a_in;
-  if (a_in.fast && getenv("NBODY_WALK_WAVE_LOG") && atoi(getenv("NBODY_WALK_WAVE_LOG")) != 0) {  // development: per-wave time and step counts
+  if (a_in.fast && lab_int("NBODY_WALK_WAVE_LOG", 0) != 0) {  // development: per-wave time and step counts
     if (hipMalloc((void**)&wave_log, (size_t)grid.x * 4 * 4 * sizeof(unsigned long long)) != hipSuccess) return hipErrorOutOfMemory;
     (void)hipMemsetAsync(wave_log, 0, (size_t)grid.x * 4 * 4 * sizeof(unsigned long long), s);
     a_log.wave_log = wave_log;
   }
   const WalkArgs<T>& a = a_log;
-  // FAST: scalar loads where the walk is bound by what it issues (Plummer 1 M 3.10 -> 3.03 ms), vector loads of one address where it
-  // is bound by its longest waves' chains (reference scene 0.298 against 0.322 ms: the scalar path's round trip is the longer one)
-  static const int rec_env = getenv("NBODY_WALK_FAST_REC") ? atoi(getenv("NBODY_WALK_FAST_REC")) : -1;
-  const int rec_mode = rec_env >= 0 ? rec_env : (a.n_tgt >= 400000 ? 3 : 0);
   if (a.fast && !fast_rows) {
     if (wave_log) walk_tile_fast<T, 0, true><<<grid, dim3(256), 0, s>>>(a, off, info, tgt_ids, hist, total_out);
     else if (rec_mode == 1) walk_tile_fast<T, 1, false><<<grid, dim3(256), 0, s>>>(a, off, info, tgt_ids, hist, total_out);
@@ -1463,12 +1466,30 @@ hipError_t launch_tree_walk_tile_main(hipStream_t s, const WalkArgs<T>& a_in, ch
     (void)hipMemcpyAsync(h.data(), wave_log, nw * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s);
     (void)hipStreamSynchronize(s);
     (void)hipFree(wave_log);
-    FILE* f = fopen(getenv("NBODY_WALK_WAVE_LOG_FILE") ? getenv("NBODY_WALK_WAVE_LOG_FILE") : "/tmp/nbody_wave_log.bin", "wb");
+    const char* path = lab_str("NBODY_WALK_WAVE_LOG_FILE");
+    FILE* f = fopen(path ? path : "/tmp/nbody_wave_log.bin", "wb");
     if (f) {
       fwrite(h.data(), sizeof(unsigned long long), h.size(), f);
       fclose(f);
     }
   }
+#else
+  // the product's instantiations: the exact walk with 8 rows and scalar node records; FAST in f32 through registers (node records
+  // by plain or scalar loads, by size), FAST in f64 through the rows
+  (void)srec; (void)tt; (void)fast_rows;
+  const WalkArgs<T>& a = a_in;
+  if constexpr (sizeof(T) == 4) {
+    if (a.fast) {
+      if (rec_mode == 3) walk_tile_fast<T, 3, false><<<grid, dim3(256), 0, s>>>(a, off, info, tgt_ids, hist, total_out);
+      else walk_tile_fast<T, 0, false><<<grid, dim3(256), 0, s>>>(a, off, info, tgt_ids, hist, total_out);
+    } else {
+      walk_tile<T, false, 8, true><<<grid, dim3(256), 0, s>>>(a, off, info, tgt_ids, hist, total_out);
+    }
+  } else {
+    if (a.fast) walk_tile<T, true, 8, true><<<grid, dim3(256), 0, s>>>(a, off, info, tgt_ids, hist, total_out);
+    else walk_tile<T, false, 8, true><<<grid, dim3(256), 0, s>>>(a, off, info, tgt_ids, hist, total_out);
+  }
+#endif
   return hipGetLastError();
 }
 

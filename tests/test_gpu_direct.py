@@ -418,7 +418,7 @@ def test_sparse_heavy_masses_ride_with_the_near_list(nb, orc, force_nearfar):
     check_fast(a0, ref64, norm, cpu32)
 
 
-def test_reference_scene_takes_the_sparse_path(nb, orc, monkeypatch):
+def test_reference_scene_takes_the_sparse_path(nb, orc, lab, monkeypatch):
     """The whole scene of World::new (151 k bodies, two heavy): the context finds the sparse structure on upload; the
     step equals the per-body-mass one within the tolerance, on sampled targets against the oracle."""
     C = nb._capi
@@ -439,12 +439,13 @@ def test_reference_scene_takes_the_sparse_path(nb, orc, monkeypatch):
 
 # ------------------------------------------------------------------ mass classes (round 3)
 @pytest.mark.parametrize("n_classes", [2, 5, 32, 33])
-def test_mass_classes_within_tolerance(nb, orc, ctx, monkeypatch, capfd, n_classes):
+def test_mass_classes_within_tolerance(nb, orc, lab_ctx, monkeypatch, capfd, n_classes):
     """Masses that differ freely but take few values: the sources are ordered by mass class (every class padded to whole
     1 024-source tiles) and the equal-mass kernel runs tile by tile, the class's mass in the FMA that closes a tile.  1 .. 32
     classes take that path (NBODY_TRACE says so), 33 fall back to the per-body-mass kernel; both inside the frozen tolerance,
     near bodies (clamped pairs, a coincident pair) included, and bitwise reproducible from one upload to the next."""
     C = nb._capi
+    ctx = lab_ctx                                            # laboratory library: the test switches kernel variants
     n = 98304 + 777                                          # >= 65 536: the near/far split (and with it the classes) is on
     pos, vel, _ = nb.scenes.plummer(n, seed=47)
     rng = np.random.default_rng(n_classes)
@@ -473,10 +474,11 @@ def test_mass_classes_within_tolerance(nb, orc, ctx, monkeypatch, capfd, n_class
     assert (n_classes > 32) == np.array_equal(a0, a1)
 
 
-def test_mass_classes_follow_the_rows_through_a_tree_build(nb, orc, ctx, monkeypatch):
+def test_mass_classes_follow_the_rows_through_a_tree_build(nb, orc, lab_ctx, monkeypatch):
     """A BVH step permutes the rows (BVHTree::from partitions in place): the class order is rebuilt for the new row order
     before the next direct step, and whole direct steps follow the per-body kernel's trajectory to rounding."""
     C = nb._capi
+    ctx = lab_ctx                                            # laboratory library: the test switches kernel variants
     n = 70000
     pos, vel, _ = nb.scenes.plummer(n, seed=48)
     w = (np.arange(n) % 4 * 3 + 1).astype(np.uint32)
@@ -542,12 +544,13 @@ def test_captured_direct_graph_is_rebuilt_when_a_tree_step_permutes_the_rows(nb,
 
 # ------------------------------------------------------------------ the main pass's variants (NBODY_DIRECT_ASM)
 @pytest.mark.parametrize("n", [65536 + 16 * 5 + 3, 131072, 200003])
-def test_packed_and_streamed_main_pass_agree(nb, orc, ctx, monkeypatch, n):
+def test_packed_and_streamed_main_pass_agree(nb, orc, lab_ctx, monkeypatch, n):
     """NBODY_DIRECT_ASM: 0 the compiler's schedule, 1 the hand-ordered block (a pair per instruction), 2 packed couples (two
     pairs per packed op) through LDS, 3 (default) the same with the far sources streamed through SGPRs.  All four within the
     tolerance of the oracle; 2 and 3 share the arithmetic and the order of additions, hence the bits — with equal masses,
     with mass classes, with n not a multiple of anything (the far copy's padding), coincident and near bodies included."""
     C = nb._capi
+    ctx = lab_ctx                                            # laboratory library: the test switches kernel variants
     pos, vel, w1 = nb.scenes.plummer(n, seed=51)
     pos[100] = pos[200]                                      # coincident: contributes nothing
     pos[300] = pos[400] + F32(0.0078125)                     # inside the clamp radius: near bodies

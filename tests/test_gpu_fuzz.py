@@ -121,12 +121,13 @@ def test_quad_builds_equal_the_oracle_on_random_cases(nb, orc, ctx, dtype):
     assert done >= 5, done
 
 
-def test_direct_main_pass_on_random_cases(nb, orc, ctx, monkeypatch):
+def test_direct_main_pass_on_random_cases(nb, orc, lab_ctx, monkeypatch):
     """The direct step's packed / streamed main pass (NBODY_DIRECT_ASM 2 / 3) on random sizes (the near/far split on), random mass
     patterns (equal, a few classes, a few heavy bodies, all different) and positions with coincident bodies and pairs inside the
     clamp radius: within the oracle's tolerance on sampled targets, bitwise reproducible, and 2 and 3 give the same bits."""
     from tests._tol import check_fast
     C = nb._capi
+    ctx = lab_ctx                                            # laboratory library: NBODY_DIRECT_ASM is one of its switches
     rng = np.random.default_rng(20261006 + 1000 * SEED)
     for case in range(CASES // 10 or 3):
         n = int(rng.integers(65536, 180000))

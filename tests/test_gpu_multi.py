@@ -62,7 +62,7 @@ def test_one_device_rccl_direct_bit_identical(nb, n):
 
 @pytest.mark.parametrize("kind_name,dtype,order", [("bvh", F32, "as_written"), ("bvh", F32, "consistent"), ("quad", F32, "consistent"),
                                                    ("quad", np.float64, "consistent"), ("bvh", np.float64, "as_written")])
-def test_one_device_rccl_tree_bit_identical(nb, monkeypatch, kind_name, dtype, order):
+def test_one_device_rccl_tree_bit_identical(nb, lab, monkeypatch, kind_name, dtype, order):
     C = nb._capi
     monkeypatch.setenv("NBODY_MULTI_FORCE_EXCHANGE", "1")   # the sliced step + the one-rank all-gather, not the shortcut
     kind = C.TREE_BVH if kind_name == "bvh" else C.TREE_QUAD

@@ -169,7 +169,7 @@ def test_device_and_host_quad_builds_agree(nb, ctx, monkeypatch):
     ctx.upload(pos, vel, w)
     ctx.accel_tree(C.TREE_QUAD, pos[:10])
     dev = ctx.tree_export()
-    monkeypatch.setenv("NBODY_QUAD_BUILD_HOST", "1")
+    monkeypatch.setenv("NBODY_TREE_BUILD_HOST", "1")
     ctx.accel_tree(C.TREE_QUAD, pos[:10])
     host = ctx.tree_export()
     for k in ("geom", "mass", "is_leaf", "first", "count", "skip", "order"):
@@ -337,7 +337,7 @@ def test_device_and_host_bvh_builds_agree_over_steps(nb, monkeypatch):
     pos, vel, w = nb.scenes.galaxy()
     res = []
     for host in ("0", "1"):
-        monkeypatch.setenv("NBODY_BVH_BUILD_HOST", host)
+        monkeypatch.setenv("NBODY_TREE_BUILD_HOST", host)
         world = nb.World(pos, vel, w, method="bvh")
         cnt = nb.Counting()
         for _ in range(20):
@@ -358,7 +358,7 @@ def test_device_bvh_build_then_host_build_keeps_weights_in_row_order(nb, orc, ct
     ctx.upload(pos, vel, w)
     ctx.update_tree(C.TREE_BVH, 0.1, 2)
     assert ctx.last_build_on_device()
-    monkeypatch.setenv("NBODY_BVH_BUILD_HOST", "1")
+    monkeypatch.setenv("NBODY_TREE_BUILD_HOST", "1")
     ctx.update_tree(C.TREE_BVH, 0.1, 1)
     assert not ctx.last_build_on_device()
     p, v, w2, ids = ctx.download()
@@ -382,10 +382,11 @@ def test_device_bvh_build_declines_nan_positions(nb, orc, ctx):
 
 
 @pytest.mark.parametrize("blind", ["1", "3"])
-def test_device_bvh_build_with_long_nodes_left_after_the_blind_levels(nb, orc, ctx, monkeypatch, blind):
+def test_device_bvh_build_with_long_nodes_left_after_the_blind_levels(nb, orc, lab_ctx, monkeypatch, blind):
     """The build enqueues the levels a balanced tree needs and checks once; a lopsided tree (or, here, too few blind
     levels) must go on level by level and still end in the same tree."""
     C = nb._capi
+    ctx = lab_ctx                                          # laboratory library: the test forces a variant / a slow path
     monkeypatch.setenv("NBODY_BVH_BLIND_LEVELS", blind)
     rng = np.random.default_rng(23)
     scenes = {"galaxy": nb.scenes.galaxy()[::2],
@@ -405,12 +406,13 @@ def test_device_bvh_build_with_long_nodes_left_after_the_blind_levels(nb, orc, c
 
 # ------------------------------------------------------------------ split walk (walk_split.hip)
 @pytest.mark.parametrize("mode", ["0", "2", "3"])
-def test_split_and_fused_walks_are_the_same_walk(nb, orc, ctx, monkeypatch, mode):
+def test_split_and_fused_walks_are_the_same_walk(nb, orc, lab_ctx, monkeypatch, mode):
     """count / emit / ordered-sum (NBODY_WALK_SPLIT=2), the one-pass walk with the terms through LDS (=3) and the fused
     wave walk (=0) against the CPU recursion: the
     same nodes, pairs, operations and order of additions, so the same bits — targets = the particles (tree order), a
     strided subset of arbitrary targets, coincident and out-of-box targets, several thetas."""
     C = nb._capi
+    ctx = lab_ctx                                          # laboratory library: the test forces a variant / a slow path
     monkeypatch.setenv("NBODY_WALK_SPLIT", mode)
     pos, vel, w = nb.scenes.galaxy()
     pos, vel, w = pos[::3].copy(), vel[::3].copy(), w[::3].copy()
@@ -426,7 +428,7 @@ def test_split_and_fused_walks_are_the_same_walk(nb, orc, ctx, monkeypatch, mode
         assert np.array_equal(ctx.accel_tree(C.TREE_BVH, tg), bvh.walk(tg, theta=theta, nthreads=8))
 
 
-def test_split_walk_steps_equal_fused_walk_steps(nb, monkeypatch):
+def test_split_walk_steps_equal_fused_walk_steps(nb, lab, monkeypatch):
     pos, vel, w = nb.scenes.galaxy()
     res = []
     for mode in ("0", "2", "3", "1"):
@@ -442,7 +444,7 @@ def test_split_walk_steps_equal_fused_walk_steps(nb, monkeypatch):
             assert np.array_equal(a, b)
 
 
-def test_split_walk_backs_off_when_the_terms_do_not_fit(nb, monkeypatch):
+def test_split_walk_backs_off_when_the_terms_do_not_fit(nb, lab, monkeypatch):
     """N = 2^21 on the reference's needle-box BVH needs more terms than 32-bit offsets hold: the three-pass walk must fall
     back to the fused walk, the one-pass walk must go on without a counted estimate, and both must give the same
     accelerations as the fused walk."""
@@ -562,7 +564,7 @@ def test_one_pass_walk_history_survives_changes_between_steps(nb, orc, monkeypat
         assert np.array_equal(got[0], p2) and np.array_equal(got[1], v2)
 
 
-def test_one_pass_walk_notices_a_history_whose_scan_wraps(nb, monkeypatch, capfd):
+def test_one_pass_walk_notices_a_history_whose_scan_wraps(nb, lab, monkeypatch, capfd):
     """A shard's slice can meet counts of older walks (another theta) whose scaled sum no longer fits 32 bits: the walk
     must notice and go on without an estimate, not cut its waves by a wrapped scan.  The test hook fills the history
     with 0xFFFFFFFF before every walk that would use it."""
@@ -641,7 +643,7 @@ def test_step_ahead_learns_how_many_levels_a_lopsided_tree_has(nb, monkeypatch, 
 
 
 @pytest.mark.parametrize("hook", ["NBODY_BVH_BLIND_LEVELS", "NBODY_WALK_TILE_POISON"])
-def test_step_ahead_recovers_when_its_speculation_fails(nb, monkeypatch, capfd, hook):
+def test_step_ahead_recovers_when_its_speculation_fails(nb, lab, monkeypatch, capfd, hook):
     """Too few blind build levels (the device verdict says 'long nodes left') and a history whose scan wraps (the walk
     flags itself) both leave the step's input rows untouched — the gather writes the other set, the integration is
     gated — and the plain sequence does the step again.  Same trajectory as without the hooks."""
@@ -711,14 +713,14 @@ def test_device_bvh64_build_equals_oracle_tree(nb, orc, leaf):
             assert np.array_equal(ids, o.ids) and np.array_equal(p, o.pos_perm) and np.array_equal(w2, w[o.ids]), name
 
 
-def test_device_and_host_bvh64_builds_agree_over_steps(nb, monkeypatch, capfd):
+def test_device_and_host_bvh64_builds_agree_over_steps(nb, lab, monkeypatch, capfd):
     """10 full f64 steps with the device build against 10 with the host build: same rows; too few blind levels (the
     build then goes on four levels at a time) changes nothing either."""
     C = nb._capi
     pos, vel, w = nb.scenes.plummer(60000, seed=92, dtype=np.float64)
     res = []
     for host, blind in (("0", None), ("1", None), ("0", "3")):
-        monkeypatch.setenv("NBODY_BVH64_BUILD_HOST", host)
+        monkeypatch.setenv("NBODY_TREE_BUILD_HOST", host)
         if blind:
             monkeypatch.setenv("NBODY_BVH_BLIND_LEVELS", blind)
         with C.Context(0) as c:
@@ -781,7 +783,7 @@ def test_async_updates_equal_synchronous_ones(nb, orc):
 
 
 # ------------------------------------------------------------------ second half of round 3: phase clock, record fetches
-def test_phase_stamps_and_event_records_time_the_same_phases(nb, monkeypatch):
+def test_phase_stamps_and_event_records_time_the_same_phases(nb, lab, monkeypatch):
     """Steps enqueued ahead time their phases by the kernels' own 100 MHz clock (bvh_init / walk_scan_est_tail /
     integrate_inplace write it at the three boundaries) instead of three event records per step; NBODY_PHASE_STAMPS=0 keeps
     the events.  Same intervals: the two Counting splits agree, sum to about the wall time, and the rows are the same."""
@@ -809,7 +811,7 @@ def test_phase_stamps_and_event_records_time_the_same_phases(nb, monkeypatch):
     assert all(np.array_equal(x, y) for x, y in zip(a[4], b[4]))
 
 
-def test_node_record_fetch_variants_walk_the_same_walk(nb, monkeypatch):
+def test_node_record_fetch_variants_walk_the_same_walk(nb, lab, monkeypatch):
     """Node records arrive by scalar loads through the constant address space (exact walk: always; FAST: from 400 000 targets) or
     by vector loads of one address; FAST can also pin / not pin them (NBODY_WALK_FAST_REC 0 / 1 / 3).  Where they come from
     changes no bit."""

@@ -2,13 +2,15 @@
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import os as _os
+_os.environ.setdefault("NBODY_HIP_LIBRARY", "lab")  # tools switch kernel variants: the laboratory build (csrc/env.h)
 import nbody_simulation_amd as nb
 C = nb._capi
 
 
 def run(name, pos, vel, w, steps=10):
     for host in ("0", "1"):
-        os.environ["NBODY_BVH_BUILD_HOST"] = host
+        os.environ["NBODY_TREE_BUILD_HOST"] = host
         with C.Context(0) as ctx:
             ctx.set_params(theta=50.0)
             ctx.upload(pos, vel, w)

@@ -2,6 +2,8 @@
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import os as _os
+_os.environ.setdefault("NBODY_HIP_LIBRARY", "lab")  # tools switch kernel variants: the laboratory build (csrc/env.h)
 import nbody_simulation_amd as nb
 C = nb._capi
 which = sys.argv[1] if len(sys.argv) > 1 else "galaxy"

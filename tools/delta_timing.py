@@ -2,6 +2,8 @@
 import sys, time
 import numpy as np
 sys.path.insert(0, __file__.rsplit("/", 2)[0])
+import os as _os
+_os.environ.setdefault("NBODY_HIP_LIBRARY", "lab")  # tools switch kernel variants: the laboratory build (csrc/env.h)
 import nbody_simulation_amd as nb
 
 

@@ -6,6 +6,8 @@ import os, sys
 os.environ["NBODY_TRACE"] = "1"
 os.environ["NBODY_STEP_AHEAD"] = "0"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import os as _os
+_os.environ.setdefault("NBODY_HIP_LIBRARY", "lab")  # tools switch kernel variants: the laboratory build (csrc/env.h)
 import nbody_simulation_amd as nb  # noqa: E402
 C = nb._capi
 for name, (pos, vel, w) in (("reference scene", nb.scenes.galaxy()), ("Plummer 1M", nb.scenes.plummer(1 << 20, seed=0x5EED0003))):

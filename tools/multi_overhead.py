@@ -4,6 +4,8 @@ what is added is G preparations (hazard scan + near/far split, replicated per ra
 barriers.  Not a scaling measurement.    python tools/multi_overhead.py"""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import os as _os
+_os.environ.setdefault("NBODY_HIP_LIBRARY", "lab")  # tools switch kernel variants: the laboratory build (csrc/env.h)
 import nbody_simulation_amd as nb  # noqa: E402
 C = nb._capi
 n = 1 << 20

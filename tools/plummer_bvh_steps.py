@@ -1,6 +1,8 @@
 """A few BVH steps (theta 50) of a Plummer sphere, for a kernel trace: python tools/plummer_bvh_steps.py [steps=8] [n=1<<20]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import os as _os
+_os.environ.setdefault("NBODY_HIP_LIBRARY", "lab")  # tools switch kernel variants: the laboratory build (csrc/env.h)
 import nbody_simulation_amd as nb  # noqa: E402
 C = nb._capi
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 8

@@ -1,10 +1,12 @@
 """Randomised cross-check of the device quad-tree build (not part of the test suite: run on a GPU box): random sizes,
 distributions and precisions; the device-built tree against the host builder's, array by array (the host builder inserts point
-after point, as quad_tree.rs does), and three steps against three steps with the host builder (NBODY_QUAD_BUILD_HOST=1).
+after point, as quad_tree.rs does), and three steps against three steps with the host builder (NBODY_TREE_BUILD_HOST=1).
     python tools/quad_fuzz.py [cases=120] [seed=1] [log10 of the smallest size=0] [of the largest=5.6]"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import os as _os
+_os.environ.setdefault("NBODY_HIP_LIBRARY", "lab")  # tools switch kernel variants: the laboratory build (csrc/env.h)
 import nbody_simulation_amd as nb  # noqa: E402
 C = nb._capi
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 120
@@ -44,14 +46,14 @@ with C.Context(0) as ctx:
         same = True
         try:
             for host in ("0", "1"):
-                os.environ["NBODY_QUAD_BUILD_HOST"] = host
+                os.environ["NBODY_TREE_BUILD_HOST"] = host
                 ctx.upload(pos, vel, w)
                 ctx.update_tree(C.TREE_QUAD, 0.05, 3)
                 res.append(ctx.download())
             same = all(np.array_equal(a, b, equal_nan=True) for a, b in zip(*res))
         except C.NBodyError as e:
             print(tag, "steps:", str(e)[:60])
-        os.environ.pop("NBODY_QUAD_BUILD_HOST", None)
+        os.environ.pop("NBODY_TREE_BUILD_HOST", None)
         if not (ok and same): bad += 1
         print(tag, "tree", "ok" if ok else "MISMATCH", "steps", "ok" if same else "MISMATCH", flush=True)
 print("mismatching cases:", bad)

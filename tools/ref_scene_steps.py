@@ -2,6 +2,8 @@
 call; prints ms/step and the Counting split.    python tools/ref_scene_steps.py [steps=200] [warmup=20]"""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import os as _os
+_os.environ.setdefault("NBODY_HIP_LIBRARY", "lab")  # tools switch kernel variants: the laboratory build (csrc/env.h)
 import nbody_simulation_amd as nb  # noqa: E402
 C = nb._capi
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 200

@@ -1,6 +1,8 @@
 """Per-step wall time of nbody_update_direct_f32 at small N: eager launches vs hipGraph replay of step pairs."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import os as _os
+_os.environ.setdefault("NBODY_HIP_LIBRARY", "lab")  # tools switch kernel variants: the laboratory build (csrc/env.h)
 import numpy as np, nbody_simulation_amd as nb
 C = nb._capi
 for n in (1024, 16384, 32768, 65536, 131072, 262144):

@@ -3,6 +3,8 @@ targets, for the 4 096 targets closest to the heaviest body (the long walks), an
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import os as _os
+_os.environ.setdefault("NBODY_HIP_LIBRARY", "lab")  # tools switch kernel variants: the laboratory build (csrc/env.h)
 import nbody_simulation_amd as nb
 C = nb._capi
 os.environ["NBODY_WALK_SPLIT"] = "3"

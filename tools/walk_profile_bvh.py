@@ -1,6 +1,8 @@
 """Reference scene (World::new, seeded), BVH, theta 50: a few steps, for rocprofv3."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import os as _os
+_os.environ.setdefault("NBODY_HIP_LIBRARY", "lab")  # tools switch kernel variants: the laboratory build (csrc/env.h)
 import nbody_simulation_amd as nb
 C = nb._capi
 pos, vel, w = nb.scenes.galaxy()

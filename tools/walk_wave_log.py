@@ -5,6 +5,8 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["NBODY_WALK_WAVE_LOG"] = "1"
 os.environ["NBODY_STEP_AHEAD"] = "0"
+import os as _os
+_os.environ.setdefault("NBODY_HIP_LIBRARY", "lab")  # tools switch kernel variants: the laboratory build (csrc/env.h)
 import nbody_simulation_amd as nb
 C = nb._capi
 scene = sys.argv[1] if len(sys.argv) > 1 else "galaxy"
