@@ -1060,6 +1060,328 @@ __global__ __launch_bounds__(256) void walk_tile_fast(const WalkArgs<T> a, const
   }
 }
 
+#ifdef NBODY_LAB
+// ---- the FAST one-pass walk, BREADTH FIRST (round 4) ------------------------------------------------------------------
+// walk_tile_fast above is its longest wave's serial chain (profiles/r03_walk_fast_variants.txt: 0.355 us per node step — a scalar
+// load's round trip plus ~100 dependent instructions — 414 node steps in the reference scene's longest wave, 273 of the kernel's
+// 334 us).  The depth-first order is what makes it a chain: node i's record must arrive before anyone knows which record comes
+// next.  Under the tolerance contract the ORDER of a target's terms is free, and the traversal itself never needed it: a lane acts
+// at a node iff it descended through the parent, so a node's acting lanes are its parent's descend mask.  So the wave keeps a
+// DEQUE of (node, 64-bit lane mask) in LDS and takes up to 64 entries at a time from its head (breadth first): 64 lanes fetch 64
+// nodes' records — and the right siblings' indices, link[i + 1].x — in ONE round trip, then the entries are tested one after the
+// other with the record broadcast out of registers (v_readlane: SGPR operands, no memory in the loop); accepted nodes' terms are
+// taken on the spot, leaves (and three-node subtrees, as in the depth-first walk) go to a small list that is worked off after the
+// batch, the next leaf's particles on their way while this one's rounds run.  Same node tests, same interaction lists, same
+// terms as walk_tile_fast (nbody_tree_walk_stats and the history are unchanged); only the order of additions differs, and it is
+// a fixed function of the inputs (no atomics): bitwise reproducible.
+// MEASURED (profiles/r04_walk_bfs_ab.txt): correct (every FAST parity test green) and SLOWER — 0.579 against 0.338 ms on the
+// reference scene, 4.96 against 2.99 ms at Plummer 1 M.  The union of a wave's paths is NARROW: its 64 tree-contiguous targets
+// share one chain from the root to their region, so a level holds ~4 entries, not ~64, and every level pays a vector load's round
+// trip (longer than the scalar load's it replaces) plus the deque's hand-offs, at 5 waves per SIMD instead of 8 (28 KB of LDS
+// per group, 81 VGPRs).  Laboratory build only (NBODY_WALK_FAST_BFS=1); the product walks depth first.
+// The deque cannot outgrow its LDS: while it is nearly full the wave takes ONE entry from the TAIL instead (depth first: a
+// stack grows by at most the depth of the subtree it is in, and the device builds stop at 56 levels); should it still fill
+// up, the overflow word is set and the caller gets an error instead of a wrong answer.
+constexpr int kBfsQ = 512;          // deque slots per wave (12 B each)
+constexpr int kBfsHeadroom = 192;   // breadth first only while at least this many slots are free
+constexpr int kBfsLeaves = 64;      // leaf entries per batch: one per entry taken
+
+__device__ __forceinline__ int rl(int v, int lane_sel) { return __builtin_amdgcn_readlane(v, lane_sel); }
+__device__ __forceinline__ float rlf(float v, int lane_sel) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane_sel)); }
+
+// One leaf step of the FAST walk for the lanes of `mask` (`act`: this lane is one of them) against the particles [first, first +
+// count): walk_tile_fast's rounds (lane = particle, eight targets' rows reduced together; lane = target where most of the wave
+// wants the leaf).  (q0, m0): the first 64 particles, already fetched by the caller.
+template <class T>
+__device__ __forceinline__ void fast_leaf_step(const unsigned long long mask, const bool act, const int first, const int count, const int lane,
+                                               const typename Vec2Of<T>::type p, const T clamp, const typename Vec2Of<T>::type* __restrict__ lpos,
+                                               const T* __restrict__ lmass, typename Vec2Of<T>::type q0, T m0, T& bx, T& by) {
+  using T2 = typename Vec2Of<T>::type;
+  const int takers = __builtin_popcountll(mask);
+  const int rank = act ? (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u)) : -1;
+  for (int k0 = 0; k0 < count; k0 += 64) {  // 64 particles at a time
+    const int mine = k0 + lane;
+    const int left = count - k0;
+    const int mc = left < 64 ? left : 64;
+    T2 q = q0;
+    T m = m0;
+    if (k0 > 0) {
+      q = T2{0, 0};
+      m = 0;  // a lane past the end: force 0, its terms are exact zeros
+      if (mine < count) {
+        q = lpos[first + mine];
+        m = lmass[first + mine];
+      }
+    }
+    if (takers * kFastRoundCost > mc * kFastPairCost) {  // most of the wave wants this leaf: lane = target
+      for (int j = 0; j < mc; ++j) {
+        const T qx = lane_t(q.x, j), qy = lane_t(q.y, j), qm = lane_t(m, j);
+        if (act) {
+          const T dx = qx - p.x, dy = qy - p.y;
+          const T sc = fast_scale(dx, dy, qm, clamp);
+          bx = fma_t(dx, sc, bx);
+          by = fma_t(dy, sc, by);
+        }
+      }
+      continue;
+    }
+    unsigned long long todo = mask;
+    int batch0 = 0;
+#define NB_FAST_ROUND(XV, YV)                                             \
+  {                                                                       \
+    const int tl = __builtin_ctzll(todo);                                 \
+    todo &= todo - 1;                                                     \
+    const T dx = q.x - lane_t(p.x, tl), dy = q.y - lane_t(p.y, tl);       \
+    const T sc = fast_scale(dx, dy, m, clamp);                            \
+    XV = dx * sc;                                                         \
+    YV = dy * sc;                                                         \
+  }
+    while (todo) {
+      const int left_t = takers - batch0;
+      const int k = rank - batch0;  // this lane's place in the batch, if it is an acting target
+      T gx, gy;
+      int took;
+      if (left_t > 4) {  // eight targets (missing ones contribute zeros): x and y reduced side by side
+        T X[8], Y[8];
+#pragma unroll
+        for (int sl = 0; sl < 5; ++sl) NB_FAST_ROUND(X[sl], Y[sl])
+#pragma unroll
+        for (int sl = 5; sl < 8; ++sl) {
+          X[sl] = 0;
+          Y[sl] = 0;
+          if (todo) NB_FAST_ROUND(X[sl], Y[sl])
+        }
+        const T rx = reduce8(X), ry = reduce8(Y);
+        const int src = slot_lane8(k & 7);
+        gx = lane_fetch(rx, src);
+        gy = lane_fetch(ry, src);
+        took = 8;
+      } else if (left_t > 2) {  // three or four targets: their x and y are the eight values of ONE reduction
+        T V[8];
+#pragma unroll
+        for (int sl = 0; sl < 3; ++sl) NB_FAST_ROUND(V[2 * sl], V[2 * sl + 1])
+        V[6] = 0;
+        V[7] = 0;
+        if (todo) NB_FAST_ROUND(V[6], V[7])
+        const T r = reduce8(V);
+        const int src = 16 * (k & 1) + 8 * ((k >> 1) & 1);
+        gx = lane_fetch(r, src);
+        gy = lane_fetch(r, src + 32);
+        took = 4;
+      } else if (left_t == 2) {  // two targets: four values
+        T V[4];
+        NB_FAST_ROUND(V[0], V[1])
+        NB_FAST_ROUND(V[2], V[3])
+        const T r = reduce4(V);
+        const int src = 16 * (k & 1);
+        gx = lane_fetch(r, src);
+        gy = lane_fetch(r, src + 32);
+        took = 2;
+      } else {  // one target
+        T x, y;
+        NB_FAST_ROUND(x, y)
+        const T r = reduce2(x, y);
+        gx = lane_t(r, 16);
+        gy = lane_t(r, 48);
+        took = 1;
+      }
+      if (k >= 0 && k < took) {
+        bx = bx + gx;
+        by = by + gy;
+      }
+      batch0 += took;
+    }
+#undef NB_FAST_ROUND
+  }
+}
+
+__global__ __launch_bounds__(256) void walk_tile_fast_bfs(const WalkArgs<float> a, const uint32_t* __restrict__ off, int* __restrict__ info,
+                                                          const uint32_t* __restrict__ tgt_ids, uint32_t* __restrict__ hist,
+                                                          unsigned long long* __restrict__ total_out) {
+  using T = float;
+  __shared__ int q_idx_all[4][kBfsQ];
+  __shared__ unsigned q_lo_all[4][kBfsQ], q_hi_all[4][kBfsQ];
+  __shared__ int lf_first_all[4][kBfsLeaves], lf_count_all[4][kBfsLeaves];
+  __shared__ unsigned lf_lo_all[4][kBfsLeaves], lf_hi_all[4][kBfsLeaves];
+  const int lane = threadIdx.x & 63;
+  const int wib = threadIdx.x >> 6;
+  int* __restrict__ q_idx = q_idx_all[wib];
+  unsigned* __restrict__ q_lo = q_lo_all[wib];
+  unsigned* __restrict__ q_hi = q_hi_all[wib];
+  int* __restrict__ lf_first = lf_first_all[wib];
+  int* __restrict__ lf_count = lf_count_all[wib];
+  unsigned* __restrict__ lf_lo = lf_lo_all[wib];
+  unsigned* __restrict__ lf_hi = lf_hi_all[wib];
+  const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + wib));
+  if (info[1] != 0) return;  // the estimate's scan wrapped: the caller walks again without one
+  if (wave > info[5]) return;  // past the last wave that can hold a target
+  const int bshift = 31 - __builtin_clz((unsigned)__builtin_amdgcn_readfirstlane(info[3]));
+  const int n_tgt = (int)a.n_tgt;
+  int t0, lo;
+  wave_targets(off, n_tgt, wave, bshift, lane, t0, lo);
+  if (lo == t0) return;
+  const int64_t t = (int64_t)t0 + lane;
+  const bool live = t < lo;
+  const int64_t row = live ? (a.tgt_index ? (int64_t)a.tgt_index[t] : t) : 0;
+  const float2 p = live ? reinterpret_cast<const float2*>(a.tgt_pos)[row] : float2{0, 0};
+  const float4* __restrict__ g0 = reinterpret_cast<const float4*>(a.geom0);
+  const float4* __restrict__ g1 = reinterpret_cast<const float4*>(a.geom1);
+  const int4* __restrict__ lk = reinterpret_cast<const int4*>(a.link);
+  const float2* __restrict__ lpos = reinterpret_cast<const float2*>(a.leaf_pos);
+  const float* __restrict__ lmass = a.leaf_mass;
+  const float theta = a.theta, clamp = a.clamp;
+  const int n_nodes = a.n_nodes_dev ? __builtin_amdgcn_readfirstlane(*a.n_nodes_dev) : a.n_nodes;
+  uint32_t n_terms = 0;
+  float ax = 0, ay = 0, bx = 0, by = 0;  // two-level summation, as walk_tile_fast: the block sum joins the total every fourth leaf step
+  int leaf_steps = 0;
+  const int last = n_nodes - 1;
+  int head = 0, occ = 0;  // wave-uniform
+  const unsigned long long live_mask = __builtin_amdgcn_ballot_w64(live);
+  if (n_nodes > 0 && lane == 0) {
+    q_idx[0] = 0;
+    q_lo[0] = (unsigned)live_mask;
+    q_hi[0] = (unsigned)(live_mask >> 32);
+  }
+  if (n_nodes > 0) occ = 1;
+  bool overflow = false;
+  while (occ > 0) {
+    // ---- take a batch: from the head while there is room for its children (breadth first), else the newest entry alone
+    int B, start;
+    if (occ <= kBfsQ - kBfsHeadroom) {
+      B = occ < 64 ? occ : 64;
+      start = head;
+      head = (head + B) & (kBfsQ - 1);
+    } else {
+      B = 1;
+      start = (head + occ - 1) & (kBfsQ - 1);
+    }
+    occ -= B;
+    wave_lds_handoff();  // the entries' stores (lane 0, the batch before) before these reads
+    int my_idx = 0;
+    unsigned my_lo = 0, my_hi = 0;
+    if (lane < B) {
+      const int pos = (start + lane) & (kBfsQ - 1);
+      my_idx = q_idx[pos];
+      my_lo = q_lo[pos];
+      my_hi = q_hi[pos];
+    }
+    // ---- the batch's records, one round trip: link, box, centre of gravity | mass | s^2, and the right sibling's index
+    my_idx = my_idx < last ? my_idx : last;
+    const int4 ml = lk[my_idx];
+    const float4 mb = g0[my_idx];
+    const float4 mc = g1[my_idx];
+    const int mr = lk[my_idx < last ? my_idx + 1 : last].x;  // skip of node i + 1 = node i's right child (inner nodes)
+    int nleaf = 0;
+    for (int e = 0; e < B; ++e) {
+      const int i = rl(my_idx, e);
+      const int lx = rl(ml.x, e), ly = rl(ml.y, e), lz = rl(ml.z, e), lw = rl(ml.w, e);
+      const unsigned long long m = ((unsigned long long)(unsigned)rl((int)my_hi, e) << 32) | (unsigned)rl((int)my_lo, e);
+      const bool act = (m >> lane) & 1ull;
+      if (lw) {  // Leaf arm, main.rs:351-363
+        if (lane == 0) {
+          lf_first[nleaf] = ly;
+          lf_count[nleaf] = lz;
+          lf_lo[nleaf] = (unsigned)m;
+          lf_hi[nleaf] = (unsigned)(m >> 32);
+        }
+        ++nleaf;
+        n_terms += act ? (uint32_t)lz : 0u;
+        continue;
+      }
+      const float b_x = rlf(mb.x, e), b_y = rlf(mb.y, e), b_z = rlf(mb.z, e), b_w = rlf(mb.w, e);
+      const float c_x = rlf(mc.x, e), c_y = rlf(mc.y, e), c_z = rlf(mc.z, e), c_w = rlf(mc.w, e);
+      // the node test is the exact walk's, bit for bit (bvh_tree.rs:15-20 all strict; main.rs:228-232, :370-372)
+      const bool contains = (p.y > b_y) & (p.x > b_x) & (p.x < b_z) & (p.y < b_w);
+      const float ddx = p.x - c_x, ddy = p.y - c_y;
+      const float d2 = ddx * ddx + ddy * ddy;
+      const bool accept = act & !contains & (c_w < d2 * theta * theta);
+      const bool descend = act & !accept;
+      const float dx = c_x - p.x, dy = c_y - p.y;  // :374-379
+      const float sc = fast_scale(dx, dy, c_z, clamp);
+      const float nbx = fma_t(dx, sc, bx), nby = fma_t(dy, sc, by);
+      bx = accept ? nbx : bx;
+      by = accept ? nby : by;
+      n_terms += accept ? 1u : 0u;
+      const unsigned long long dmask = __builtin_amdgcn_ballot_w64(descend);
+      if (dmask == 0) continue;
+      if (lx - i == 3) {  // both children are leaves: their particles are this node's own range (walk_tile_fast's three-node fold)
+        if (lane == 0) {
+          lf_first[nleaf] = ly;
+          lf_count[nleaf] = lz;
+          lf_lo[nleaf] = (unsigned)dmask;
+          lf_hi[nleaf] = (unsigned)(dmask >> 32);
+        }
+        ++nleaf;
+        n_terms += descend ? (uint32_t)lz : 0u;
+        continue;
+      }
+      if (occ + 2 > kBfsQ) {  // never expected (see above): say so instead of walking on with a hole in the lists
+        overflow = true;
+        continue;
+      }
+      const int right = rl(mr, e);
+      if (lane == 0) {
+        const int t0q = (head + occ) & (kBfsQ - 1), t1q = (head + occ + 1) & (kBfsQ - 1);
+        q_idx[t0q] = i + 1;  // children[0] then children[1], main.rs:381-382
+        q_lo[t0q] = (unsigned)dmask;
+        q_hi[t0q] = (unsigned)(dmask >> 32);
+        q_idx[t1q] = right;
+        q_lo[t1q] = (unsigned)dmask;
+        q_hi[t1q] = (unsigned)(dmask >> 32);
+      }
+      occ += 2;
+    }
+    if (nleaf == 0) continue;
+    // ---- the batch's leaves: the next one's particles are fetched while this one's rounds run
+    wave_lds_handoff();
+    int f_cur = lf_first[0], c_cur = lf_count[0];
+    float2 q_cur = float2{0, 0};
+    float m_cur = 0;
+    if (lane < c_cur) {
+      q_cur = lpos[f_cur + lane];
+      m_cur = lmass[f_cur + lane];
+    }
+    for (int j = 0; j < nleaf; ++j) {
+      const unsigned long long m = ((unsigned long long)lf_hi[j] << 32) | lf_lo[j];
+      int f_nxt = 0, c_nxt = 0;
+      float2 q_nxt = float2{0, 0};
+      float m_nxt = 0;
+      if (j + 1 < nleaf) {
+        f_nxt = lf_first[j + 1];
+        c_nxt = lf_count[j + 1];
+        if (lane < c_nxt) {
+          q_nxt = lpos[f_nxt + lane];
+          m_nxt = lmass[f_nxt + lane];
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);  // (the loads above stay above the rounds below)
+      fast_leaf_step<float>(m, (m >> lane) & 1ull, f_cur, c_cur, lane, p, clamp, lpos, lmass, q_cur, m_cur, bx, by);
+      if (++leaf_steps == 4) {
+        ax = ax + bx;
+        ay = ay + by;
+        bx = by = 0;
+        leaf_steps = 0;
+      }
+      f_cur = f_nxt;
+      c_cur = c_nxt;
+      q_cur = q_nxt;
+      m_cur = m_nxt;
+    }
+  }
+  ax = ax + bx;
+  ay = ay + by;
+  if (overflow && lane == 0) info[1] = 1;
+  if (live) {
+    reinterpret_cast<float2*>(a.acc)[row] = float2{ax, ay};
+    if (hist) hist[tgt_ids[t]] = n_terms;  // by particle id: the rows are permuted by every build
+  }
+  unsigned long long sum = live ? n_terms : 0ull;  // what this walk cost, for the next estimate's scale
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) sum += (unsigned long long)__shfl_xor((long long)sum, d, 64);
+  if (lane == 0) atomicAdd(total_out, sum);
+}
+#endif  // NBODY_LAB (walk_tile_fast_bfs)
+
 struct EstimateOf {  // target t's terms in the last walk, scaled
   const uint32_t* hist;
   const uint32_t* ids;
@@ -1451,7 +1773,13 @@ hipError_t launch_tree_walk_tile_main(hipStream_t s, const WalkArgs<T>& a_in, ch
     a_log.wave_log = wave_log;
   }
   const WalkArgs<T>& a = a_log;
-  if (a.fast && !fast_rows) {
+  // NBODY_WALK_FAST_BFS=1: round 4's breadth-first FAST walk (walk_tile_fast_bfs) — measured SLOWER than the depth-first kernel
+  // (reference scene 0.579 against 0.338 ms, Plummer 1 M 4.96 against 2.99: profiles/r04_walk_bfs_ab.txt), kept here for that A/B only
+  bool bfs = false;
+  if constexpr (sizeof(T) == 4) bfs = a.fast && !fast_rows && !wave_log && lab_int("NBODY_WALK_FAST_BFS", 0) != 0;
+  if (bfs) {
+    if constexpr (sizeof(T) == 4) walk_tile_fast_bfs<<<grid, dim3(256), 0, s>>>(a, off, info, tgt_ids, hist, total_out);
+  } else if (a.fast && !fast_rows) {
     if (wave_log) walk_tile_fast<T, 0, true><<<grid, dim3(256), 0, s>>>(a, off, info, tgt_ids, hist, total_out);
     else if (rec_mode == 1) walk_tile_fast<T, 1, false><<<grid, dim3(256), 0, s>>>(a, off, info, tgt_ids, hist, total_out);
     else if (rec_mode == 3) walk_tile_fast<T, 3, false><<<grid, dim3(256), 0, s>>>(a, off, info, tgt_ids, hist, total_out);
