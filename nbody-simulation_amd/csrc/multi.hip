@@ -33,6 +33,8 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cstdio>
+#include <cmath>
 #include <condition_variable>
 #include <cstring>
 #include <functional>
@@ -109,6 +111,9 @@ struct Multi {
   std::vector<hipStream_t> comm_stream;
   std::vector<std::vector<hipEvent_t>> ev_chunk;  // [device][chunk]: that chunk's kernels are done
   std::vector<hipEvent_t> ev_done;                // [device]: this device's communication stream has drained
+  // NBODY_TRACE: timed events of a direct call's LAST step, [device][chunk] — the chunk's kernels have ended (compute stream), its
+  // gather begins / has ended (communication stream): says whether the exchange hides behind the next chunk's kernels
+  std::vector<std::vector<hipEvent_t>> tr_kend, tr_gbeg, tr_gend;
   Pool pool;
   Barrier barrier;
   // layout of the current upload
@@ -133,6 +138,9 @@ struct Multi {
       if ((size_t)d < ev_chunk.size())
         for (auto e : ev_chunk[(size_t)d]) (void)hipEventDestroy(e);
       if ((size_t)d < ev_done.size() && ev_done[(size_t)d]) (void)hipEventDestroy(ev_done[(size_t)d]);
+      for (auto* set : {&tr_kend, &tr_gbeg, &tr_gend})
+        if ((size_t)d < set->size())
+          for (auto e : (*set)[(size_t)d]) (void)hipEventDestroy(e);
       if ((size_t)d < comm_stream.size() && comm_stream[(size_t)d]) (void)hipStreamDestroy(comm_stream[(size_t)d]);
       ctx_destroy_single(sub[(size_t)d]);
     }
@@ -244,8 +252,19 @@ int direct_worker(Multi& M, int d, float delta, int n_steps) {
   std::vector<char*> bases((size_t)G);
   // one rank under RCCL still goes through its (no-op) all-gather, so that the RCCL path runs on a one-GPU box too
   const bool exch = G > 1 || M.exchange == NBODY_EXCHANGE_RCCL;
+  // NBODY_TRACE: time the last step's chunks against their gathers (events with timing, made on first use)
+  const bool trace = exch && C > 1 && env_int("NBODY_TRACE", 0) != 0;
+  if (trace && M.tr_kend[(size_t)d].size() < (size_t)C) {
+    for (auto* set : {&M.tr_kend, &M.tr_gbeg, &M.tr_gend})
+      while ((*set)[(size_t)d].size() < (size_t)C) {
+        hipEvent_t ev = nullptr;
+        if (hipEventCreate(&ev) != hipSuccess) return M.hip_fail(d, hipGetLastError(), "hipEventCreate");
+        (*set)[(size_t)d].push_back(ev);
+      }
+  }
   int par = 0;
   for (int step = 0; step < n_steps; ++step, par ^= 1) {
+    const bool timed = trace && step == n_steps - 1;
     float2* cur = (float2*)M.posbuf[par][(size_t)d];
     float2* nxt = (float2*)M.posbuf[par ^ 1][(size_t)d];
     for (int p = 0; p < G; ++p) bases[(size_t)p] = (char*)M.posbuf[par ^ 1][(size_t)p];
@@ -264,12 +283,15 @@ int direct_worker(Multi& M, int d, float delta, int n_steps) {
       if (!exch) continue;
       if (ok) {  // the chunk's gather starts when its kernels are done; the compute stream goes on with the next chunk
         hipError_t e = hipEventRecord(M.ev_chunk[(size_t)d][(size_t)c], S->stream);
+        if (e == hipSuccess && timed) e = hipEventRecord(M.tr_kend[(size_t)d][(size_t)c], S->stream);
         if (e == hipSuccess) e = hipStreamWaitEvent(M.comm_stream[(size_t)d], M.ev_chunk[(size_t)d][(size_t)c], 0);
+        if (e == hipSuccess && timed) e = hipEventRecord(M.tr_gbeg[(size_t)d][(size_t)c], M.comm_stream[(size_t)d]);
         if (e != hipSuccess) { rc = M.hip_fail(d, e, "chunk event"); ok = false; }
       }
       if (!M.barrier.arrive(ok)) return ok ? NBODY_ERR_HIP : rc;  // some rank failed: nobody enters the exchange
       rc = M.gather_piece(d, bases, (size_t)c * G * M.block * rowb, (size_t)M.block * rowb, (size_t)nt * rowb);
       ok = rc == NBODY_OK;
+      if (ok && timed && hipEventRecord(M.tr_gend[(size_t)d][(size_t)c], M.comm_stream[(size_t)d]) != hipSuccess) (void)hipGetLastError();
     }
     if (exch) {
       if (!M.barrier.arrive(ok)) return ok ? NBODY_ERR_HIP : rc;
@@ -283,6 +305,23 @@ int direct_worker(Multi& M, int d, float delta, int n_steps) {
   if (par) std::swap(st.pos, s.pos_next);
   hipError_t e = hipStreamSynchronize(S->stream);
   if (e != hipSuccess) return M.hip_fail(d, e, "hipStreamSynchronize");
+  if (trace && n_steps > 0) {
+    // chunk c's gather against chunk c + 1's kernels: it should BEGIN before they end (the streams overlap at all) and, where the
+    // exchange is shorter than a chunk's kernels, END before they do (only the last chunk's gather is exposed)
+    for (int c = 0; c + 1 < C; ++c) {
+      if (M.block_count(c + 1, d) <= 0) continue;
+      float lead_ms = 0.f, slack_ms = 0.f, took_ms = 0.f;
+      if (hipEventElapsedTime(&lead_ms, M.tr_gbeg[(size_t)d][(size_t)c], M.tr_kend[(size_t)d][(size_t)c + 1]) != hipSuccess ||
+          hipEventElapsedTime(&slack_ms, M.tr_gend[(size_t)d][(size_t)c], M.tr_kend[(size_t)d][(size_t)c + 1]) != hipSuccess ||
+          hipEventElapsedTime(&took_ms, M.tr_gbeg[(size_t)d][(size_t)c], M.tr_gend[(size_t)d][(size_t)c]) != hipSuccess) {
+        (void)hipGetLastError();
+        continue;
+      }
+      std::fprintf(stderr, "[nbody] multi: rank %d (device %d) chunk %d: gather began %.1f us before chunk %d's kernels ended, took %.1f us, "
+                           "ended %.1f us %s them\n", d, M.dev[(size_t)d], c, 1e3 * lead_ms, c + 1, 1e3 * took_ms, 1e3 * std::fabs(slack_ms),
+                   slack_ms >= 0.f ? "before" : "after");
+    }
+  }
   s.tree_valid = false;
   S->steps_done += (uint64_t)n_steps;
   return NBODY_OK;
@@ -588,6 +627,9 @@ NB_API int nbody_create_multi_ex(nbody_ctx** out, int n_devices, const int* devi
   M->sub.assign((size_t)n_devices, nullptr);
   M->comm.assign((size_t)n_devices, nullptr);
   M->comm_stream.assign((size_t)n_devices, nullptr);
+  M->tr_kend.assign((size_t)n_devices, {});
+  M->tr_gbeg.assign((size_t)n_devices, {});
+  M->tr_gend.assign((size_t)n_devices, {});
   M->ev_chunk.assign((size_t)n_devices, {});
   M->ev_done.assign((size_t)n_devices, nullptr);
   M->xbuf.assign((size_t)n_devices, nullptr);

@@ -16,6 +16,38 @@ __device__ __forceinline__ void wave_lds_handoff() {
 #endif
 }
 
+// A node's three records by SCALAR loads: the index is wave-uniform, but the compiler only picks s_load for memory it can prove
+// unwritten during the kernel, which it cannot here (the kernels store accelerations and history) — so plain loads become
+// vector loads of one address (a round trip through the vector L1 and 64 lanes' worth of return data for 48 bytes).  The tree was
+// written by the kernels BEFORE this one, so reading it through the constant address space is sound.
+template <class T> struct NodeVec4;
+template <> struct NodeVec4<float> { using type = float4; };
+template <> struct NodeVec4<double> { using type = double4; };
+template <class T> struct NodeRec { int4 l; typename NodeVec4<T>::type b, c; };
+template <class T>
+__device__ __forceinline__ NodeRec<T> scalar_node_rec(const void* link, const void* geom0, const void* geom1, const int k) {
+  typedef int v4i __attribute__((ext_vector_type(4)));
+  typedef T v4t __attribute__((ext_vector_type(4)));
+  using T4 = typename NodeVec4<T>::type;
+  const v4i l = ((const v4i __attribute__((address_space(4)))*)link)[k];
+  const v4t b = ((const v4t __attribute__((address_space(4)))*)geom0)[k];
+  const v4t c = ((const v4t __attribute__((address_space(4)))*)geom1)[k];
+  return NodeRec<T>{int4{l.x, l.y, l.z, l.w}, T4{b.x, b.y, b.z, b.w}, T4{c.x, c.y, c.z, c.w}};
+}
+// A tree-ordered particle (position, mass) the same way: leaf data is wave-uniform in the fused walks.
+template <class T> struct NodeVec2;
+template <> struct NodeVec2<float> { using type = float2; };
+template <> struct NodeVec2<double> { using type = double2; };
+template <class T>
+__device__ __forceinline__ typename NodeVec2<T>::type scalar_leaf_pos(const void* leaf_pos, const int k) {
+  typedef T v2t __attribute__((ext_vector_type(2)));
+  const v2t q = ((const v2t __attribute__((address_space(4)))*)leaf_pos)[k];
+  return typename NodeVec2<T>::type{q.x, q.y};
+}
+template <class T> __device__ __forceinline__ T scalar_leaf_mass(const T* leaf_mass, const int k) {
+  return ((const T __attribute__((address_space(4)))*)leaf_mass)[k];
+}
+
 template <class T> struct WalkArgs {
   const void* geom0;      // T4[n_nodes]  lo.x lo.y hi.x hi.y
   const void* geom1;      // T4[n_nodes]  cog.x cog.y mass s2

@@ -151,7 +151,9 @@ __global__ __launch_bounds__(256) void tree_walk(const WalkArgs<T> a) {
 // reduction: sleeping lanes resume at or after skip[i] (their sleeping subtree contains node i), therefore
 //     next = any(acting lane descends) ? i + 1 : skip[i].
 // The wave visits the union of its lanes' paths; targets are handed out in tree order so that union stays small.
-template <class T, int LB, bool PREFETCH, bool FAST>
+// STATS: the three counters of nbody_tree_walk_stats ride along (a template parameter: the counting costs every node step six
+// instructions of ~60 whether or not anyone asked).
+template <class T, int LB, bool PREFETCH, bool FAST, bool STATS>
 __global__ __launch_bounds__(256) void tree_walk_wave(const WalkArgs<T> a) {
   using T2 = typename V2<T>::type;
   using T4 = typename V4<T>::type;
@@ -212,9 +214,9 @@ __global__ __launch_bounds__(256) void tree_walk_wave(const WalkArgs<T> a) {
         T2 q[LB];
         T m[LB];
 #pragma unroll
-        for (int j = 0; j < LB; ++j) {
-          q[j] = lpos[k0 + j];
-          m[j] = lmass[k0 + j];
+        for (int j = 0; j < LB; ++j) {  // (wave-uniform: scalar loads)
+          q[j] = scalar_leaf_pos<T>(a.leaf_pos, k0 + j);
+          m[j] = scalar_leaf_mass<T>(a.leaf_mass, k0 + j);
         }
         if (act) {
 #pragma unroll
@@ -232,7 +234,7 @@ __global__ __launch_bounds__(256) void tree_walk_wave(const WalkArgs<T> a) {
       }
       if (act) {
         resume = l.x;
-        if (a.stats) { visits++; leaf_pairs += (unsigned long long)l.z; }
+        if constexpr (STATS) { visits++; leaf_pairs += (unsigned long long)l.z; }
       }
       next = l.x;
     } else {
@@ -251,7 +253,7 @@ __global__ __launch_bounds__(256) void tree_walk_wave(const WalkArgs<T> a) {
         by = accept ? nay : by;
       }
       resume = accept ? l.x : (descend ? i + 1 : resume);
-      if (a.stats) {
+      if constexpr (STATS) {
         accepted += accept ? 1u : 0u;
         visits += act ? 1u : 0u;
       }
@@ -261,7 +263,11 @@ __global__ __launch_bounds__(256) void tree_walk_wave(const WalkArgs<T> a) {
     if (PREFETCH && next == i + 1) {
       l = ln; b = bn; c = cn;
     } else if (next < n_nodes) {
-      l = lk[next]; b = g0[next]; c = g1[next];
+      // the three records by scalar loads (scalar_node_rec), TOGETHER: left alone the compiler sinks the box and the centre of gravity
+      // into the node arm, behind the wait for the link — two dependent round trips per node step
+      const NodeRec<T> r = scalar_node_rec<T>(a.link, a.geom0, a.geom1, next);
+      asm volatile("" : : "s"(r.b.x), "s"(r.c.w));
+      l = r.l; b = r.b; c = r.c;
     }
     i = next;
 #ifdef NB_WALK_TIMING
@@ -282,7 +288,7 @@ __global__ __launch_bounds__(256) void tree_walk_wave(const WalkArgs<T> a) {
   }
   return;
 #endif
-  if (a.stats && live) {
+  if (STATS && a.stats && live) {
     atomicAdd(&a.stats[0], visits);
     atomicAdd(&a.stats[1], accepted);
     atomicAdd(&a.stats[2], leaf_pairs);
@@ -340,8 +346,10 @@ __global__ __launch_bounds__(256) void tree_walk_small(const WalkArgs<T> a, cons
   int resume = live ? 0 : n_nodes;
   int i = 0;
   while (i < n_nodes) {  // i is wave-uniform
-    const int4 l = lk[i];
-    const T4 b = g0[i], c = g1[i];
+    const NodeRec<T> rec = scalar_node_rec<T>(a.link, a.geom0, a.geom1, i);  // scalar loads, the three together (see tree_walk_wave)
+    asm volatile("" : : "s"(rec.b.x), "s"(rec.c.w));
+    const int4 l = rec.l;
+    const T4 b = rec.b, c = rec.c;
     const bool act = resume <= i;
     int next;
     if (l.w) {  // Leaf arm, main.rs:351-363
@@ -550,8 +558,9 @@ template <class T> hipError_t launch_tree_walk(hipStream_t s, const WalkArgs<T>&
   // leaf batch / successor prefetch, measured in profiles/r01_walk_kernels_ab.txt: big leaves (BVH, 64) want 8
   // particles per fetch, small ones (quad, <= 8) 4; prefetching node i+1 never pays (the walk is bound by the
   // IEEE divides of the as-written pair function, not by scalar-load latency)
-#define NB_W(L, P) do { if (a.fast) hipLaunchKernelGGL((tree_walk_wave<T, L, P, true>), grid, dim3(256), 0, s, a); \
-                        else hipLaunchKernelGGL((tree_walk_wave<T, L, P, false>), grid, dim3(256), 0, s, a); } while (0)
+#define NB_WS(L, P, F) do { if (a.stats) hipLaunchKernelGGL((tree_walk_wave<T, L, P, F, true>), grid, dim3(256), 0, s, a); \
+                           else hipLaunchKernelGGL((tree_walk_wave<T, L, P, F, false>), grid, dim3(256), 0, s, a); } while (0)
+#define NB_W(L, P) do { if (a.fast) NB_WS(L, P, true); else NB_WS(L, P, false); } while (0)
 #ifdef NBODY_LAB
   const int env_lb = lab_int("NBODY_WALK_LB", 0);
   const int env_pf = lab_int("NBODY_WALK_PREFETCH", -1);
@@ -564,6 +573,7 @@ template <class T> hipError_t launch_tree_walk(hipStream_t s, const WalkArgs<T>&
   if (a.big_leaves) NB_W(8, false); else NB_W(4, false);
 #endif
 #undef NB_W
+#undef NB_WS
   return hipGetLastError();
 }
 __global__ __launch_bounds__(256) void div_pair_selftest(const float* __restrict__ nx, const float* __restrict__ ny, const float* __restrict__ den,

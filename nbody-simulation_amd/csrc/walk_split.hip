@@ -438,22 +438,6 @@ __device__ __forceinline__ void wave_targets(const uint32_t* __restrict__ off, c
   if (t1 > n_tgt) t1 = n_tgt;
 }
 
-// A node's three records by SCALAR loads: the index is wave-uniform, but the compiler only picks s_load for memory it can prove
-// unwritten during the kernel, which it cannot here (the kernels store accelerations and history) — so plain loads become
-// vector loads of one address (a round trip through the vector L1 and 64 lanes' worth of return data for 48 bytes).  The tree was
-// written by the kernels BEFORE this one, so reading it through the constant address space is sound (as `off` is read).
-template <class T> struct NodeRec { int4 l; typename Vec4Of<T>::type b, c; };
-template <class T>
-__device__ __forceinline__ NodeRec<T> scalar_node_rec(const void* link, const void* geom0, const void* geom1, const int k) {
-  typedef int v4i __attribute__((ext_vector_type(4)));
-  typedef T v4t __attribute__((ext_vector_type(4)));
-  using T4 = typename Vec4Of<T>::type;
-  const v4i l = ((const v4i __attribute__((address_space(4)))*)link)[k];
-  const v4t b = ((const v4t __attribute__((address_space(4)))*)geom0)[k];
-  const v4t c = ((const v4t __attribute__((address_space(4)))*)geom1)[k];
-  return NodeRec<T>{int4{l.x, l.y, l.z, l.w}, T4{b.x, b.y, b.z, b.w}, T4{c.x, c.y, c.z, c.w}};
-}
-
 template <class T, bool FAST, int TT, bool SREC = false>
 __global__ __launch_bounds__(256) void walk_tile(const WalkArgs<T> a, const uint32_t* __restrict__ off, const int* __restrict__ info,
                                                  const uint32_t* __restrict__ tgt_ids, uint32_t* __restrict__ hist,
