@@ -164,8 +164,6 @@ __global__ __launch_bounds__(256) void tree_walk_wave(const WalkArgs<T> a) {
   const T4* __restrict__ g0 = reinterpret_cast<const T4*>(a.geom0);
   const T4* __restrict__ g1 = reinterpret_cast<const T4*>(a.geom1);
   const int4* __restrict__ lk = reinterpret_cast<const int4*>(a.link);
-  const T2* __restrict__ lpos = reinterpret_cast<const T2*>(a.leaf_pos);
-  const T* __restrict__ lmass = a.leaf_mass;
   const T theta = a.theta, clamp = a.clamp;
   const int n_nodes = a.n_nodes;
   T ax = 0, ay = 0;
@@ -335,9 +333,6 @@ __global__ __launch_bounds__(256) void tree_walk_small(const WalkArgs<T> a, cons
   const bool live = t < a.n_tgt;
   const int64_t row = live ? (a.tgt_index ? (int64_t)a.tgt_index[t] : t) : 0;
   const T2 p = live ? reinterpret_cast<const T2*>(a.tgt_pos)[row] : T2{0, 0};
-  const T4* __restrict__ g0 = reinterpret_cast<const T4*>(a.geom0);
-  const T4* __restrict__ g1 = reinterpret_cast<const T4*>(a.geom1);
-  const int4* __restrict__ lk = reinterpret_cast<const int4*>(a.link);
   const T2* __restrict__ lpos = reinterpret_cast<const T2*>(a.leaf_pos);
   const T* __restrict__ lmass = a.leaf_mass;
   const T theta = a.theta, clamp = a.clamp;
