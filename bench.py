@@ -226,7 +226,8 @@ def _tree_leg(nb, name, workload, pos, vel, w, kind, theta, steps, profile_names
             ach = flops / (kms * 1e-3) / 1e12 if kms > 0 else 0.0
             peak = PEAK_F64_TFLOPS if f64 else PEAK_F32_TFLOPS
             roof = {"bound": "valu_f64" if f64 else "valu_f32", "bound_class": "compute",
-                    "kernel": ("nbody::tree_walk_small" if kind == C.TREE_QUAD else "nbody::walk_tile") + ("<FAST>" if label == "fast" else ""),
+                    "kernel": {(True, "exact"): "nbody::tree_walk_small", (True, "fast"): "nbody::tree_walk_wave<FAST>",
+                               (False, "exact"): "nbody::walk_tile", (False, "fast"): "nbody::walk_tile_fast"}[(kind == C.TREE_QUAD, label)],
                     "achieved": ach, "peak": peak,
                     "unit": "TFLOP/s", "frac": ach / peak, "kernel_ms": kms, "launches_timed": kl,
                     "pair_evaluations_per_launch": float(leaf_pairs + accepted), "node_tests_per_launch": float(visits),
