@@ -69,7 +69,7 @@ typedef enum nbody_status {
 
 /* Arithmetic of the pair function.  Direct sum: all three values below.  Tree walks: AUTO and EXACT use the reference's
  * operations (bit-identical results); FAST is an opt-in that keeps the reference's node tests and interaction lists but
- * evaluates each pair with one reciprocal (tolerance of DESIGN.md §6 instead of bit parity). */
+ * evaluates each pair with one reciprocal (tolerance of DESIGN.md §5 instead of bit parity). */
 typedef enum nbody_arith {
   NBODY_ARITH_AUTO = 0,  /* FAST, switching per step on device to EXACT when a position is non-finite,
                             >= 2^60 in magnitude, or non-zero below 2^-22 (the inputs on which FAST and the

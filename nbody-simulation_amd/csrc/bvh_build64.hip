@@ -4,7 +4,7 @@
 //
 // bvh_build.hip (f32) is tuned to the last microsecond for the reference's own scene; this one is the same mathematics
 // written plainly, level by level over ALL open nodes at once, because what it replaces is a 50-65 ms host build at
-// N = 4 M, not a 0.7 ms device one:
+// N = 4 M (HISTORY.md §4.3c), not a 0.7 ms device one:
 //   per level   fold64      one work-group per (open node, coordinate): min / max and the sum EXACTLY as the sequential chain
 //                           `sum = sum + p` rounds it (bvh_tree.rs:58-61) — the parity-map scan of exact_sum64.h, a tile of
 //                           addends per round, real adds wherever the chain leaves its binade;

@@ -309,7 +309,7 @@ int direct_plan(nbody_ctx* c, int64_t n_src, const void* mass_all, float uniform
     return fail(c, NBODY_ERR_INVALID, "direct_step: bad target/source counts");
   if (arith < NBODY_ARITH_AUTO || arith > NBODY_ARITH_EXACT) return fail(c, NBODY_ERR_INVALID, "direct_step: bad arith");
   if (!ws || ws_bytes < direct_ws_bytes(n_src, n_tgt_max)) return fail(c, NBODY_ERR_INVALID, "direct_step: workspace too small");
-  // FAST's zero-distance bias needs clamp >= 2^-19; smaller clamps always take EXACT.
+  // FAST's zero-distance bias needs clamp >= 2^-19 (HISTORY.md §4.1); smaller clamps always take EXACT.
   if (arith != NBODY_ARITH_EXACT && !(clamp >= 1.9073486328125e-06f)) arith = NBODY_ARITH_EXACT;
   DirectPlan p;
   p.arith = arith;

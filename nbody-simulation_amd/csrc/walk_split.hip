@@ -403,8 +403,6 @@ __global__ __launch_bounds__(256) void walk_sum(const WalkArgs<float> a, const u
 
 #endif  // NBODY_LAB (walk_sum)
 
-constexpr int kHeavyWaveTargets = 16;  // a one-pass-walk wave with at most this many targets runs at a raised priority (see walk_tile)
-
 // ---- the walk in ONE pass, terms through LDS (walk_tile) --------------------------------------------------------------
 // Same idea as the three passes above - a leaf's terms are evaluated lane = particle, so a leaf step costs what its
 // takers cost - but the terms never leave the CU: up to TT acting targets of the wave are evaluated against the leaf
@@ -460,9 +458,6 @@ __global__ __launch_bounds__(256) void walk_tile(const WalkArgs<T> a, const uint
   int t0, lo;
   wave_targets(off, n_tgt, wave, bshift, lane, t0, lo);
   if (lo == t0) return;
-  // A wave the budget cut short holds heavy targets: long paths, the kernel's critical chain (profiles/r03_walk_fast_variants.txt).
-  // It issues ahead of the lighter waves it shares its SIMD with.
-  if (lo - t0 <= kHeavyWaveTargets) __builtin_amdgcn_s_setprio(2);
   const int64_t t = (int64_t)t0 + lane;
   const bool live = t < lo;
   const int64_t row = live ? (a.tgt_index ? (int64_t)a.tgt_index[t] : t) : 0;
@@ -812,9 +807,6 @@ __global__ __launch_bounds__(256) void walk_tile_fast(const WalkArgs<T> a, const
   int t0, lo;
   wave_targets(off, n_tgt, wave, bshift, lane, t0, lo);
   if (lo == t0) return;
-  // A wave the budget cut short holds heavy targets: long paths, the kernel's critical chain (profiles/r03_walk_fast_variants.txt).
-  // It issues ahead of the lighter waves it shares its SIMD with.
-  if (lo - t0 <= kHeavyWaveTargets) __builtin_amdgcn_s_setprio(2);
   const int64_t t = (int64_t)t0 + lane;
   const bool live = t < lo;
   const int64_t row = live ? (a.tgt_index ? (int64_t)a.tgt_index[t] : t) : 0;
