@@ -208,7 +208,7 @@ def test_fast_walks_on_random_cases(nb, orc, ctx, monkeypatch):
 
 def test_sharded_direct_steps_on_random_cases(nb, orc):
     """Several ranks behind one handle (the one device listed several times, peer copies), random sizes with the near/far split
-    on (the streamed main pass over couples, ragged last blocks, 1-4 chunks, mass classes or equal masses): one FAST step from
+    on (the streamed main pass over couples, ragged last blocks, 1-4 chunks; equal masses, mass classes or free per-body masses): one FAST step from
     rest gives v = fl(a dt) with a inside the frozen tolerance on sampled targets, and x = x + v dt bit for bit."""
     from tests._tol import ACC_RTOL
     C = nb._capi
@@ -218,7 +218,10 @@ def test_sharded_direct_steps_on_random_cases(nb, orc):
         ranks = int(rng.choice([2, 3, 4, 8]))
         chunks = int(rng.choice([1, 2, 4]))
         pos = _scene(rng, (0, 1, 5)[int(rng.integers(0, 3))], n, np.float32, nb)
-        w = np.ones(n, np.uint32) if rng.random() < 0.5 else rng.integers(1, 5, n).astype(np.uint32)
+        mk = int(rng.integers(0, 3))                             # equal masses | four mass classes | free masses (direct_stream_m)
+        w = (np.ones(n, np.uint32), rng.integers(1, 5, n).astype(np.uint32), rng.integers(1, 1 << 20, n).astype(np.uint32))[mk]
+        if case == 0:
+            w = rng.integers(1, 1 << 20, n).astype(np.uint32)    # every run covers the free-mass path at least once
         vel = np.zeros_like(pos)
         tg = np.sort(rng.choice(n, 2048, replace=False))
         ref64, norm = orc.direct_accel(pos, w, targets=tg, accum="f64", nthreads=16)
