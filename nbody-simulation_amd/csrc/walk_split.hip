@@ -38,8 +38,17 @@ constexpr int kCountTPW = 64;
 constexpr uint32_t kTermBudget = 8192;  // terms a wave of the term pass writes, about (at least: see walk_total)
 constexpr uint32_t kBudgetTargets = 12; // ... or this many average targets' worth, if that is more
 constexpr uint32_t kTileBudget = 8192;        // smallest budget of a wave of the one-pass walk (walk_tile)
-constexpr int64_t kTileWaves = 16384;         // waves it aims at: twice what the chip holds (256 CUs x 32), unless the
-                                              // targets need more anyway (then a quarter more than n / 64)
+// Waves the one-pass walk aims at (the budget is the power of two that keeps the count at or under it).  Round 4, measured on the
+// bench's reference-scene leg (300 steps; profiles/r04_walk_wave_target.txt): the walk is its longest waves' chains, and those
+// chains all start at once only while EVERY wave is resident — 256 CUs x 32 slots = 8 192.  The round-3 constant 16 384 put
+// 9 700 waves on the evolved scene (a second residency round: exact 0.636 ms, FAST 0.338); 6 144 keeps them in one (0.476 /
+// 0.297).  Scenes whose head count alone fills the chip several times over (n / 64 >= 8 192) keep "a quarter more than n / 64".
+__host__ __device__ inline int64_t tile_waves_target(int64_t n_tgt) {
+  const int64_t heads = n_tgt / 64;
+  const int64_t extra = n_tgt / 256 > 2048 ? n_tgt / 256 : 2048;
+  const int64_t w = heads + extra;
+  return w > 6144 ? w : 6144;
+}
 constexpr int kTileRoundCost = 66;            // instructions a target costs at a leaf, lane = particle (a round + its share of the adds)
 constexpr int kFusedPairCost = 48;            // ... and a particle costs the wave, lane = target
 
@@ -1695,8 +1704,8 @@ hipError_t launch_tree_walk_tile_prep(hipStream_t s, const WalkArgs<T>& a, char*
     if (estimate == 1 && !tail)
       walk_check_wrap_est<<<dim3((unsigned)((a.n_tgt + 255) / 256)), dim3(256), 0, s>>>(EstimateOf{hist, tgt_ids, shift}, off, a.n_tgt, info);
   }
-  const int ew = lab_int("NBODY_WALK_TILE_WAVES", 0);  // (laboratory: override of kTileWaves)
-  int64_t extra = (ew > 0 ? (int64_t)ew : kTileWaves) - a.n_tgt / 64;
+  const int ew = lab_int("NBODY_WALK_TILE_WAVES", 0);  // (laboratory: override of tile_waves_target)
+  int64_t extra = (ew > 0 ? (int64_t)ew : tile_waves_target(a.n_tgt)) - a.n_tgt / 64;
   if (extra < a.n_tgt / 256) extra = a.n_tgt / 256;
   const uint32_t bt = tile_budget_targets();  // development override: a budget of this many average targets
   if (bt) extra = a.n_tgt / bt;
