@@ -425,13 +425,17 @@ __global__ __launch_bounds__(256) void walk_sum(const WalkArgs<float> a, const u
 // every lane probes one point of the range, a ballot finds the first that has reached w — narrows 64-fold per round trip: three
 // rounds for 151 405 targets and ONE for the second bound (t1 <= t0 + 64), instead of the forty dependent probes of two binary
 // searches (16 us of every wave's start, on the scalar side; 125 us as vector loads with a division each before that).
-__device__ __forceinline__ void wave_targets(const uint32_t* __restrict__ off, const int n_tgt, const int wave, const int bshift, const int lane,
+// off / budget as a multiply-high by M = floor((2^32 - 1) / budget): monotone in `off`, never above the true quotient, the same
+// integer for every wave — all that g needs.  The budget is then ANY integer (round 4: a power of two left the wave count anywhere
+// between the aim and half of it, and the walk's time follows the wave count: profiles/r04_walk_wave_target.txt).
+__device__ __forceinline__ int off_quot(uint32_t off, uint32_t M) { return (int)__umulhi(off, M); }
+__device__ __forceinline__ void wave_targets(const uint32_t* __restrict__ off, const int n_tgt, const int wave, const uint32_t M, const int lane,
                                              int& t0, int& t1) {
   int lo = 0, hi = n_tgt;  // the first t with g(t) >= wave lies in [lo, hi] (hi = "none below hi")
   while (lo < hi) {
     const int step = (hi - lo + 63) >> 6;
     const int idx = lo + lane * step;
-    const bool reached = idx >= hi || (int)(off[idx] >> bshift) + (idx >> 6) >= wave;
+    const bool reached = idx >= hi || off_quot(off[idx], M) + (idx >> 6) >= wave;
     const unsigned long long m = __builtin_amdgcn_ballot_w64(reached);
     const int first = m ? __builtin_ctzll(m) : 64;  // (lane 0 probes lo itself)
     if (first == 0) { hi = lo; break; }
@@ -441,7 +445,7 @@ __device__ __forceinline__ void wave_targets(const uint32_t* __restrict__ off, c
   }
   t0 = lo;
   const int idx = t0 + lane;                        // the first t with g(t) > wave: at most 64 further on
-  const bool past = idx >= n_tgt || (int)(off[idx] >> bshift) + (idx >> 6) > wave;
+  const bool past = idx >= n_tgt || off_quot(off[idx], M) + (idx >> 6) > wave;
   const unsigned long long m = __builtin_amdgcn_ballot_w64(past);
   t1 = t0 + (m ? __builtin_ctzll(m) : 64);
   if (t1 > n_tgt) t1 = n_tgt;
@@ -462,10 +466,10 @@ __global__ __launch_bounds__(256) void walk_tile(const WalkArgs<T> a, const uint
   if (wave > info[5]) return;  // past the last wave that can hold a target (most of the grid on a small scene): no searches
   // first t with g(t) >= wave, g(t) = off[t] / budget + t / 64 (see walk_pass), then the first with g(t) > wave: all on the
   // scalar side (`off` through the constant address space; the budget is a power of two, tile_total)
-  const int bshift = 31 - __builtin_clz((unsigned)__builtin_amdgcn_readfirstlane(info[3]));
+  const uint32_t qmul = 0xFFFFFFFFu / (uint32_t)__builtin_amdgcn_readfirstlane(info[3]);  // (budget >= 64)
   const int n_tgt = (int)a.n_tgt;  // (the scan, hence the walk, is 32 bits wide)
   int t0, lo;
-  wave_targets(off, n_tgt, wave, bshift, lane, t0, lo);
+  wave_targets(off, n_tgt, wave, qmul, lane, t0, lo);
   if (lo == t0) return;
   const int64_t t = (int64_t)t0 + lane;
   const bool live = t < lo;
@@ -811,10 +815,10 @@ __global__ __launch_bounds__(256) void walk_tile_fast(const WalkArgs<T> a, const
   // space (s_load: it was written by kernels before this one) and the budget is a power of two (tile_total), so the
   // quotient is a shift — forty dependent steps that cost a wave 125 us as vector loads and a 32-bit division each, on
   // SIMDs whose vector pipes the other waves keep busy (profiles/r03_walk_wave_log.txt).
-  const int bshift = 31 - __builtin_clz((unsigned)__builtin_amdgcn_readfirstlane(info[3]));
+  const uint32_t qmul = 0xFFFFFFFFu / (uint32_t)__builtin_amdgcn_readfirstlane(info[3]);  // (budget >= 64)
   const int n_tgt = (int)a.n_tgt;  // (the scan, hence the walk, is 32 bits wide)
   int t0, lo;
-  wave_targets(off, n_tgt, wave, bshift, lane, t0, lo);
+  wave_targets(off, n_tgt, wave, qmul, lane, t0, lo);
   if (lo == t0) return;
   const int64_t t = (int64_t)t0 + lane;
   const bool live = t < lo;
@@ -1208,10 +1212,10 @@ __global__ __launch_bounds__(256) void walk_tile_fast_bfs(const WalkArgs<float> 
   const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + wib));
   if (info[1] != 0) return;  // the estimate's scan wrapped: the caller walks again without one
   if (wave > info[5]) return;  // past the last wave that can hold a target
-  const int bshift = 31 - __builtin_clz((unsigned)__builtin_amdgcn_readfirstlane(info[3]));
+  const uint32_t qmul = 0xFFFFFFFFu / (uint32_t)__builtin_amdgcn_readfirstlane(info[3]);  // (budget >= 64)
   const int n_tgt = (int)a.n_tgt;
   int t0, lo;
-  wave_targets(off, n_tgt, wave, bshift, lane, t0, lo);
+  wave_targets(off, n_tgt, wave, qmul, lane, t0, lo);
   if (lo == t0) return;
   const int64_t t = (int64_t)t0 + lane;
   const bool live = t < lo;
@@ -1392,6 +1396,16 @@ __global__ __launch_bounds__(256) void walk_check_wrap_est(EstimateOf est, const
   if (i + 1 == n && (unsigned long long)off[i] + est((int)i) > 0x7fffffffull) info[1] = 1;  // the budget arithmetic is 31 bits wide
 }
 // budget of walk_tile's waves from the estimate's total (see walk_total)
+// A wave's budget in (scaled) terms: total / extra_waves rounded up — g(t) = off[t] / budget + t / 64 then ends within extra_waves of the
+// head count — never below kTileBudget (scaled like the estimate) or 64.
+__device__ __forceinline__ uint32_t tile_budget(unsigned long long total, int64_t extra_waves, int shift) {
+  const unsigned long long want = (total + (unsigned long long)extra_waves - 1) / (unsigned long long)extra_waves;
+  unsigned long long budget = kTileBudget >> shift;
+  if (budget < 64) budget = 64;
+  if (budget < want) budget = want;
+  if (budget > (1ull << 30)) budget = 1ull << 30;
+  return (uint32_t)budget;
+}
 __device__ __forceinline__ void tile_total(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off, int64_t n,
                                            const uint32_t* __restrict__ tgt_ids, const uint32_t* __restrict__ hist, int shift,
                                            int64_t extra_waves, int64_t grid_waves, int* __restrict__ info) {
@@ -1400,10 +1414,7 @@ __device__ __forceinline__ void tile_total(const uint32_t* __restrict__ cnt, con
   info[0] = (int)(total > 0x7fffffffull ? 0x7fffffffull : total);
   // g(t) = off[t] / budget + t / 64 ends near total / budget + n / 64: `extra_waves` more than the head count alone
   // (ceiling: with the floor, total / budget could reach extra_waves + extra_waves / want, past the grid)
-  unsigned long long want = (total + (unsigned long long)extra_waves - 1) / (unsigned long long)extra_waves;
-  uint32_t budget = kTileBudget >> shift;
-  if (budget < 64) budget = 64;
-  while (budget < want && budget < (1u << 30)) budget <<= 1;
+  const uint32_t budget = tile_budget(total, extra_waves, shift);
   info[3] = (int)budget;
   info[5] = (int)(total / budget + (unsigned long long)((n > 0 ? n - 1 : 0) / 64));  // the last wave that can hold a target (g of the last one)
   // belt and braces: a wave index the grid does not hold would leave its targets unwalked — flag it like a wrapped scan,
@@ -1425,10 +1436,7 @@ __device__ __forceinline__ void tile_tail_duties(unsigned long long total, int w
     int out[8] = {0, wrapped, wrapped2, 0, 0, 0, 0, 0};
     out[0] = (int)(total > 0x7fffffffull ? 0x7fffffffull : total);
     // walk_tile_total's arithmetic (a total clipped to 2^31 - 1 has raised the flag already)
-    unsigned long long want = (total + (unsigned long long)extra_waves - 1) / (unsigned long long)extra_waves;
-    uint32_t budget = kTileBudget >> shift;
-    if (budget < 64) budget = 64;
-    while (budget < want && budget < (1u << 30)) budget <<= 1;
+    const uint32_t budget = tile_budget(total, extra_waves, shift);
     out[3] = (int)budget;
     out[5] = (int)(total / budget + (unsigned long long)((n > 0 ? n - 1 : 0) / 64));  // the last wave that can hold a target
     if (total / budget + (unsigned long long)(n / 64) + 1 >= (unsigned long long)grid_waves) out[1] = 1;

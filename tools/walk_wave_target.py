@@ -23,12 +23,16 @@ def run(pos, vel, w, steps, arith):
     return 1e3 * dt / steps, kms
 
 
-scenes = [("reference scene", nb.scenes.galaxy(), 300)]
-for n, steps in ((262144, 100), (400000, 60), (655360, 40), (1 << 20, 20)):
-    scenes.append((f"plummer {n}", nb.scenes.plummer(n, seed=0x5EED0003), steps))
+# python tools/walk_wave_target.py [all | ref | plummer] [W ...]   (default: all, the values below)
+which = sys.argv[1] if len(sys.argv) > 1 else "all"
+values = tuple(sys.argv[2:]) or ("default", "16384", "8192", "6144")
+scenes = [("reference scene", nb.scenes.galaxy(), 300)] if which in ("all", "ref") else []
+if which in ("all", "plummer"):
+    for n, steps in ((262144, 100), (400000, 60), (655360, 40), (1 << 20, 20)):
+        scenes.append((f"plummer {n}", nb.scenes.plummer(n, seed=0x5EED0003), steps))
 print(f"{'scene':<18} {'NBODY_WALK_TILE_WAVES':<22} {'exact ms/step (kernel)':<26} FAST ms/step (kernel)")
 for name, (pos, vel, w), steps in scenes:
-    for waves in ("default", "16384", "8192", "6144"):
+    for waves in values:
         if waves == "default":
             os.environ.pop("NBODY_WALK_TILE_WAVES", None)
         else:
