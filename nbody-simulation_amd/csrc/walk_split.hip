@@ -38,16 +38,16 @@ constexpr int kCountTPW = 64;
 constexpr uint32_t kTermBudget = 8192;  // terms a wave of the term pass writes, about (at least: see walk_total)
 constexpr uint32_t kBudgetTargets = 12; // ... or this many average targets' worth, if that is more
 constexpr uint32_t kTileBudget = 8192;        // smallest budget of a wave of the one-pass walk (walk_tile)
-// Waves the one-pass walk aims at (the budget is the power of two that keeps the count at or under it).  Round 4, measured on the
-// bench's reference-scene leg (300 steps; profiles/r04_walk_wave_target.txt): the walk is its longest waves' chains, and those
-// chains all start at once only while EVERY wave is resident — 256 CUs x 32 slots = 8 192.  The round-3 constant 16 384 put
-// 9 700 waves on the evolved scene (a second residency round: exact 0.636 ms, FAST 0.338); 6 144 keeps them in one (0.476 /
-// 0.297).  Scenes whose head count alone fills the chip several times over (n / 64 >= 8 192) keep "a quarter more than n / 64".
+// Waves the one-pass walk aims at; a wave's budget is total terms / (this - n / 64), any integer (tile_budget).  Round 4, measured
+// (profiles/r04_walk_wave_target.txt): the walk is its longest waves' chains, and they all start at once only while EVERY wave is
+// resident — 256 CUs x 32 slots = 8 192.  Round 3 aimed at 16 384 ("twice what the chip holds") with power-of-two budgets: 9 700 waves
+// on the bench's reference-scene leg, a second residency round (exact 0.636 ms, FAST 0.338).  Kept inside one round the same walk takes
+// 0.48-0.49 / 0.29-0.30 ms; Plummer 262 144: 0.76 -> 0.61-0.63, 400 000: 1.32 -> 1.15.  Where the head count alone exceeds the
+// chip (n / 64 > 8 192) every extra wave repeats a traversal for nothing: 1 024 more than the head count is the measured optimum at
+// 400 000, 655 360 and 1 048 576 bodies.
 __host__ __device__ inline int64_t tile_waves_target(int64_t n_tgt) {
-  const int64_t heads = n_tgt / 64;
-  const int64_t extra = n_tgt / 256 > 2048 ? n_tgt / 256 : 2048;
-  const int64_t w = heads + extra;
-  return w > 6144 ? w : 6144;
+  const int64_t w = n_tgt / 64 + 1024;
+  return w > 6656 ? w : 6656;
 }
 constexpr int kTileRoundCost = 66;            // instructions a target costs at a leaf, lane = particle (a round + its share of the adds)
 constexpr int kFusedPairCost = 48;            // ... and a particle costs the wave, lane = target
@@ -1714,7 +1714,7 @@ hipError_t launch_tree_walk_tile_prep(hipStream_t s, const WalkArgs<T>& a, char*
   }
   const int ew = lab_int("NBODY_WALK_TILE_WAVES", 0);  // (laboratory: override of tile_waves_target)
   int64_t extra = (ew > 0 ? (int64_t)ew : tile_waves_target(a.n_tgt)) - a.n_tgt / 64;
-  if (extra < a.n_tgt / 256) extra = a.n_tgt / 256;
+  if (extra < 256) extra = 256;
   const uint32_t bt = tile_budget_targets();  // development override: a budget of this many average targets
   if (bt) extra = a.n_tgt / bt;
   if (extra < 1) extra = 1;

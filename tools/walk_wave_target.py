@@ -35,6 +35,8 @@ for name, (pos, vel, w), steps in scenes:
     for waves in values:
         if waves == "default":
             os.environ.pop("NBODY_WALK_TILE_WAVES", None)
+        elif waves.startswith("+"):                           # "+k": k waves more than the head count n / 64
+            os.environ["NBODY_WALK_TILE_WAVES"] = str(pos.shape[0] // 64 + int(waves[1:]))
         else:
             os.environ["NBODY_WALK_TILE_WAVES"] = waves
         e = run(pos, vel, w, steps, C.ARITH_AUTO)
