@@ -43,6 +43,19 @@ def _free_port():
     return p
 
 
+def _spawn(fn, make_args, nprocs):
+    """mp.spawn with a rendezvous port probed just before: between the probe and the children's bind another process can take the
+    port (seen once on the GPU box: EADDRINUSE in the TCPStore, before any rank had touched the GPU).  That — and only that — is
+    tried again with a fresh port; any other failure is the test's."""
+    for attempt in range(3):
+        try:
+            mp.spawn(fn, args=make_args(_free_port()), nprocs=nprocs, join=True)
+            return
+        except Exception as e:  # noqa: BLE001
+            if "EADDRINUSE" not in str(e) or attempt == 2:
+                raise
+
+
 def _worker(rank, world, port, n, steps, ret, chunks=0):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -68,7 +81,7 @@ def test_sharded_steps_equal_single_rank(world, n, chunks, orc, nb):
     steps = 3
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), n, steps, ret, chunks), nprocs=world, join=True)
+    _spawn(_worker, lambda port: (world, port, n, steps, ret, chunks), world)
     pos, vel, _ = nb.scenes.plummer(n, seed=61)
     w = (np.arange(n) % 3 + 1).astype(np.uint32)
     rp, rv, _ = orc.update_direct(pos, vel, w, delta=0.1, nsteps=steps)
