@@ -1,5 +1,5 @@
 """NBODY_WALK_WAVE_LOG=1: per-wave clock ticks (100 MHz) and step counts of the FAST one-pass BVH walk (walk_tile_fast).
-    python tools/walk_wave_log.py [galaxy|plummer]"""
+    python tools/walk_wave_log.py [galaxy|plummer] [steps before the logged one = 2]"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -10,12 +10,15 @@ _os.environ.setdefault("NBODY_HIP_LIBRARY", "lab")  # tools switch kernel varian
 import nbody_simulation_amd as nb
 C = nb._capi
 scene = sys.argv[1] if len(sys.argv) > 1 else "galaxy"
+warm = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 pos, vel, w = nb.scenes.galaxy() if scene == "galaxy" else nb.scenes.plummer(1 << 20, seed=0x5EED0003)
 with C.Context(0) as ctx:
     ctx.set_params(theta=50.0, order=C.ORDER_AS_WRITTEN, arith=C.ARITH_FAST)
     ctx.upload(pos, vel, w)
     t = C.Timer()
-    ctx.update_tree(C.TREE_BVH, 0.1, 2)
+    os.environ["NBODY_WALK_WAVE_LOG"] = "0"
+    ctx.update_tree(C.TREE_BVH, 0.1, warm)
+    os.environ["NBODY_WALK_WAVE_LOG"] = "1"
     ctx.set_timer(t)
     ctx.update_tree(C.TREE_BVH, 0.1, 1)
     ms, _ = t.read()
@@ -25,7 +28,7 @@ us = (log[:, 0] & np.uint64(0xFFFFFF)) * 0.01
 nodes, leaves = log[:, 1].astype(np.int64), log[:, 2].astype(np.int64)
 targets, rounds = (log[:, 3] >> np.uint64(32)).astype(np.int64), (log[:, 3] & np.uint64(0xFFFFFFFF)).astype(np.int64)
 live = targets > 0
-print(f"{scene}: walk kernel {ms:.3f} ms (with the log's overhead); {live.sum()} of {len(us)} waves have targets")
+print(f"{scene} after {warm} steps, NBODY_WALK_TILE_WAVES={os.environ.get('NBODY_WALK_TILE_WAVES', 'default')}: walk kernel {ms:.3f} ms (with the log's overhead); {live.sum()} of {len(us)} waves have targets")
 print(f"per live wave: {us[live].mean():.1f} us mean, {np.percentile(us[live], 99):.1f} p99, {us[live].max():.1f} max; steps {nodes[live].mean():.0f} node + "
       f"{leaves[live].mean():.0f} leaf, {rounds[live].mean():.0f} rounds, {targets[live].mean():.1f} targets")
 steps = nodes + leaves
@@ -39,5 +42,12 @@ end = start + (us * 100).astype(np.int64)
 print(f"waves start between 0 and {(start[live].max() - t_first) * 0.01:.1f} us after the first; the last one ends at {(end[live].max() - t_first) * 0.01:.1f} us")
 for k in np.argsort(-end * live)[:5]:
     print(f"  ends last: wave {k}: starts at {(start[k] - t_first) * 0.01:.1f} us, runs {us[k]:.1f} us, {targets[k]} targets, {nodes[k]} node steps, {leaves[k]} leaf steps")
+h = np.histogram(us[live], bins=[0, 25, 50, 75, 100, 125, 150, 175, 200, 250, 300, 400, 1000])[0]
+print("waves by run time (us) <25 <50 <75 <100 <125 <150 <175 <200 <250 <300 <400 more:", " ".join(str(x) for x in h))
+big = live & (targets >= 48)
+few = live & (targets <= 8)
+for name, m in (("waves of >= 48 targets", big), ("waves of <= 8 targets", few)):
+    if m.sum():
+        print(f"  {name}: {m.sum()}, {us[m].mean():.1f} us mean, {us[m].max():.1f} max, {nodes[m].mean():.0f} node + {leaves[m].mean():.0f} leaf steps, {rounds[m].mean():.0f} rounds")
 for k in np.argsort(-us)[:8]:
     print(f"  wave {k}: {us[k]:.1f} us, {targets[k]} targets, {nodes[k]} node steps, {leaves[k]} leaf steps, {rounds[k]} rounds")
