@@ -225,3 +225,32 @@ def test_fast_quad_f64_walk_at_config4_size(nb, orc):
     assert np.all(np.isfinite(acc)) and err.max() <= F64_RTOL
     _, st = quad.walk(rows_pos, theta=0.5, nthreads=16, stats=True)
     assert tuple(int(x) for x in st) == stats
+
+
+# ------------------------------------------------------------------ laboratory: the breadth-first FAST walk (kept for its A/B)
+@pytest.mark.parametrize("scene,n,theta", [("galaxy", 40000, 50.0), ("plummer", 30000, 0.5), ("clumps", 20000, 50.0)])
+def test_lab_breadth_first_fast_walk_has_the_depth_first_lists(nb, orc, lab, monkeypatch, scene, n, theta):
+    """walk_tile_fast_bfs (laboratory build, NBODY_WALK_FAST_BFS=1; profiles/r04_walk_bfs_ab.txt: correct and slower, so not in the
+    product) visits what the depth-first walk visits: inside the FAST tolerance of the oracle's lists, the per-particle term counts
+    it leaves behind (the next walk's estimate) equal the depth-first kernel's, and two runs give the same bits."""
+    C = lab
+    monkeypatch.setenv("NBODY_WALK_SPLIT", "3")
+    pos, vel, w = _scene(nb, scene, n, np.float32)
+    bvh = orc.BVH(pos, w)
+    flat = bvh.flat()
+    ref64, norm = bvh.walk_ref(flat.pos_perm, theta=theta, nthreads=16)
+    out = {}
+    for bfs in ("0", "1"):
+        monkeypatch.setenv("NBODY_WALK_FAST_BFS", bfs)
+        with C.Context(0) as c:
+            c.set_params(theta=theta, leaf_size=64, order=C.ORDER_CONSISTENT, arith=C.ARITH_FAST)
+            c.upload(pos, vel, w)
+            a1 = c.accel_tree(C.TREE_BVH)
+            c.upload(pos, vel, w)
+            a2 = c.accel_tree(C.TREE_BVH)
+            assert np.array_equal(a1, a2)                   # no atomics: a fixed function of the inputs
+            check_fast(a1, ref64, norm, label=f" bfs={bfs} {scene}")
+            c.update_tree(C.TREE_BVH, 0.1, 3)               # whole steps on its history too
+            out[bfs] = c.download()
+    # the trajectories agree to the tolerance's order of magnitude (different order of additions, same terms)
+    assert np.abs(out["0"][0].astype(np.float64) - out["1"][0]).max() <= 1e-3
