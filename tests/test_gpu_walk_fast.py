@@ -253,4 +253,5 @@ def test_lab_breadth_first_fast_walk_has_the_depth_first_lists(nb, orc, lab, mon
             c.update_tree(C.TREE_BVH, 0.1, 3)               # whole steps on its history too
             out[bfs] = c.download()
     # the trajectories agree to the tolerance's order of magnitude (different order of additions, same terms)
-    assert np.abs(out["0"][0].astype(np.float64) - out["1"][0]).max() <= 1e-3
+    by_id = {k: v[0][np.argsort(v[3])].astype(np.float64) for k, v in out.items()}   # (a last-bit difference may permute the rows)
+    assert np.abs(by_id["0"] - by_id["1"]).max() <= 1e-3
