@@ -1757,10 +1757,11 @@ hipError_t launch_tree_walk_tile_main(hipStream_t s, const WalkArgs<T>& a_in, ch
   // the occupancy: Plummer 4 M f64 205 ms against 92 (the exact walk: 124).  Laboratory: NBODY_WALK_FAST_ROWS=0/1 forces one or the other.
   static const int fast_rows_env = lab_int("NBODY_WALK_FAST_ROWS", -1);
   const bool fast_rows = fast_rows_env >= 0 ? fast_rows_env != 0 : sizeof(T) == 8;
-  // FAST: scalar loads where the walk is bound by what it issues (Plummer 1 M 3.10 -> 3.03 ms), vector loads of one address where it
-  // is bound by its longest waves' chains (reference scene 0.298 against 0.322 ms: the scalar path's round trip is the longer one)
+  // FAST: node records by scalar loads (round 3 took vector loads of one address below 400 000 targets: 0.298 against 0.322 ms on the
+  // reference scene's FIRST steps; over the bench leg's 300 steps, with the waves in one residency round, scalar loads win there too:
+  // 0.299 -> 0.277 ms, profiles/r04_walk_wave_target.txt).  Laboratory: NBODY_WALK_FAST_REC=0 / 1 the plain / pinned vector loads.
   static const int rec_env = lab_int("NBODY_WALK_FAST_REC", -1);
-  const int rec_mode = rec_env >= 0 ? rec_env : (a_in.n_tgt >= 400000 ? 3 : 0);
+  const int rec_mode = rec_env >= 0 ? rec_env : 3;
 #ifdef NBODY_LAB
   // every variant the A/B tools switch between: rows 4 / 8 / 16, node records by vector loads, the rows arm in f32, the register arm
   // in f64, the per-wave log
@@ -1805,12 +1806,11 @@ hipError_t launch_tree_walk_tile_main(hipStream_t s, const WalkArgs<T>& a_in, ch
 #else
   // the product's instantiations: the exact walk with 8 rows and scalar node records; FAST in f32 through registers (node records
   // by plain or scalar loads, by size), FAST in f64 through the rows
-  (void)srec; (void)tt; (void)fast_rows;
+  (void)srec; (void)tt; (void)fast_rows; (void)rec_mode;
   const WalkArgs<T>& a = a_in;
   if constexpr (sizeof(T) == 4) {
     if (a.fast) {
-      if (rec_mode == 3) walk_tile_fast<T, 3, false><<<grid, dim3(256), 0, s>>>(a, off, info, tgt_ids, hist, total_out);
-      else walk_tile_fast<T, 0, false><<<grid, dim3(256), 0, s>>>(a, off, info, tgt_ids, hist, total_out);
+      walk_tile_fast<T, 3, false><<<grid, dim3(256), 0, s>>>(a, off, info, tgt_ids, hist, total_out);
     } else {
       walk_tile<T, false, 8, true><<<grid, dim3(256), 0, s>>>(a, off, info, tgt_ids, hist, total_out);
     }
