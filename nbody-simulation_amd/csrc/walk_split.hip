@@ -35,8 +35,8 @@ namespace {
 // Targets per wave.  Counting is cheapest with full waves; in the term pass a wave's time grows with the number of
 // leaves its targets visit, so its waves are cut by work (see walk_pass).
 constexpr int kCountTPW = 64;
-constexpr uint32_t kTermBudget = 8192;  // terms a wave of the term pass writes, about (at least: see walk_total)
-constexpr uint32_t kBudgetTargets = 12; // ... or this many average targets' worth, if that is more
+[[maybe_unused]] constexpr uint32_t kTermBudget = 8192;  // (three-pass walk, laboratory build) terms a wave of the term pass writes, about (at least: see walk_total)
+[[maybe_unused]] constexpr uint32_t kBudgetTargets = 12; // ... or this many average targets' worth, if that is more
 constexpr uint32_t kTileBudget = 8192;        // smallest budget of a wave of the one-pass walk (walk_tile)
 // Waves the one-pass walk aims at; a wave's budget is total terms / (this - n / 64), any integer (tile_budget).  Round 4, measured
 // (profiles/r04_walk_wave_target.txt): the walk is its longest waves' chains, and they all start at once only while EVERY wave is
@@ -99,7 +99,7 @@ __device__ __forceinline__ float2 pair_term_sel(bool valid, float px, float py, 
 
 // nbody_arith FAST (opt-in, tolerance instead of bit parity): one reciprocal instead of two IEEE divisions; a zero difference
 // contributes exactly 0 through the biased denominator (direct_kernels.hip)
-__device__ __forceinline__ float2 pair_term_fast(float px, float py, float qx, float qy, float force, float clamp) {
+[[maybe_unused]] __device__ __forceinline__ float2 pair_term_fast(float px, float py, float qx, float qy, float force, float clamp) {
   const float dx = qx - px, dy = qy - py;
   const float sum = __builtin_fabsf(dx) + __builtin_fabsf(dy);
   const float d2 = __builtin_fmaxf(__builtin_fmaf(dy, dy, dx * dx), clamp);
@@ -690,14 +690,14 @@ __device__ __forceinline__ void swap_halves(float& a, float& b) {
 __device__ __forceinline__ void swap_rows(float& a, float& b) {
   asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
 }
-__device__ __forceinline__ void swap_halves(double& a, double& b) {
+[[maybe_unused]] __device__ __forceinline__ void swap_halves(double& a, double& b) {
   unsigned long long ua = __builtin_bit_cast(unsigned long long, a), ub = __builtin_bit_cast(unsigned long long, b);
   unsigned al = (unsigned)ua, ah = (unsigned)(ua >> 32), bl = (unsigned)ub, bh = (unsigned)(ub >> 32);
   asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %2\n\tv_permlane32_swap_b32 %1, %3" : "+v"(al), "+v"(ah), "+v"(bl), "+v"(bh));
   a = __builtin_bit_cast(double, ((unsigned long long)ah << 32) | al);
   b = __builtin_bit_cast(double, ((unsigned long long)bh << 32) | bl);
 }
-__device__ __forceinline__ void swap_rows(double& a, double& b) {
+[[maybe_unused]] __device__ __forceinline__ void swap_rows(double& a, double& b) {
   unsigned long long ua = __builtin_bit_cast(unsigned long long, a), ub = __builtin_bit_cast(unsigned long long, b);
   unsigned al = (unsigned)ua, ah = (unsigned)(ua >> 32), bl = (unsigned)ub, bh = (unsigned)(ub >> 32);
   asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %2\n\tv_permlane16_swap_b32 %1, %3" : "+v"(al), "+v"(ah), "+v"(bl), "+v"(bh));
@@ -787,7 +787,7 @@ __device__ __forceinline__ float fast_scale(float dx, float dy, float force, flo
   const float d2 = __builtin_fmaxf(__builtin_fmaf(dy, dy, dx * dx), clamp);
   return force * __builtin_amdgcn_rcpf(__builtin_fmaf(sum, d2, 8.0779356694631609e-28f));  // 2^-90
 }
-__device__ __forceinline__ double fast_scale(double dx, double dy, double force, double clamp) {
+[[maybe_unused]] __device__ __forceinline__ double fast_scale(double dx, double dy, double force, double clamp) {
   const double sum = __builtin_fabs(dx) + __builtin_fabs(dy);
   const double d2 = __builtin_fmax(__builtin_fma(dy, dy, dx * dx), clamp);
   const double den = __builtin_fma(sum, d2, 0x1p-700);
@@ -797,7 +797,7 @@ __device__ __forceinline__ double fast_scale(double dx, double dy, double force,
   return force * r;
 }
 __device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
-__device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
+[[maybe_unused]] __device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
 
 template <class T, int REC, bool LOG>  // REC: how the node records are fetched (0 plain loads: the compiler picks scalar loads; 1 vector loads); LOG: per-wave log (development)
 __global__ __launch_bounds__(256) void walk_tile_fast(const WalkArgs<T> a, const uint32_t* __restrict__ off, const int* __restrict__ info,
