@@ -1195,7 +1195,6 @@ __device__ __forceinline__ void fast_leaf_step(const unsigned long long mask, co
 __global__ __launch_bounds__(256) void walk_tile_fast_bfs(const WalkArgs<float> a, const uint32_t* __restrict__ off, int* __restrict__ info,
                                                           const uint32_t* __restrict__ tgt_ids, uint32_t* __restrict__ hist,
                                                           unsigned long long* __restrict__ total_out) {
-  using T = float;
   __shared__ int q_idx_all[4][kBfsQ];
   __shared__ unsigned q_lo_all[4][kBfsQ], q_hi_all[4][kBfsQ];
   __shared__ int lf_first_all[4][kBfsLeaves], lf_count_all[4][kBfsLeaves];
