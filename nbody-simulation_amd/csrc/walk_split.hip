@@ -49,7 +49,13 @@ __host__ __device__ inline int64_t tile_waves_target(int64_t n_tgt) {
   const int64_t w = n_tgt / 64 + 1024;
   return w > 6656 ? w : 6656;
 }
-constexpr int kTileRoundCost = 66;            // instructions a target costs at a leaf, lane = particle (a round + its share of the adds)
+#ifndef NB_TILE_ROUND_COST
+#define NB_TILE_ROUND_COST 66
+#endif
+#ifndef NB_FAST_ROUND_COST
+#define NB_FAST_ROUND_COST 19
+#endif
+constexpr int kTileRoundCost = NB_TILE_ROUND_COST;  // instructions a target costs at a leaf, lane = particle (a round + its share of the adds)
 constexpr int kFusedPairCost = 48;            // ... and a particle costs the wave, lane = target
 
 __device__ __forceinline__ float lane_f(float v, int k) {  // k uniform
@@ -675,7 +681,7 @@ __global__ __launch_bounds__(256) void walk_tile(const WalkArgs<T> a, const uint
 //   * where most of the wave wants the leaf the particles are broadcast instead (lane = target), as before.
 // Any order of additions is inside the tolerance (tests/_tol.py: 2e-5 of sum |term|; a tree of 64 + one add per leaf is
 // a better-conditioned sum than the reference's sequential chain).
-constexpr int kFastRoundCost = 19;  // VALU instructions a target costs at a leaf, lane = particle (round + its share of the reduction)
+constexpr int kFastRoundCost = NB_FAST_ROUND_COST;  // VALU instructions a target costs at a leaf, lane = particle (round + its share of the reduction)
 constexpr int kFastPairCost = 14;   // ... and a particle costs the wave, lane = target (three broadcasts, the pair, two FMAs)
 
 // v_permlane32_swap / v_permlane16_swap (new in gfx950) through inline asm: this compiler's __builtin_amdgcn_permlane32_swap
