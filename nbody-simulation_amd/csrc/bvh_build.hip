@@ -338,7 +338,7 @@ template <int NW> __device__ __forceinline__ unsigned group_sum(unsigned v, unsi
 }
 
 #ifdef NB_FOLD_TIMING
-__device__ unsigned long long g_fold_t[8];
+__device__ unsigned long long g_fold_t[16];
 #define NB_FT_ADD(k, v) { if (tid == 0) atomicAdd(&g_fold_t[k], (unsigned long long)(v)); }
 #else
 #define NB_FT_ADD(k, v)
@@ -929,6 +929,9 @@ __global__ __launch_bounds__(512) void bvh_big_fold(BvhPtrs a, int level, int us
       {  // the chunks' runs are merged, rm at a time, into the <= 64 runs the chain will walk (one thread per merged run)
         const int b0 = 0, nb = nrun;
         int glen = 0;
+#ifdef NB_FOLD_TIMING
+        long long tr0 = wall_clock64();
+#endif
         if (tid < nrun) {
           const int f0 = tid * rm, f1 = f0 + rm < nch ? f0 + rm : nch;
           xsum::Run A = xsum::run_none(), B = xsum::run_none();
@@ -989,6 +992,9 @@ __global__ __launch_bounds__(512) void bvh_big_fold(BvhPtrs a, int level, int us
           if (tid == 63) gap_total = inc < kGapCap ? inc : kGapCap;
         }
         __syncthreads();
+#ifdef NB_FOLD_TIMING
+        { const long long t = wall_clock64(); NB_FT_ADD(8, t - tr0) tr0 = t; }
+#endif
         {
           const float* __restrict__ X = reinterpret_cast<const float*>(P) + comp;
           const int G = gap_total;
@@ -1004,6 +1010,9 @@ __global__ __launch_bounds__(512) void bvh_big_fold(BvhPtrs a, int level, int us
           }
         }
         __syncthreads();
+#ifdef NB_FOLD_TIMING
+        { const long long t = wall_clock64(); NB_FT_ADD(9, t - tr0) NB_FT_ADD(13, gap_total) tr0 = t; }
+#endif
         int ci = b0;
         while (ci < b0 + nb) {  // ... and the chain walks through them in order
           // one wave runs ahead as long as the prepared runs hold (a few dozen instructions per chunk, no barrier) ...
@@ -1049,6 +1058,9 @@ __global__ __launch_bounds__(512) void bvh_big_fold(BvhPtrs a, int level, int us
             if (tid == 0) { sh.bad_s = xsum::f2u(sum); sh.bad = ci; }
           }
           __syncthreads();
+#ifdef NB_FOLD_TIMING
+          { const long long t = wall_clock64(); NB_FT_ADD(10, t - tr0) tr0 = t; }
+#endif
           sum = xsum::u2f(sh.bad_s);
           ci = sh.bad;
           __syncthreads();
@@ -1060,6 +1072,9 @@ __global__ __launch_bounds__(512) void bvh_big_fold(BvhPtrs a, int level, int us
             staged_fold<8, 8>(P, lo, hi, sum, comp, tid, &sh, stage, sum, dmn, dmx, stops);
             (void)rec;
             ++ci;
+#ifdef NB_FOLD_TIMING
+            { const long long t = wall_clock64(); NB_FT_ADD(11, t - tr0) NB_FT_ADD(12, 1) tr0 = t; }
+#endif
           }
         }
         __syncthreads();
@@ -2056,12 +2071,14 @@ const uint32_t* bvh_build_order(const char* scratch, const BvhBuildLayout& L) { 
 
 #ifdef NB_FOLD_TIMING
 static void bvh_debug_fold_times(hipStream_t s) {
-  unsigned long long h[8] = {};
+  unsigned long long h[16] = {};
   (void)hipStreamSynchronize(s);
   (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_fold_t), sizeof(h));
   std::fprintf(stderr, "[fold timing, 10 ns ticks] seq %llu in %llu runs; scan %llu in %llu rounds; nodes %llu ticks over %llu chains, %llu points; %llu slow rounds\n",
                h[0], h[2], h[1], h[3], h[4], h[5], h[6], h[7]);
-  unsigned long long z[8] = {};
+  if (h[8] | h[9] | h[10] | h[11])
+    std::fprintf(stderr, "    run path: merge %llu, gap fetch %llu (%llu addends), run walks %llu, scanned chunks %llu in %llu\n", h[8], h[9], h[13], h[10], h[11], h[12]);
+  unsigned long long z[16] = {};
   (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fold_t), z, sizeof(z));
 }
 #endif
