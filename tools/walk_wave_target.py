@@ -2,6 +2,7 @@
 reference scene and on Plummer spheres of three sizes, for several NBODY_WALK_TILE_WAVES (laboratory library) and the product's
 size-aware default (tile_waves_target, csrc/walk_split.hip).  python tools/walk_wave_target.py"""
 import os, sys, time
+import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("NBODY_HIP_LIBRARY", "lab")
 import nbody_simulation_amd as nb  # noqa: E402
@@ -25,11 +26,14 @@ def run(pos, vel, w, steps, arith):
 
 # python tools/walk_wave_target.py [all | ref | plummer] [W ...]   (default: all, the values below)
 which = sys.argv[1] if len(sys.argv) > 1 else "all"
+f64 = which.endswith("64")                              # "plummer64": the same spheres in f64 (walk_tile<double>)
+which = which[:-2] if f64 else which
 values = tuple(sys.argv[2:]) or ("default", "16384", "8192", "6144")
 scenes = [("reference scene", nb.scenes.galaxy(), 300)] if which in ("all", "ref") else []
 if which in ("all", "plummer"):
     for n, steps in ((262144, 100), (400000, 60), (655360, 40), (1 << 20, 20)):
-        scenes.append((f"plummer {n}", nb.scenes.plummer(n, seed=0x5EED0003), steps))
+        scenes.append((f"plummer {n}" + (" f64" if f64 else ""), nb.scenes.plummer(n, seed=0x5EED0003, dtype=np.float64 if f64 else np.float32),
+                       steps // 4 if f64 else steps))
 print(f"{'scene':<18} {'NBODY_WALK_TILE_WAVES':<22} {'exact ms/step (kernel)':<26} FAST ms/step (kernel)")
 for name, (pos, vel, w), steps in scenes:
     for waves in values:
