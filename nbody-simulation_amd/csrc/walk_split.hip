@@ -562,13 +562,9 @@ __global__ __launch_bounds__(256) void walk_tile(const WalkArgs<T> a, const uint
               if constexpr (sizeof(T) == 4) {
                 // eight terms at a time, the next eight on their way from LDS while these are added (two register sets
                 // taken in turn; left to itself the compiler reads a batch, waits, adds, and reads the next)
-                // (round 4) x and y are two independent chains in lockstep: ONE v_pk_add_f32 per term does both — each half is the plain
-                // IEEE add, so the bits are the same, and the chain of dependent instructions is half as long
-                typedef float row_v2 __attribute__((ext_vector_type(2)));
-                row_v2 acc2 = {ax, ay};
 #define NB_ROW_LOAD(dst, blk) _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) dst[j_] = r[(blk) * 8 + j_];
-#define NB_ROW_ADD(src) _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) { acc2 = acc2 + row_v2{src[j_].x, src[j_].y}; } \
-  __builtin_amdgcn_sched_group_barrier(0x100, 8, 0); __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+#define NB_ROW_ADD(src) _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) { ax = ax + src[j_].x; ay = ay + src[j_].y; } \
+  __builtin_amdgcn_sched_group_barrier(0x100, 8, 0); __builtin_amdgcn_sched_group_barrier(0x002, 16, 0);
                 T2 va[8], vb[8];
                 NB_ROW_LOAD(va, 0)
                 int j0 = 0;
@@ -585,8 +581,6 @@ __global__ __launch_bounds__(256) void walk_tile(const WalkArgs<T> a, const uint
                 } else {
                   NB_ROW_ADD(va)
                 }
-                ax = acc2.x;
-                ay = acc2.y;
 #undef NB_ROW_LOAD
 #undef NB_ROW_ADD
               } else {
