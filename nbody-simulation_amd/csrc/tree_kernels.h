@@ -65,6 +65,8 @@ template <class T> struct WalkArgs {
   int big_leaves;             // leaves hold tens of particles (BVH) rather than a handful (quad)
   const int* n_nodes_dev;     // optional (walk_tile only): the node count is read here instead — the walk was enqueued
                               // before the host saw the build's verdict; 0 there = the build failed, walk nothing
+  int block_stride;              // one-pass walks: work-group b takes the waves of group (b * block_stride) mod gridDim.x (a stride coprime with
+                                 // the grid; 1 = in order): consecutive groups hold tree-order neighbours of like weight, the stride deals them out
   unsigned long long* wave_log;  // optional (walk_tile_fast, NBODY_WALK_WAVE_LOG=1): per wave {clock ticks, node steps, leaf steps,
                                  // (target, leaf) rounds} — where the longest waves spend their time (tools/walk_wave_log.py)
 };

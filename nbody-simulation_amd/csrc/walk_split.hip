@@ -55,6 +55,10 @@ __host__ __device__ inline int64_t tile_waves_target(int64_t n_tgt) {
 #ifndef NB_FAST_ROUND_COST
 #define NB_FAST_ROUND_COST 19
 #endif
+// Which group of four waves a work-group takes (WalkArgs::block_stride).
+__device__ __forceinline__ unsigned group_of_block(unsigned b, unsigned nb, int stride) {
+  return stride > 1 ? (unsigned)(((unsigned long long)b * (unsigned)stride) % nb) : b;
+}
 constexpr int kTileRoundCost = NB_TILE_ROUND_COST;  // instructions a target costs at a leaf, lane = particle (a round + its share of the adds)
 constexpr int kFusedPairCost = 48;            // ... and a particle costs the wave, lane = target
 
@@ -467,7 +471,7 @@ __global__ __launch_bounds__(256) void walk_tile(const WalkArgs<T> a, const uint
   __shared__ T2 tile_all[4][TT * kStride];
   const int lane = threadIdx.x & 63;
   T2* __restrict__ tile = tile_all[threadIdx.x >> 6];
-  const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+  const int wave = __builtin_amdgcn_readfirstlane((int)(group_of_block(blockIdx.x, gridDim.x, a.block_stride) * 4 + (threadIdx.x >> 6)));
   if (info[1] != 0) return;  // the estimate's scan wrapped: the caller takes the fused walk
   if (wave > info[5]) return;  // past the last wave that can hold a target (most of the grid on a small scene): no searches
   // first t with g(t) >= wave, g(t) = off[t] / budget + t / 64 (see walk_pass), then the first with g(t) > wave: all on the
@@ -812,7 +816,7 @@ __global__ __launch_bounds__(256) void walk_tile_fast(const WalkArgs<T> a, const
   using T2 = typename Vec2Of<T>::type;
   using T4 = typename Vec4Of<T>::type;
   const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+  const int wave = __builtin_amdgcn_readfirstlane((int)(group_of_block(blockIdx.x, gridDim.x, a.block_stride) * 4 + (threadIdx.x >> 6)));
   if (info[1] != 0) return;  // the estimate's scan wrapped: the caller walks again without one
   if (wave > info[5]) return;  // past the last wave that can hold a target (most of the grid on a small scene): no searches
   const long long log_t0 = LOG ? wall_clock64() : 0;
@@ -1754,6 +1758,15 @@ hipError_t launch_tree_walk_tile_main(hipStream_t s, const WalkArgs<T>& a_in, ch
   unsigned long long* total_out = (unsigned long long*)(info + 6);
   const int tt = tile_targets();
   const dim3 grid((unsigned)((grid_waves + 3) / 4));
+  // laboratory: NBODY_WALK_BLOCK_STRIDE=1 deals the work-groups out with a golden-ratio stride (coprime with the grid) instead of in order
+  WalkArgs<T> a_strided = a_in;
+  a_strided.block_stride = 1;
+  if (lab_int("NBODY_WALK_BLOCK_STRIDE", 0) != 0 && grid.x > 8) {
+    auto gcd = [](unsigned x, unsigned y) { while (y) { const unsigned t = x % y; x = y; y = t; } return x; };
+    unsigned st = (unsigned)(0.6180339887 * grid.x) | 1u;
+    while (gcd(st, grid.x) != 1) st += 2;
+    a_strided.block_stride = (int)st;
+  }
   // node records by scalar loads (scalar_node_rec): the exact walk always (62 instead of 72 VGPRs: eight waves per SIMD instead of seven;
   // reference scene 0.579 -> 0.567 ms, Plummer 1 M 6.07 -> 5.96); NBODY_WALK_SCALAR_REC=0: the vector loads of one address
   static const bool srec = lab_int("NBODY_WALK_SCALAR_REC", 1) != 0;
@@ -1773,7 +1786,7 @@ hipError_t launch_tree_walk_tile_main(hipStream_t s, const WalkArgs<T>& a_in, ch
 #define NB_TILE(F, R) do { if (srec) walk_tile<T, F, R, true><<<grid, dim3(256), 0, s>>>(a, off, info, tgt_ids, hist, total_out); \
                            else walk_tile<T, F, R, false><<<grid, dim3(256), 0, s>>>(a, off, info, tgt_ids, hist, total_out); } while (0)
   unsigned long long* wave_log = nullptr;
-  WalkArgs<T> a_log = a_in;
+  WalkArgs<T> a_log = a_strided;
   if (a_in.fast && lab_int("NBODY_WALK_WAVE_LOG", 0) != 0) {  // development: per-wave time and step counts
     if (hipMalloc((void**)&wave_log, (size_t)grid.x * 4 * 4 * sizeof(unsigned long long)) != hipSuccess) return hipErrorOutOfMemory;
     (void)hipMemsetAsync(wave_log, 0, (size_t)grid.x * 4 * 4 * sizeof(unsigned long long), s);
@@ -1812,7 +1825,7 @@ hipError_t launch_tree_walk_tile_main(hipStream_t s, const WalkArgs<T>& a_in, ch
   // the product's instantiations: the exact walk with 8 rows and scalar node records; FAST in f32 through registers (node records
   // by plain or scalar loads, by size), FAST in f64 through the rows
   (void)srec; (void)tt; (void)fast_rows; (void)rec_mode;
-  const WalkArgs<T>& a = a_in;
+  const WalkArgs<T>& a = a_strided;
   if constexpr (sizeof(T) == 4) {
     if (a.fast) {
       walk_tile_fast<T, 3, false><<<grid, dim3(256), 0, s>>>(a, off, info, tgt_ids, hist, total_out);
