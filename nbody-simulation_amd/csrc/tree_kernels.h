@@ -65,6 +65,10 @@ template <class T> struct WalkArgs {
   int big_leaves;             // leaves hold tens of particles (BVH) rather than a handful (quad)
   const int* n_nodes_dev;     // optional (walk_tile only): the node count is read here instead — the walk was enqueued
                               // before the host saw the build's verdict; 0 there = the build failed, walk nothing
+  // One-pass walks on scenes whose waves do not all fit the chip at once (round 4): the work-groups are dealt out CHUNK by chunk of
+  // `order_chunk` consecutive groups, the chunks in the order `group_order` gives (heaviest first, walk_order_chunks); null: in order.
+  const int* group_order;
+  int order_chunk;
   int block_stride;              // one-pass walks: work-group b takes the waves of group (b * block_stride) mod gridDim.x (a stride coprime with
                                  // the grid; 1 = in order): consecutive groups hold tree-order neighbours of like weight, the stride deals them out
   unsigned long long* wave_log;  // optional (walk_tile_fast, NBODY_WALK_WAVE_LOG=1): per wave {clock ticks, node steps, leaf steps,

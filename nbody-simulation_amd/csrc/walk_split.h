@@ -11,7 +11,9 @@ namespace nbody {
 struct WalkSplitLayout {
   size_t cnt, off, info, cub_temp, cub_temp_bytes, total;  // bytes from the start of the scratch block
   size_t scan_state, scan_state_bytes;  // walk_scan_est_tail: a ticket and one 64-bit state per work-group (zeroed once, by the caller)
+  size_t order;                         // walk_order_chunks: the chunks of work-groups, heaviest first (kWalkOrderChunks ints)
 };
+constexpr int kWalkOrderChunks = 256;   // at most this many chunks (a chunk: at least 64 work-groups = 256 waves)
 WalkSplitLayout walk_split_layout(int64_t n_tgt);
 constexpr int64_t kWalkFusedScanMaxTargets = (int64_t)1 << 24;  // TileTail::fused_scan: at most this many targets
 

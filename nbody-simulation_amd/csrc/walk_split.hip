@@ -59,6 +59,13 @@ __host__ __device__ inline int64_t tile_waves_target(int64_t n_tgt) {
 __device__ __forceinline__ unsigned group_of_block(unsigned b, unsigned nb, int stride) {
   return stride > 1 ? (unsigned)(((unsigned long long)b * (unsigned)stride) % nb) : b;
 }
+template <class T> __device__ __forceinline__ unsigned group_of_block(const WalkArgs<T>& a, unsigned b, unsigned nb) {
+  if (a.group_order) {  // chunk by chunk, the chunks heaviest first (walk_order_chunks); inside a chunk in order (tree-order neighbours share their L2 lines)
+    const unsigned slot = b / (unsigned)a.order_chunk;
+    return (unsigned)a.group_order[slot] * (unsigned)a.order_chunk + (b - slot * (unsigned)a.order_chunk);
+  }
+  return group_of_block(b, nb, a.block_stride);
+}
 constexpr int kTileRoundCost = NB_TILE_ROUND_COST;  // instructions a target costs at a leaf, lane = particle (a round + its share of the adds)
 constexpr int kFusedPairCost = 48;            // ... and a particle costs the wave, lane = target
 
@@ -439,6 +446,22 @@ __global__ __launch_bounds__(256) void walk_sum(const WalkArgs<float> a, const u
 // integer for every wave — all that g needs.  The budget is then ANY integer (round 4: a power of two left the wave count anywhere
 // between the aim and half of it, and the walk's time follows the wave count: profiles/r04_walk_wave_target.txt).
 __device__ __forceinline__ int off_quot(uint32_t off, uint32_t M) { return (int)__umulhi(off, M); }
+// the first target t with g(t) >= wave (n_tgt if none): the whole wave calls it
+__device__ __forceinline__ int first_target_reaching(const uint32_t* __restrict__ off, const int n_tgt, const int wave, const uint32_t M, const int lane) {
+  int lo = 0, hi = n_tgt;
+  while (lo < hi) {
+    const int step = (hi - lo + 63) >> 6;
+    const int idx = lo + lane * step;
+    const bool reached = idx >= hi || off_quot(off[idx], M) + (idx >> 6) >= wave;
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(reached);
+    const int first = m ? __builtin_ctzll(m) : 64;
+    if (first == 0) { hi = lo; break; }
+    const int below = lo + (first - 1) * step;
+    if (first < 64) hi = min(hi, lo + first * step);
+    lo = below + 1;
+  }
+  return lo;
+}
 __device__ __forceinline__ void wave_targets(const uint32_t* __restrict__ off, const int n_tgt, const int wave, const uint32_t M, const int lane,
                                              int& t0, int& t1) {
   int lo = 0, hi = n_tgt;  // the first t with g(t) >= wave lies in [lo, hi] (hi = "none below hi")
@@ -471,7 +494,7 @@ __global__ __launch_bounds__(256) void walk_tile(const WalkArgs<T> a, const uint
   __shared__ T2 tile_all[4][TT * kStride];
   const int lane = threadIdx.x & 63;
   T2* __restrict__ tile = tile_all[threadIdx.x >> 6];
-  const int wave = __builtin_amdgcn_readfirstlane((int)(group_of_block(blockIdx.x, gridDim.x, a.block_stride) * 4 + (threadIdx.x >> 6)));
+  const int wave = __builtin_amdgcn_readfirstlane((int)(group_of_block(a, blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6)));
   if (info[1] != 0) return;  // the estimate's scan wrapped: the caller takes the fused walk
   if (wave > info[5]) return;  // past the last wave that can hold a target (most of the grid on a small scene): no searches
   // first t with g(t) >= wave, g(t) = off[t] / budget + t / 64 (see walk_pass), then the first with g(t) > wave: all on the
@@ -816,7 +839,7 @@ __global__ __launch_bounds__(256) void walk_tile_fast(const WalkArgs<T> a, const
   using T2 = typename Vec2Of<T>::type;
   using T4 = typename Vec4Of<T>::type;
   const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane((int)(group_of_block(blockIdx.x, gridDim.x, a.block_stride) * 4 + (threadIdx.x >> 6)));
+  const int wave = __builtin_amdgcn_readfirstlane((int)(group_of_block(a, blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6)));
   if (info[1] != 0) return;  // the estimate's scan wrapped: the caller walks again without one
   if (wave > info[5]) return;  // past the last wave that can hold a target (most of the grid on a small scene): no searches
   const long long log_t0 = LOG ? wall_clock64() : 0;
@@ -1626,6 +1649,42 @@ __global__ __launch_bounds__(256) void walk_scan_est_tail(EstimateOf est, uint32
   tile_tail_duties(total, wrapped, wrapped, est.shift, n, extra_waves, grid_waves, (int)gridDim.x, info, tail, tid);
 }
 
+// ---- which work-groups go first (round 4) --------------------------------------------------------------------------------
+// On a scene whose waves do not all fit the chip at once (Plummer 1 M: 17 400 waves on 8 192 slots) the work-groups are
+// dispatched in index order = tree order, and the dense centre's long waves (2.2 ms against a mean of 0.9) sit in the middle of
+// it: those past the first residency round start a millisecond late and end the kernel at 2.9 ms where the sum of all wave
+// times over the slots is 1.9 (profiles/r04_walk_wave_log.txt).  So the groups are dealt out longest first — in CHUNKS of
+// consecutive groups (neighbouring groups walk neighbouring targets and share their nodes and leaves in the L2s: dealing single
+// groups out costs 10-25 %), a chunk's weight being its targets' estimated terms, which the scan has left in `off`.  One
+// work-group: a wave per chunk finds the chunk's first target (the walk's own 64-ary search), then the chunks are ranked.
+__global__ __launch_bounds__(1024) void walk_order_chunks(const uint32_t* __restrict__ off, const int n_tgt, const int* __restrict__ info,
+                                                         const int chunk_groups, const int n_chunks, int* __restrict__ order) {
+  __shared__ int bnd[kWalkOrderChunks + 1];
+  __shared__ unsigned long long cost[kWalkOrderChunks];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const uint32_t M = 0xFFFFFFFFu / (uint32_t)__builtin_amdgcn_readfirstlane(info[3]);
+  for (int c = w; c < n_chunks; c += 16) {
+    const int t = first_target_reaching(off, n_tgt, c * chunk_groups * 4, M, lane);
+    if (lane == 0) bnd[c] = t;
+  }
+  if (tid == 0) bnd[n_chunks] = n_tgt;
+  __syncthreads();
+  const unsigned long long total = (unsigned long long)(unsigned)info[0];
+  if (tid < n_chunks) {
+    const int b0 = bnd[tid], b1 = bnd[tid + 1];
+    const unsigned long long o0 = b0 < n_tgt ? off[b0] : total, o1 = b1 < n_tgt ? off[b1] : total;
+    // (the estimate's terms and, so that equal estimates still order by work, the head count)
+    cost[tid] = (o1 >= o0 ? o1 - o0 : 0ull) + (unsigned long long)(b1 - b0);
+  }
+  __syncthreads();
+  if (tid < n_chunks) {
+    const unsigned long long mine = cost[tid];
+    int rank = 0;
+    for (int h = 0; h < n_chunks; ++h) rank += (cost[h] > mine || (cost[h] == mine && h < tid)) ? 1 : 0;
+    order[rank] = tid;  // (a bijection: every chunk has its own rank)
+  }
+}
+
 inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 inline uint32_t tile_budget_targets() {  // (laboratory: a wave's budget as this many average targets)
   const int v = lab_int("NBODY_WALK_TILE_BUDGET_TARGETS", 0);
@@ -1650,6 +1709,7 @@ WalkSplitLayout walk_split_layout(int64_t n_tgt) {
   L.cnt = take(4 * n);
   L.off = take(4 * n);
   L.info = take(32);
+  L.order = take(4 * (size_t)kWalkOrderChunks);
   size_t tb = 0;
   (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tb, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)n, (hipStream_t) nullptr);
   L.cub_temp_bytes = tb;
@@ -1761,6 +1821,21 @@ hipError_t launch_tree_walk_tile_main(hipStream_t s, const WalkArgs<T>& a_in, ch
   // laboratory: NBODY_WALK_BLOCK_STRIDE=1 deals the work-groups out with a golden-ratio stride (coprime with the grid) instead of in order
   WalkArgs<T> a_strided = a_in;
   a_strided.block_stride = 1;
+  a_strided.group_order = nullptr;
+  a_strided.order_chunk = 0;
+  dim3 grid_ordered = grid;
+  // more waves than the chip holds at once (256 CUs x 32): chunks of work-groups, heaviest first (walk_order_chunks)
+  if (grid_waves > 10240 && lab_int("NBODY_WALK_ORDER", 1) != 0 && lab_int("NBODY_WALK_WAVE_LOG", 0) == 0 && lab_int("NBODY_WALK_FAST_BFS", 0) == 0) {
+    const int ng = (int)grid.x;
+    int cg = (ng + kWalkOrderChunks - 1) / kWalkOrderChunks;
+    if (cg < 64) cg = 64;
+    const int nc = (ng + cg - 1) / cg;
+    int* order = (int*)(scratch + L.order);
+    walk_order_chunks<<<dim3(1), dim3(1024), 0, s>>>(off, (int)a_in.n_tgt, info, cg, nc, order);
+    a_strided.group_order = order;
+    a_strided.order_chunk = cg;
+    grid_ordered = dim3((unsigned)(nc * cg));  // (whole chunks: the groups past the last real one find no targets and leave)
+  }
   if (lab_int("NBODY_WALK_BLOCK_STRIDE", 0) != 0 && grid.x > 8) {
     auto gcd = [](unsigned x, unsigned y) { while (y) { const unsigned t = x % y; x = y; y = t; } return x; };
     unsigned st = (unsigned)(0.6180339887 * grid.x) | 1u;
@@ -1783,8 +1858,8 @@ hipError_t launch_tree_walk_tile_main(hipStream_t s, const WalkArgs<T>& a_in, ch
 #ifdef NBODY_LAB
   // every variant the A/B tools switch between: rows 4 / 8 / 16, node records by vector loads, the rows arm in f32, the register arm
   // in f64, the per-wave log
-#define NB_TILE(F, R) do { if (srec) walk_tile<T, F, R, true><<<grid, dim3(256), 0, s>>>(a, off, info, tgt_ids, hist, total_out); \
-                           else walk_tile<T, F, R, false><<<grid, dim3(256), 0, s>>>(a, off, info, tgt_ids, hist, total_out); } while (0)
+#define NB_TILE(F, R) do { if (srec) walk_tile<T, F, R, true><<<grid_ordered, dim3(256), 0, s>>>(a, off, info, tgt_ids, hist, total_out); \
+                           else walk_tile<T, F, R, false><<<grid_ordered, dim3(256), 0, s>>>(a, off, info, tgt_ids, hist, total_out); } while (0)
   unsigned long long* wave_log = nullptr;
   WalkArgs<T> a_log = a_strided;
   if (a_in.fast && lab_int("NBODY_WALK_WAVE_LOG", 0) != 0) {  // development: per-wave time and step counts
@@ -1800,10 +1875,10 @@ hipError_t launch_tree_walk_tile_main(hipStream_t s, const WalkArgs<T>& a_in, ch
   if (bfs) {
     if constexpr (sizeof(T) == 4) walk_tile_fast_bfs<<<grid, dim3(256), 0, s>>>(a, off, info, tgt_ids, hist, total_out);
   } else if (a.fast && !fast_rows) {
-    if (wave_log) walk_tile_fast<T, 0, true><<<grid, dim3(256), 0, s>>>(a, off, info, tgt_ids, hist, total_out);
-    else if (rec_mode == 1) walk_tile_fast<T, 1, false><<<grid, dim3(256), 0, s>>>(a, off, info, tgt_ids, hist, total_out);
-    else if (rec_mode == 3) walk_tile_fast<T, 3, false><<<grid, dim3(256), 0, s>>>(a, off, info, tgt_ids, hist, total_out);
-    else walk_tile_fast<T, 0, false><<<grid, dim3(256), 0, s>>>(a, off, info, tgt_ids, hist, total_out);
+    if (wave_log) walk_tile_fast<T, 0, true><<<grid_ordered, dim3(256), 0, s>>>(a, off, info, tgt_ids, hist, total_out);
+    else if (rec_mode == 1) walk_tile_fast<T, 1, false><<<grid_ordered, dim3(256), 0, s>>>(a, off, info, tgt_ids, hist, total_out);
+    else if (rec_mode == 3) walk_tile_fast<T, 3, false><<<grid_ordered, dim3(256), 0, s>>>(a, off, info, tgt_ids, hist, total_out);
+    else walk_tile_fast<T, 0, false><<<grid_ordered, dim3(256), 0, s>>>(a, off, info, tgt_ids, hist, total_out);
   }
   else if (a.fast) { if (tt == 16) NB_TILE(true, 16); else if (tt == 4) NB_TILE(true, 4); else NB_TILE(true, 8); }
   else { if (tt == 16) NB_TILE(false, 16); else if (tt == 4) NB_TILE(false, 4); else NB_TILE(false, 8); }
@@ -1828,13 +1903,13 @@ hipError_t launch_tree_walk_tile_main(hipStream_t s, const WalkArgs<T>& a_in, ch
   const WalkArgs<T>& a = a_strided;
   if constexpr (sizeof(T) == 4) {
     if (a.fast) {
-      walk_tile_fast<T, 3, false><<<grid, dim3(256), 0, s>>>(a, off, info, tgt_ids, hist, total_out);
+      walk_tile_fast<T, 3, false><<<grid_ordered, dim3(256), 0, s>>>(a, off, info, tgt_ids, hist, total_out);
     } else {
-      walk_tile<T, false, 8, true><<<grid, dim3(256), 0, s>>>(a, off, info, tgt_ids, hist, total_out);
+      walk_tile<T, false, 8, true><<<grid_ordered, dim3(256), 0, s>>>(a, off, info, tgt_ids, hist, total_out);
     }
   } else {
-    if (a.fast) walk_tile<T, true, 8, true><<<grid, dim3(256), 0, s>>>(a, off, info, tgt_ids, hist, total_out);
-    else walk_tile<T, false, 8, true><<<grid, dim3(256), 0, s>>>(a, off, info, tgt_ids, hist, total_out);
+    if (a.fast) walk_tile<T, true, 8, true><<<grid_ordered, dim3(256), 0, s>>>(a, off, info, tgt_ids, hist, total_out);
+    else walk_tile<T, false, 8, true><<<grid_ordered, dim3(256), 0, s>>>(a, off, info, tgt_ids, hist, total_out);
   }
 #endif
   return hipGetLastError();
