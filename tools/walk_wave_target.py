@@ -31,7 +31,7 @@ which = which[:-2] if f64 else which
 values = tuple(sys.argv[2:]) or ("default", "16384", "8192", "6144")
 scenes = [("reference scene", nb.scenes.galaxy(), 300)] if which in ("all", "ref") else []
 if which in ("all", "plummer"):
-    for n, steps in ((262144, 100), (400000, 60), (655360, 40), (1 << 20, 20)):
+    for n, steps in ((262144, 100), (400000, 60), (655360, 40), (1 << 20, 20)) + (((1 << 21, 12),) if os.environ.get("WALK_SWEEP_2M") else ()):
         scenes.append((f"plummer {n}" + (" f64" if f64 else ""), nb.scenes.plummer(n, seed=0x5EED0003, dtype=np.float64 if f64 else np.float32),
                        steps // 4 if f64 else steps))
 print(f"{'scene':<18} {'NBODY_WALK_TILE_WAVES':<22} {'exact ms/step (kernel)':<26} FAST ms/step (kernel)")
