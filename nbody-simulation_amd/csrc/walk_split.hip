@@ -1657,8 +1657,11 @@ __global__ __launch_bounds__(256) void walk_scan_est_tail(EstimateOf est, uint32
 // consecutive groups (neighbouring groups walk neighbouring targets and share their nodes and leaves in the L2s: dealing single
 // groups out costs 10-25 %), a chunk's weight being its targets' estimated terms, which the scan has left in `off`.  One
 // work-group: a wave per chunk finds the chunk's first target (the walk's own 64-ary search), then the chunks are ranked.
+// mode 2: all chunks heaviest first.  mode 1: the LIGHTEST chunks — as many as one residency round holds — go last, everything else stays
+// in index order: what matters is that no long wave starts late, and the rest of the order is the locality the walks live on.
 __global__ __launch_bounds__(1024) void walk_order_chunks(const uint32_t* __restrict__ off, const int n_tgt, const int* __restrict__ info,
-                                                         const int chunk_groups, const int n_chunks, int* __restrict__ order) {
+                                                         const int chunk_groups, const int n_chunks, int* __restrict__ order, const int mode,
+                                                         const int n_light) {
   __shared__ int bnd[kWalkOrderChunks + 1];
   __shared__ unsigned long long cost[kWalkOrderChunks];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -1677,11 +1680,22 @@ __global__ __launch_bounds__(1024) void walk_order_chunks(const uint32_t* __rest
     cost[tid] = (o1 >= o0 ? o1 - o0 : 0ull) + (unsigned long long)(b1 - b0);
   }
   __syncthreads();
+  __shared__ unsigned char light[kWalkOrderChunks];
+  int rank = 0;  // among all chunks, heaviest first (a bijection: every chunk has its own rank)
   if (tid < n_chunks) {
     const unsigned long long mine = cost[tid];
-    int rank = 0;
     for (int h = 0; h < n_chunks; ++h) rank += (cost[h] > mine || (cost[h] == mine && h < tid)) ? 1 : 0;
-    order[rank] = tid;  // (a bijection: every chunk has its own rank)
+    light[tid] = rank >= n_chunks - n_light ? 1 : 0;
+  }
+  __syncthreads();
+  if (tid < n_chunks) {
+    if (mode == 2) {
+      order[rank] = tid;
+    } else {
+      int before_same = 0;  // chunks of my kind before me, in index order
+      for (int h = 0; h < tid; ++h) before_same += light[h] == light[tid] ? 1 : 0;
+      order[light[tid] ? n_chunks - n_light + before_same : before_same] = tid;
+    }
   }
 }
 
@@ -1825,13 +1839,16 @@ hipError_t launch_tree_walk_tile_main(hipStream_t s, const WalkArgs<T>& a_in, ch
   a_strided.order_chunk = 0;
   dim3 grid_ordered = grid;
   // more waves than the chip holds at once (256 CUs x 32): chunks of work-groups, heaviest first (walk_order_chunks)
-  if (grid_waves > 10240 && lab_int("NBODY_WALK_ORDER", 1) != 0 && lab_int("NBODY_WALK_WAVE_LOG", 0) == 0 && lab_int("NBODY_WALK_FAST_BFS", 0) == 0) {
+  const int order_mode = lab_int("NBODY_WALK_ORDER", 1);  // laboratory: 0 in order, 2 every chunk heaviest first
+  if (grid_waves > 10240 && order_mode != 0 && lab_int("NBODY_WALK_WAVE_LOG", 0) == 0 && lab_int("NBODY_WALK_FAST_BFS", 0) == 0) {
     const int ng = (int)grid.x;
     int cg = (ng + kWalkOrderChunks - 1) / kWalkOrderChunks;
     if (cg < 64) cg = 64;
     const int nc = (ng + cg - 1) / cg;
     int* order = (int*)(scratch + L.order);
-    walk_order_chunks<<<dim3(1), dim3(1024), 0, s>>>(off, (int)a_in.n_tgt, info, cg, nc, order);
+    int n_light = 8192 / (cg * 4);  // chunks of one residency round (256 CUs x 32 waves)
+    if (n_light > nc / 2) n_light = nc / 2;
+    walk_order_chunks<<<dim3(1), dim3(1024), 0, s>>>(off, (int)a_in.n_tgt, info, cg, nc, order, order_mode, n_light);
     a_strided.group_order = order;
     a_strided.order_chunk = cg;
     grid_ordered = dim3((unsigned)(nc * cg));  // (whole chunks: the groups past the last real one find no targets and leave)
