@@ -1649,6 +1649,7 @@ __global__ __launch_bounds__(256) void walk_scan_est_tail(EstimateOf est, uint32
   tile_tail_duties(total, wrapped, wrapped, est.shift, n, extra_waves, grid_waves, (int)gridDim.x, info, tail, tid);
 }
 
+#ifdef NBODY_LAB
 // ---- which work-groups go first (round 4) --------------------------------------------------------------------------------
 // On a scene whose waves do not all fit the chip at once (Plummer 1 M: 17 400 waves on 8 192 slots) the work-groups are
 // dispatched in index order = tree order, and the dense centre's long waves (2.2 ms against a mean of 0.9) sit in the middle of
@@ -1657,6 +1658,9 @@ __global__ __launch_bounds__(256) void walk_scan_est_tail(EstimateOf est, uint32
 // consecutive groups (neighbouring groups walk neighbouring targets and share their nodes and leaves in the L2s: dealing single
 // groups out costs 10-25 %), a chunk's weight being its targets' estimated terms, which the scan has left in `off`.  One
 // work-group: a wave per chunk finds the chunk's first target (the walk's own 64-ary search), then the chunks are ranked.
+// MEASURED (profiles/r04_walk_order_ab.txt): heaviest first gains 10 % at Plummer 1 M (f32) and 6-8 % at 655 360 / 1 M in f64, and LOSES
+// 5 % at 655 360 and 4-8 % at 2 M in f32; "lightest last" gains nothing anywhere.  No rule follows from that, so the product keeps the
+// index order and this stays a laboratory switch (NBODY_WALK_ORDER=2 / 1).
 // mode 2: all chunks heaviest first.  mode 1: the LIGHTEST chunks — as many as one residency round holds — go last, everything else stays
 // in index order: what matters is that no long wave starts late, and the rest of the order is the locality the walks live on.
 __global__ __launch_bounds__(1024) void walk_order_chunks(const uint32_t* __restrict__ off, const int n_tgt, const int* __restrict__ info,
@@ -1698,6 +1702,7 @@ __global__ __launch_bounds__(1024) void walk_order_chunks(const uint32_t* __rest
     }
   }
 }
+#endif  // NBODY_LAB (walk_order_chunks)
 
 inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 inline uint32_t tile_budget_targets() {  // (laboratory: a wave's budget as this many average targets)
@@ -1838,8 +1843,9 @@ hipError_t launch_tree_walk_tile_main(hipStream_t s, const WalkArgs<T>& a_in, ch
   a_strided.group_order = nullptr;
   a_strided.order_chunk = 0;
   dim3 grid_ordered = grid;
-  // more waves than the chip holds at once (256 CUs x 32): chunks of work-groups, heaviest first (walk_order_chunks)
-  const int order_mode = lab_int("NBODY_WALK_ORDER", 1);  // laboratory: 0 in order, 2 every chunk heaviest first
+  // laboratory: more waves than the chip holds at once (256 CUs x 32): chunks of work-groups, heaviest first (walk_order_chunks)
+#ifdef NBODY_LAB
+  const int order_mode = lab_int("NBODY_WALK_ORDER", 0);  // laboratory: 2 every chunk heaviest first, 1 the lightest chunks last
   if (grid_waves > 10240 && order_mode != 0 && lab_int("NBODY_WALK_WAVE_LOG", 0) == 0 && lab_int("NBODY_WALK_FAST_BFS", 0) == 0) {
     const int ng = (int)grid.x;
     int cg = (ng + kWalkOrderChunks - 1) / kWalkOrderChunks;
@@ -1853,6 +1859,7 @@ hipError_t launch_tree_walk_tile_main(hipStream_t s, const WalkArgs<T>& a_in, ch
     a_strided.order_chunk = cg;
     grid_ordered = dim3((unsigned)(nc * cg));  // (whole chunks: the groups past the last real one find no targets and leave)
   }
+#endif
   if (lab_int("NBODY_WALK_BLOCK_STRIDE", 0) != 0 && grid.x > 8) {
     auto gcd = [](unsigned x, unsigned y) { while (y) { const unsigned t = x % y; x = y; y = t; } return x; };
     unsigned st = (unsigned)(0.6180339887 * grid.x) | 1u;
