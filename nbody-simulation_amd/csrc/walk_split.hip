@@ -447,7 +447,7 @@ __global__ __launch_bounds__(256) void walk_sum(const WalkArgs<float> a, const u
 // between the aim and half of it, and the walk's time follows the wave count: profiles/r04_walk_wave_target.txt).
 __device__ __forceinline__ int off_quot(uint32_t off, uint32_t M) { return (int)__umulhi(off, M); }
 // the first target t with g(t) >= wave (n_tgt if none): the whole wave calls it
-__device__ __forceinline__ int first_target_reaching(const uint32_t* __restrict__ off, const int n_tgt, const int wave, const uint32_t M, const int lane) {
+[[maybe_unused]] __device__ __forceinline__ int first_target_reaching(const uint32_t* __restrict__ off, const int n_tgt, const int wave, const uint32_t M, const int lane) {
   int lo = 0, hi = n_tgt;
   while (lo < hi) {
     const int step = (hi - lo + 63) >> 6;
