@@ -220,6 +220,30 @@ int nbody_host_tree_export_f32(const nbody_host_tree* t, float* geom, uint32_t* 
 int nbody_host_tree_export_f64(const nbody_host_tree* t, double* geom, uint32_t* mass, int32_t* is_leaf,
                                int64_t* leaf_first, int64_t* leaf_count, int64_t* skip, uint32_t* order);
 
+/* The force map alone (main.rs:406-416) over a CALLER'S tree: for a host that keeps its own builder (BVHTree::from +
+ * calculate_gravity, bvh_tree.rs:56-158) and hands over only the walk -- SURVEY 8b's nbody_walk_tree.  The tree comes in the
+ * layout nbody_tree_export_* writes (pre-order; node i's first child is i + 1; skip[i] the pre-order index after i's subtree;
+ * geom BVH [n_nodes][6] = off_x off_y size_x size_y cog_x cog_y, quad [n_nodes][5] = off_x off_y height cog_x cog_y;
+ * leaf_first / leaf_count for EVERY node: an inner node's range is its children's ranges one after the other), over the
+ * particles uploaded to the context: order[n] = the current row of each tree-ordered particle (the permutation the host's
+ * in-place partition made).  The rows are brought into tree order as a build would leave them (BVH) and the tree becomes
+ * the context's current tree (nbody_tree_export_* returns it).  target_xy NULL: the particles themselves, acc_xy[2*n] in the
+ * context's row order after the call (BVH: tree order, the rows having been permuted; quad: the rows stay where they were).
+ * The shape is validated before anything reaches the device (nbody_tree_validate: forward skip links, nested subtrees,
+ * two children per BVH root / one to four per quad root, ranges inside the particles, `order` a permutation):
+ * NBODY_ERR_INVALID with the reason in nbody_last_error.  Geometry and masses are taken as they are. */
+int nbody_walk_tree_f32(nbody_ctx* ctx, int tree_kind, int64_t n_nodes, const float* geom, const uint32_t* mass,
+                        const int32_t* is_leaf, const int64_t* leaf_first, const int64_t* leaf_count, const int64_t* skip,
+                        const uint32_t* order, int64_t n_targets, const float* target_xy, float* acc_xy);
+int nbody_walk_tree_f64(nbody_ctx* ctx, int tree_kind, int64_t n_nodes, const double* geom, const uint32_t* mass,
+                        const int32_t* is_leaf, const int64_t* leaf_first, const int64_t* leaf_count, const int64_t* skip,
+                        const uint32_t* order, int64_t n_targets, const double* target_xy, double* acc_xy);
+/* The shape check of nbody_walk_tree_* on its own (host only, no device): NBODY_OK or NBODY_ERR_INVALID with the first
+ * violation written to reason[reason_cap] (may be NULL). */
+int nbody_tree_validate(int tree_kind, int64_t n_nodes, const int32_t* is_leaf, const int64_t* leaf_first,
+                        const int64_t* leaf_count, const int64_t* skip, int64_t n_particles, const uint32_t* order,
+                        char* reason, size_t reason_cap);
+
 /* Walk statistics of the most recent tree walk made while collection was enabled (node visits, accepted nodes,
  * leaf pairs, summed over targets).  `enable` != 0 turns collection on for later walks (it costs three atomics
  * per target), 0 turns it off.  Used to price the walk's algorithmic bytes. */

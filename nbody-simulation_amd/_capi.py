@@ -82,6 +82,9 @@ _SIGS = {
     "nbody_accel_tree_f32": (C.c_int, [_vp, _i32, _i64, _vp, _vp]),
     "nbody_accel_tree_f64": (C.c_int, [_vp, _i32, _i64, _vp, _vp]),
     "nbody_tree_info": (C.c_int, [_vp, C.POINTER(TreeView)]),
+    "nbody_walk_tree_f32": (C.c_int, [_vp, _i32, _i64] + [_vp] * 7 + [_i64, _vp, _vp]),
+    "nbody_walk_tree_f64": (C.c_int, [_vp, _i32, _i64] + [_vp] * 7 + [_i64, _vp, _vp]),
+    "nbody_tree_validate": (C.c_int, [_i32, _i64] + [_vp] * 4 + [_i64, _vp, C.c_char_p, _sz]),
     "nbody_tree_export_f32": (C.c_int, [_vp] + [_vp] * 7),
     "nbody_tree_export_f64": (C.c_int, [_vp] + [_vp] * 7),
     "nbody_host_tree_build_f32": (C.c_int, [_i32, _i64, _vp, _vp, C.POINTER(Params), C.POINTER(_vp)]),
@@ -383,6 +386,24 @@ def host_tree(kind, pos, weight=None, params: "Params | None" = None):
         lib.nbody_host_tree_free(h)
 
 
+def _tree_arrays(tree, dt):
+    return dict(geom=np.ascontiguousarray(tree["geom"], dtype=dt), mass=np.ascontiguousarray(tree["mass"], dtype=np.uint32),
+                is_leaf=np.ascontiguousarray(tree["is_leaf"], dtype=np.int32), first=np.ascontiguousarray(tree["first"], dtype=np.int64),
+                count=np.ascontiguousarray(tree["count"], dtype=np.int64), skip=np.ascontiguousarray(tree["skip"], dtype=np.int64),
+                order=np.ascontiguousarray(tree["order"], dtype=np.uint32))
+
+
+def tree_validate(tree, n_particles=None):
+    """The shape check nbody_walk_tree_* applies to a caller's tree, on the host alone -> (ok, reason)."""
+    lib = load()
+    a = _tree_arrays(tree, np.float32)
+    n = a["order"].shape[0] if n_particles is None else int(n_particles)
+    buf = C.create_string_buffer(256)
+    rc = lib.nbody_tree_validate(int(tree["kind"]), a["skip"].shape[0], _ptr(a["is_leaf"]), _ptr(a["first"]), _ptr(a["count"]),
+                                 _ptr(a["skip"]), n, _ptr(a["order"]), buf, 256)
+    return rc == OK, buf.value.decode()
+
+
 class Context:
     """Owner of one nbody_ctx (one GPU)."""
 
@@ -513,6 +534,24 @@ class Context:
         tg = np.ascontiguousarray(targets, dtype=dt).reshape(-1, 2)
         acc = np.zeros_like(tg)
         check(self.h, f(self.h, int(kind), tg.shape[0], _ptr(tg), _ptr(acc)))
+        return acc
+
+    def walk_tree(self, tree, targets=None):
+        """The force map alone over a caller's linearised tree (nbody_walk_tree_*): `tree` is a dict in tree_export()'s /
+        host_tree()'s layout (geom, mass, is_leaf, first, count, skip, order, kind) over the uploaded particles.
+        targets None: the particles themselves, in the row order after the call (BVH: tree order; quad: unchanged)."""
+        dt = self.dtype
+        f = self.lib.nbody_walk_tree_f64 if dt == np.float64 else self.lib.nbody_walk_tree_f32
+        a = _tree_arrays(tree, dt)
+        if targets is None:
+            tg, nt = None, 0
+            acc = np.zeros((self.n, 2), dt)
+        else:
+            tg = np.ascontiguousarray(targets, dtype=dt).reshape(-1, 2)
+            nt = tg.shape[0]
+            acc = np.zeros_like(tg)
+        check(self.h, f(self.h, int(tree["kind"]), a["geom"].shape[0], _ptr(a["geom"]), _ptr(a["mass"]), _ptr(a["is_leaf"]),
+                        _ptr(a["first"]), _ptr(a["count"]), _ptr(a["skip"]), _ptr(a["order"]), nt, _ptr(tg), _ptr(acc)))
         return acc
 
     def snapshot_begin(self):

@@ -952,51 +952,22 @@ int phase_drain(nbody_ctx* c) {
   return NBODY_OK;
 }
 
-// Phase 1 of update (main.rs:398-401): snapshot + build + upward pass.  After it, for the BVH, set[cur] holds the
-// permuted particles and set[1-cur].pos the pre-build snapshot (`cloned`); for the quad tree set[1-cur].pos/.mass
-// hold the leaf-ordered copies the leaves own.
-template <class T> int tree_build_phase(nbody_ctx* c, State<T>& s, int kind) {
-  using T2 = typename State<T>::T2;
-  if (kind != NBODY_TREE_BVH && kind != NBODY_TREE_QUAD) return fail(c, NBODY_ERR_INVALID, "unknown tree kind");
+// The host's mirror of the weights, in the current row order.
+template <class T> int refresh_host_weights(nbody_ctx* c, State<T>& s) {
+  if (!s.h_weight_stale) return NBODY_OK;
   const int64_t n = s.n;
-  s.tree_valid = false;
-  s.tree_host_stale = false;
-  c->last_build_device = true;
-  c->bvh_stops = 0;
-  if (kind == NBODY_TREE_QUAD && n > 0 && env_int("NBODY_TREE_BUILD_HOST", 0) == 0) {
-    int rc = quad_build_device<T>(c, s);
-    if (rc != 1) return rc;  // 1 = the device build declined (too deep for its key / sizes): host builder below
-  }
-  if (kind == NBODY_TREE_BVH && n > 0 && c->params.leaf_size >= 1 && env_int("NBODY_TREE_BUILD_HOST", 0) == 0) {
-    int rc = bvh_build_device<T>(c, s);
-    if (rc != 1) return rc;
-  }
-  c->last_build_device = false;
-  if (s.h_weight_stale) {  // the host builder reads the weights in the current row order
-    s.h_weight.resize((size_t)n);
-    if (n) HIPCHK(c, hipMemcpyAsync(s.h_weight.data(), s.set[s.cur].weight, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    s.h_weight_stale = false;
-  }
-  const bool trace = env_int("NBODY_TRACE", 0) != 0;
-  double tt0 = now_s();
-  s.h_pos.resize((size_t)(2 * n));
-  if (n) {
-    HIPCHK(c, hipMemcpyAsync(s.h_pos.data(), s.set[s.cur].pos, (size_t)n * sizeof(T2), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-  }
-  double tt1 = now_s();
-  if (kind == NBODY_TREE_BVH) {
-    if (c->params.leaf_size < 1) return fail(c, NBODY_ERR_INVALID, "leaf_size must be >= 1");
-    build_bvh<T>(s.h_pos.data(), s.h_weight.data(), n, c->params.leaf_size, s.tree);
-  } else {
-    build_quad<T>(s.h_pos.data(), s.h_weight.data(), n, (T)c->params.quad_root_x, (T)c->params.quad_root_y,
-                  (T)c->params.quad_root_h, s.tree);
-  }
-  double tt2 = now_s();
-  if (trace) std::fprintf(stderr, "[nbody] host tree build: D2H %.3f ms, build %.3f ms (%zu nodes)\n", 1e3 * (tt1 - tt0), 1e3 * (tt2 - tt1), s.tree.size());
-  if (s.tree.overflow)
-    return fail(c, NBODY_ERR_DEGENERATE, "tree build exceeded the depth cap (more coincident points than a leaf holds)");
+  s.h_weight.resize((size_t)n);
+  if (n) HIPCHK(c, hipMemcpyAsync(s.h_weight.data(), s.set[s.cur].weight, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  s.h_weight_stale = false;
+  return NBODY_OK;
+}
+
+// A linearised tree in s.tree (the host builders', or a caller's: walk_tree) becomes the tree the walks use: its records go
+// to the device and the rows into its order, as the in-place partition leaves `self.particles` (bvh_tree.rs:73-77); for the
+// quad tree the leaf-ordered copies.  s.h_weight must be current (refresh_host_weights).
+template <class T> int install_host_tree(nbody_ctx* c, State<T>& s, int kind) {
+  const int64_t n = s.n;
   s.n_nodes = (int)s.tree.size();
   s.tree_kind = s.tree.kind;
   s.tree_max_depth = s.tree.max_depth;
@@ -1026,6 +997,51 @@ template <class T> int tree_build_phase(nbody_ctx* c, State<T>& s, int kind) {
   }
   s.tree_valid = true;
   return NBODY_OK;
+}
+
+
+// Phase 1 of update (main.rs:398-401): snapshot + build + upward pass.  After it, for the BVH, set[cur] holds the
+// permuted particles and set[1-cur].pos the pre-build snapshot (`cloned`); for the quad tree set[1-cur].pos/.mass
+// hold the leaf-ordered copies the leaves own.
+template <class T> int tree_build_phase(nbody_ctx* c, State<T>& s, int kind) {
+  using T2 = typename State<T>::T2;
+  if (kind != NBODY_TREE_BVH && kind != NBODY_TREE_QUAD) return fail(c, NBODY_ERR_INVALID, "unknown tree kind");
+  const int64_t n = s.n;
+  s.tree_valid = false;
+  s.tree_host_stale = false;
+  c->last_build_device = true;
+  c->bvh_stops = 0;
+  if (kind == NBODY_TREE_QUAD && n > 0 && env_int("NBODY_TREE_BUILD_HOST", 0) == 0) {
+    int rc = quad_build_device<T>(c, s);
+    if (rc != 1) return rc;  // 1 = the device build declined (too deep for its key / sizes): host builder below
+  }
+  if (kind == NBODY_TREE_BVH && n > 0 && c->params.leaf_size >= 1 && env_int("NBODY_TREE_BUILD_HOST", 0) == 0) {
+    int rc = bvh_build_device<T>(c, s);
+    if (rc != 1) return rc;
+  }
+  c->last_build_device = false;
+  int rcw = refresh_host_weights<T>(c, s);  // the host builder reads the weights in the current row order
+  if (rcw) return rcw;
+  const bool trace = env_int("NBODY_TRACE", 0) != 0;
+  double tt0 = now_s();
+  s.h_pos.resize((size_t)(2 * n));
+  if (n) {
+    HIPCHK(c, hipMemcpyAsync(s.h_pos.data(), s.set[s.cur].pos, (size_t)n * sizeof(T2), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  double tt1 = now_s();
+  if (kind == NBODY_TREE_BVH) {
+    if (c->params.leaf_size < 1) return fail(c, NBODY_ERR_INVALID, "leaf_size must be >= 1");
+    build_bvh<T>(s.h_pos.data(), s.h_weight.data(), n, c->params.leaf_size, s.tree);
+  } else {
+    build_quad<T>(s.h_pos.data(), s.h_weight.data(), n, (T)c->params.quad_root_x, (T)c->params.quad_root_y,
+                  (T)c->params.quad_root_h, s.tree);
+  }
+  double tt2 = now_s();
+  if (trace) std::fprintf(stderr, "[nbody] host tree build: D2H %.3f ms, build %.3f ms (%zu nodes)\n", 1e3 * (tt1 - tt0), 1e3 * (tt2 - tt1), s.tree.size());
+  if (s.tree.overflow)
+    return fail(c, NBODY_ERR_DEGENERATE, "tree build exceeded the depth cap (more coincident points than a leaf holds)");
+  return install_host_tree<T>(c, s, kind);
 }
 
 // Phase 2 (main.rs:406-416).  tgt_pos == nullptr: the particles themselves.
@@ -1517,15 +1533,21 @@ template <class T> int import_rows_api(nbody_ctx* c, int64_t n_rows, const void*
   return NBODY_OK;
 }
 
+template <class T> int accel_built_tree(nbody_ctx* c, State<T>& s, int kind, int64_t n_targets, const T* target_xy, T* acc_xy);
 template <class T> int accel_tree(nbody_ctx* c, int kind, int64_t n_targets, const T* target_xy, T* acc_xy) {
   if (!c) return NBODY_ERR_INVALID;
   if (!has_state<T>(c)) return fail(c, NBODY_ERR_INVALID, "accel_tree: no particles of this precision uploaded");
   if (!acc_xy) return fail(c, NBODY_ERR_INVALID, "accel_tree: acc_xy is NULL");
-  using T2 = typename State<T>::T2;
   HIPCHK(c, hipSetDevice(c->device));
   State<T>& s = state_of<T>(c);
   int rc = tree_build_phase<T>(c, s, kind);
   if (rc) return rc;
+  return accel_built_tree<T>(c, s, kind, n_targets, target_xy, acc_xy);
+}
+// ... the walk alone, over the tree that is installed (the library's build or a caller's tree)
+template <class T> int accel_built_tree(nbody_ctx* c, State<T>& s, int kind, int64_t n_targets, const T* target_xy, T* acc_xy) {
+  using T2 = typename State<T>::T2;
+  int rc = NBODY_OK;
   if (!target_xy) {
     // particles themselves, post-build row order, regardless of params.order
     const void* tp = s.set[s.cur].pos;
@@ -1555,6 +1577,120 @@ template <class T> int accel_tree(nbody_ctx* c, int kind, int64_t n_targets, con
   (void)hipFree(tp);
   (void)hipFree(ta);
   return rc;
+}
+
+// ---- a caller's tree (the force map alone, main.rs:406-416, for a host that keeps bvh_tree.rs:56-158) --------
+// What the walks rely on and a foreign tree has to prove before it reaches the device: every skip link points forward (the
+// walk's node index only ever grows: it ends), subtrees nest, an inner node's children are i + 1, skip[i + 1], ... and its range is
+// their ranges one after the other (the walks take the range of an inner node whose children are two leaves in one step),
+// leaves are single nodes, every range lies inside the particles, `order` is a permutation.  BVH: two children (BVHTree::Root,
+// bvh_tree.rs:28); quad: one to four (quad_tree.rs:47-50).  The geometry and the masses are only ever operands.
+bool tree_shape_ok(int kind, int64_t m, const int32_t* is_leaf, const int64_t* first, const int64_t* count, const int64_t* skip,
+                   int64_t n, const uint32_t* order, int* max_depth, std::string& why) {
+  auto bad = [&](int64_t i, const char* what) {
+    why = "node " + std::to_string(i) + ": " + what;
+    return false;
+  };
+  if (kind != NBODY_TREE_BVH && kind != NBODY_TREE_QUAD) { why = "unknown tree kind"; return false; }
+  if (m < 1 || m > (int64_t)INT32_MAX - 1) { why = "n_nodes out of range"; return false; }
+  if (n < 0 || n > (int64_t)INT32_MAX - 64) { why = "particle count out of range"; return false; }
+  if (!is_leaf || !first || !count || !skip || (n > 0 && !order)) { why = "a tree array is NULL"; return false; }
+  const int max_kids = kind == NBODY_TREE_BVH ? 2 : 4, min_kids = kind == NBODY_TREE_BVH ? 2 : 1;
+  struct Open { int64_t id, end, cursor; int kids; };
+  std::vector<Open> open;
+  int deepest = 0;
+  auto close = [&](const Open& o) {
+    if (o.cursor != first[o.id] + count[o.id]) return bad(o.id, "its range is not its children's ranges one after the other");
+    if (o.kids < min_kids || o.kids > max_kids) return bad(o.id, kind == NBODY_TREE_BVH ? "a BVH root has two children" : "a quad root has one to four children");
+    return true;
+  };
+  for (int64_t i = 0; i < m; ++i) {
+    while (!open.empty() && open.back().end == i) {
+      if (!close(open.back())) return false;
+      open.pop_back();
+    }
+    if (i > 0 && open.empty()) return bad(i, "lies outside the root's subtree (skip[0] must be n_nodes)");
+    if (skip[i] <= i || skip[i] > m) return bad(i, "skip does not point forward inside the tree");
+    if (first[i] < 0 || count[i] < 0 || first[i] > n || count[i] > n - first[i]) return bad(i, "range outside the particles");
+    if (!open.empty()) {
+      Open& parent = open.back();
+      if (skip[i] > parent.end) return bad(i, "subtree reaches past its parent's");
+      if (first[i] != parent.cursor) return bad(i, "range does not follow its sibling's");
+      parent.cursor += count[i];
+      ++parent.kids;
+    }
+    if (is_leaf[i]) {
+      if (skip[i] != i + 1) return bad(i, "a leaf with nodes below it");
+    } else {
+      if (skip[i] == i + 1) return bad(i, "a root without children");
+      open.push_back({i, skip[i], first[i], 0});
+      if ((int)open.size() > deepest) deepest = (int)open.size();
+    }
+  }
+  while (!open.empty()) {
+    if (open.back().end != m) return bad(open.back().id, "subtree ends past the last node");
+    if (!close(open.back())) return false;
+    open.pop_back();
+  }
+  if (skip[0] != m) return bad(0, "skip[0] must be n_nodes");
+  if (first[0] != 0 || count[0] != n) return bad(0, "the root's range must be every particle");
+  std::vector<bool> seen((size_t)n, false);
+  for (int64_t k = 0; k < n; ++k) {
+    if (order[k] >= (uint64_t)n || seen[order[k]]) { why = "order is not a permutation of the rows"; return false; }
+    seen[order[k]] = true;
+  }
+  if (max_depth) *max_depth = deepest;
+  return true;
+}
+
+template <class T>
+int walk_tree(nbody_ctx* c, int kind, int64_t m, const T* geom, const uint32_t* mass, const int32_t* is_leaf, const int64_t* first,
+              const int64_t* count, const int64_t* skip, const uint32_t* order, int64_t n_targets, const T* target_xy, T* acc_xy) {
+  if (!c) return NBODY_ERR_INVALID;
+  if (!has_state<T>(c)) return fail(c, NBODY_ERR_INVALID, "walk_tree: no particles of this precision uploaded");
+  if (!geom || !mass) return fail(c, NBODY_ERR_INVALID, "walk_tree: geom or mass is NULL");
+  if (!acc_xy) return fail(c, NBODY_ERR_INVALID, "walk_tree: acc_xy is NULL");
+  if (target_xy && n_targets < 0) return fail(c, NBODY_ERR_INVALID, "walk_tree: n_targets < 0");
+  State<T>& s = state_of<T>(c);
+  std::string why;
+  int depth = 0;
+  if (!tree_shape_ok(kind, m, is_leaf, first, count, skip, s.n, order, &depth, why)) return fail(c, NBODY_ERR_INVALID, "walk_tree: " + why);
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc = refresh_host_weights<T>(c, s);
+  if (rc) return rc;
+  s.tree_valid = false;
+  s.tree_host_stale = false;
+  c->last_build_device = false;
+  c->bvh_stops = 0;
+  TreeHost<T>& t = s.tree;
+  t.clear();
+  t.kind = kind;
+  t.max_depth = depth;
+  t.geom0.resize((size_t)m); t.geom1.resize((size_t)m); t.link.resize((size_t)m);
+  t.size_x.resize((size_t)m); t.size_y.resize((size_t)m); t.mass_u32.resize((size_t)m);
+  for (int64_t i = 0; i < m; ++i) {
+    const size_t k = (size_t)i;
+    if (kind == NBODY_TREE_BVH) {
+      const T* g = geom + 6 * k;
+      const T w = g[2], h = g[3];
+      const T tx = sse_max(w, h), ty = sse_max(h, w);  // size.max(size.yx()), main.rs:371 (as build_bvh and bvh_emit)
+      t.geom0[k] = {g[0], g[1], g[0] + w, g[1] + h};
+      t.geom1[k] = {g[4], g[5], (T)mass[k], tx * ty};
+      t.size_x[k] = w; t.size_y[k] = h;
+    } else {
+      const T* g = geom + 5 * k;
+      const T h = g[2];
+      t.geom0[k] = {g[0], g[1], g[0] + h, g[1] + h};
+      t.geom1[k] = {g[3], g[4], (T)mass[k], h * h};
+      t.size_x[k] = h; t.size_y[k] = h;
+    }
+    t.mass_u32[k] = mass[k];
+    t.link[k] = {(int32_t)skip[k], (int32_t)first[k], (int32_t)count[k], is_leaf[k] ? 1 : 0};
+  }
+  t.order.assign(order, order + s.n);
+  rc = install_host_tree<T>(c, s, kind);
+  if (rc) return rc;
+  return accel_built_tree<T>(c, s, kind, n_targets, target_xy, acc_xy);
 }
 
 template <class T>
@@ -2160,6 +2296,29 @@ NB_API int nbody_accel_tree_f32(nbody_ctx* c, int kind, int64_t n_targets, const
 NB_API int nbody_accel_tree_f64(nbody_ctx* c, int kind, int64_t n_targets, const double* target_xy, double* acc_xy) {
   NB_VIA_PRIMARY(c, true, accel_tree<double>(p, kind, n_targets, target_xy, acc_xy));
   return accel_tree<double>(c, kind, n_targets, target_xy, acc_xy);
+}
+NB_API int nbody_walk_tree_f32(nbody_ctx* c, int kind, int64_t n_nodes, const float* geom, const uint32_t* mass, const int32_t* is_leaf,
+                               const int64_t* leaf_first, const int64_t* leaf_count, const int64_t* skip, const uint32_t* order,
+                               int64_t n_targets, const float* target_xy, float* acc_xy) {
+  NB_VIA_PRIMARY(c, true, walk_tree<float>(p, kind, n_nodes, geom, mass, is_leaf, leaf_first, leaf_count, skip, order, n_targets, target_xy, acc_xy));
+  return walk_tree<float>(c, kind, n_nodes, geom, mass, is_leaf, leaf_first, leaf_count, skip, order, n_targets, target_xy, acc_xy);
+}
+NB_API int nbody_walk_tree_f64(nbody_ctx* c, int kind, int64_t n_nodes, const double* geom, const uint32_t* mass, const int32_t* is_leaf,
+                               const int64_t* leaf_first, const int64_t* leaf_count, const int64_t* skip, const uint32_t* order,
+                               int64_t n_targets, const double* target_xy, double* acc_xy) {
+  NB_VIA_PRIMARY(c, true, walk_tree<double>(p, kind, n_nodes, geom, mass, is_leaf, leaf_first, leaf_count, skip, order, n_targets, target_xy, acc_xy));
+  return walk_tree<double>(c, kind, n_nodes, geom, mass, is_leaf, leaf_first, leaf_count, skip, order, n_targets, target_xy, acc_xy);
+}
+NB_API int nbody_tree_validate(int kind, int64_t n_nodes, const int32_t* is_leaf, const int64_t* leaf_first, const int64_t* leaf_count,
+                               const int64_t* skip, int64_t n_particles, const uint32_t* order, char* reason, size_t reason_cap) {
+  std::string why;
+  const bool ok = tree_shape_ok(kind, n_nodes, is_leaf, leaf_first, leaf_count, skip, n_particles, order, nullptr, why);
+  if (reason && reason_cap) {
+    const size_t k = why.size() < reason_cap - 1 ? why.size() : reason_cap - 1;
+    std::memcpy(reason, why.data(), k);
+    reason[k] = 0;
+  }
+  return ok ? NBODY_OK : NBODY_ERR_INVALID;
 }
 
 NB_API int nbody_tree_info(const nbody_ctx* c, nbody_tree_view* out) {
