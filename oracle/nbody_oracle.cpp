@@ -273,6 +273,27 @@ QuadHandle<T>* quad_create(size_t n, const T* pos, const uint32_t* w, T rx, T ry
   quad_flatten(*h->tree, 0, 0u, 0ull, h->flat, h->order);
   return h;
 }
+// The life of a tree that is kept from step to step, which is what empty() and prune() are for (quad_tree.rs:66-137; nothing
+// upstream calls them): empty it, insert the points where they are now, the upward pass, prune.  counts[0] = empty()'s return,
+// counts[1] = prune()'s.  The cells of such a tree are NOT a fresh build's: a root stays a root however few points it still
+// holds (the TODO at :91-93).
+template <class T>
+void quad_reuse(QuadHandle<T>* h, size_t n, const T* pos, const uint32_t* w, uint32_t* counts) {
+  h->ps = to_aos<T>(n, pos, nullptr, w);
+  const uint32_t emptied = quad_empty(*h->tree);
+  BuildLimits lim;
+  for (size_t i = 0; i < h->ps.size(); ++i) {
+    QPoint<T> q{h->ps[i].position, h->ps[i].weight, h->ps[i].id};
+    quad_insert(*h->tree, q, lim, 0);
+  }
+  h->overflow = lim.overflow;
+  quad_calculate_gravity(*h->tree);
+  const uint32_t pruned = quad_prune(*h->tree);
+  h->flat.clear();
+  h->order.clear();
+  quad_flatten(*h->tree, 0, 0u, 0ull, h->flat, h->order);
+  if (counts) { counts[0] = emptied; counts[1] = pruned; }
+}
 template <class T>
 void quad_walk(QuadHandle<T>* h, size_t n_tgt, const T* tgt, T theta, T clamp, int nthreads, T* acc, uint64_t* stats) {
   if (stats) {
@@ -382,6 +403,10 @@ ORC_API void orc_pair_f64(double p1x, double p1y, double p2x, double p2y, double
     return quad_create<T>((size_t)n, pos, w, rx, ry, rh);                                                           \
   }                                                                                                                 \
   ORC_API void orc_quad_free_##SFX(void* h) { delete (QuadHandle<T>*)h; }                                           \
+  ORC_API void orc_quad_reuse_##SFX(void* h, int64_t n, const T* pos, const uint32_t* w, uint32_t* counts) {        \
+    quad_reuse<T>((QuadHandle<T>*)h, (size_t)n, pos, w, counts);                                                    \
+  }                                                                                                                 \
+  ORC_API uint32_t orc_quad_empty_##SFX(void* h) { return quad_empty<T>(*((QuadHandle<T>*)h)->tree); }              \
   ORC_API int64_t orc_quad_num_nodes_##SFX(void* h) { return (int64_t)((QuadHandle<T>*)h)->flat.size(); }           \
   ORC_API int orc_quad_overflow_##SFX(void* h) { return ((QuadHandle<T>*)h)->overflow; }                            \
   ORC_API void orc_quad_export_##SFX(void* hv, T* geom /*[n][5]*/, uint32_t* mass, int32_t* is_leaf,                \

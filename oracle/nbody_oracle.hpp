@@ -366,6 +366,47 @@ template <class T> void quad_calculate_gravity(QuadNode<T>& n) {  // :229-270
   n.total_mass = mass;
 }
 
+// quad_tree.rs:66-89: the tree keeps its cells and loses its points.  Returns the cells visited, the one it was called on
+// included; a root whose mass is already 0 counts as one and is not entered (:77-79).  Centres of gravity are left as they were.
+template <class T> uint32_t quad_empty(QuadNode<T>& n) {
+  if (n.is_leaf) {
+    n.count = 0;  // (children.iter_mut().for_each(|child| *child = None): the slots past `count` are never read)
+    return 1;
+  }
+  if (n.total_mass == 0) return 1;
+  n.total_mass = 0;
+  uint32_t sum = 0;
+  for (auto& c : n.children)
+    if (c) sum += quad_empty(*c);
+  return sum + 1;
+}
+// quad_tree.rs:94-137 ("Must be ran after calculate_gravity"): children that are empty leaves or roots without mass are
+// dropped and their flag bit flipped; roots with mass are entered.  Returns the children dropped (a dropped root counts once,
+// whatever hung below it).
+template <class T> uint32_t quad_prune(QuadNode<T>& n) {
+  uint32_t sum = 0;
+  if (n.is_leaf) return sum;
+  for (int i = 0; i < 4; ++i) {
+    bool child_empty = false;
+    if (n.children[i]) {
+      QuadNode<T>& inner = *n.children[i];
+      if (inner.is_leaf) {
+        if (inner.count == 0) child_empty = true;
+      } else if (inner.total_mass == 0) {
+        child_empty = true;
+      } else {
+        sum += quad_prune(inner);
+      }
+    }
+    if (child_empty) {
+      n.children[i].reset();
+      n.flags ^= (uint8_t)(1 << i);
+      sum += 1;
+    }
+  }
+  return sum;
+}
+
 // No walker exists upstream.  Defined here by analogy with main.rs:348-386:
 // leaf -> every stored point in slot order; root -> accept iff !contains && height2 < d2*theta*theta,
 // else children in index order 0..3.

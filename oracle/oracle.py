@@ -347,6 +347,26 @@ class Quad:
            _p(skip, C.c_int64), _p(order, C.c_uint32))
         return FlatQuad(geom, mass, is_leaf, depth, code, path, first, count, skip, order, bool(fo(self.h)))
 
+    def reuse(self, pos, weight=None):
+        """The kept tree's next step (quad_tree.rs:66-137; no caller upstream): empty(), the points inserted where they are
+        now, calculate_gravity(), prune() -> (empty()'s return, prune()'s return).  flat() / walk() then see the kept tree."""
+        pos = _prep(pos, self.nt)
+        self.n = pos.shape[0]
+        w = None if weight is None else np.ascontiguousarray(weight, dtype=np.uint32)
+        counts = np.zeros(2, np.uint32)
+        f = getattr(self._L, f"orc_quad_reuse_{self.sfx}")
+        f.restype = None
+        f.argtypes = [C.c_void_p, C.c_int64, C.POINTER(self.ct), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        f(self.h, self.n, _p(pos, self.ct), _p(w, C.c_uint32), _p(counts, C.c_uint32))
+        return int(counts[0]), int(counts[1])
+
+    def empty(self):
+        """QuadTree::empty alone (quad_tree.rs:66-89) -> the cells visited.  (flat() is stale until reuse().)"""
+        f = getattr(self._L, f"orc_quad_empty_{self.sfx}")
+        f.restype = C.c_uint32
+        f.argtypes = [C.c_void_p]
+        return int(f(self.h))
+
     def walk(self, targets, theta=50.0, clamp=0.001, nthreads=1, stats=False):
         ct = self.ct
         tg = _prep(targets, self.nt)

@@ -253,6 +253,58 @@ class PyQuad:
             node["cog"] = (T(bx / T(mass)), T(by / T(mass)))
         node["mass"] = mass
 
+    def empty(self, node=None):
+        """quad_tree.rs:66-89 -> cells visited (a root whose mass is 0 already counts as one and is not entered)."""
+        node = self.root if node is None else node
+        if node["leaf"]:
+            node["pts"] = []
+            return 1
+        if node["mass"] == 0:
+            return 1
+        node["mass"] = 0
+        return 1 + sum(self.empty(k) for k in node["kids"] if k is not None)
+
+    def prune(self, node=None):
+        """quad_tree.rs:94-137 -> children dropped (empty leaves, roots without mass); roots with mass are entered."""
+        node = self.root if node is None else node
+        dropped = 0
+        if node["leaf"]:
+            return dropped
+        for i, k in enumerate(node["kids"]):
+            if k is None:
+                continue
+            if k["leaf"]:
+                gone = len(k["pts"]) == 0
+            elif k["mass"] == 0:
+                gone = True
+            else:
+                gone = False
+                dropped += self.prune(k)
+            if gone:
+                node["kids"][i] = None
+                dropped += 1
+        return dropped
+
+    def reuse(self, pos, weight):
+        """empty(), the points where they are now, the upward pass, prune() -> (empty()'s return, prune()'s return)."""
+        T = self.T
+        emptied = self.empty()
+        for i, (p, w) in enumerate(zip(pos, weight)):
+            self._insert(self.root, (T(p[0]), T(p[1]), int(w), i))
+        self._upward(self.root)
+        return emptied, self.prune()
+
+    def cells(self, node=None, path=()):
+        """The tree's shape: every cell as (path of child codes, is a leaf, ids of its points)."""
+        node = self.root if node is None else node
+        if node["leaf"]:
+            return [(path, True, tuple(q[3] for q in node["pts"]))]
+        out = [(path, False, ())]
+        for c, k in enumerate(node["kids"]):
+            if k is not None:
+                out += self.cells(k, path + (c,))
+        return out
+
     def walk(self, p, theta, clamp=0.001):
         T = self.T
         acc = [T(0), T(0)]

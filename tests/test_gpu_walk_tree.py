@@ -129,3 +129,27 @@ def test_fast_arithmetic_over_a_callers_tree_keeps_the_tolerance(nb, orc, ctx):
     ref64, norm = h.walk_ref(f.pos_perm, theta=50.0, nthreads=8)
     check_fast(acc, ref64, np.maximum(norm, 1e-300), label=" caller's tree, FAST")
     ctx.set_params(arith=C.ARITH_AUTO)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_a_kept_quad_tree_is_walked_as_the_host_keeps_it(nb, orc, ctx, dtype):
+    """QuadTree::empty / prune (quad_tree.rs:66-137) keep a tree from step to step, and its cells are then not a fresh build's
+    (a root stays a root however few points it holds).  The library rebuilds every step and has no such tree of its own: a
+    host that keeps one hands it to nbody_walk_tree_* and gets ITS tree's interaction lists."""
+    C = nb._capi
+    n = 20000
+    pos, vel, _ = nb.scenes.plummer(n, seed=64)
+    pos, vel = pos.astype(dtype), vel.astype(dtype)
+    w = (np.arange(n) % 3 + 1).astype(np.uint32)
+    q = orc.Quad(pos, w)
+    fresh_nodes = len(q.flat().skip)
+    rng = np.random.default_rng(23)
+    moved = (pos * 0.5 + 25000.0 + rng.standard_normal(pos.shape) * 50.0).astype(dtype)   # the cloud shrinks: its old cells thin out
+    q.reuse(moved, w)
+    f = q.flat()
+    assert len(f.skip) != len(orc.Quad(moved, w).flat().skip) and fresh_nodes > 0
+    tree = dict(geom=f.geom, mass=f.mass, is_leaf=f.is_leaf, first=f.first, count=f.count, skip=f.skip, order=f.order, kind=C.TREE_QUAD)
+    ctx.set_params(theta=0.5, arith=C.ARITH_AUTO)
+    ctx.upload(moved, vel, w)
+    assert np.array_equal(ctx.walk_tree(tree), q.walk(moved, theta=0.5, nthreads=8))
+    assert not np.array_equal(ctx.accel_tree(C.TREE_QUAD), q.walk(moved, theta=0.5, nthreads=8))   # the library's own (fresh) tree differs

@@ -465,3 +465,82 @@ def test_draw_matches_independent_python_loop(orc, dtype):
     want = npr.draw(pos, vel, w, 100_000, 1250)
     assert np.array_equal(got, want)
     assert np.array_equal(orc.draw(pos, vel, w, 100_000, 100), npr.draw(pos, vel, w, 100_000, 100))
+
+
+# ---------------------------------------------------------------- QuadTree::empty / prune  (quad_tree.rs:66-137)
+def _quad_cells(flat):
+    """The oracle's flat quad tree as PyQuad.cells() lists a tree: (path of child codes, is a leaf, ids of its points)."""
+    out = []
+    for i in range(len(flat.skip)):
+        d = int(flat.depth[i])
+        path = tuple((int(flat.path[i]) >> (2 * (d - 1 - k))) & 3 for k in range(d))
+        ids = tuple(int(x) for x in flat.order[flat.first[i]:flat.first[i] + flat.count[i]]) if flat.is_leaf[i] else ()
+        out.append((path, bool(flat.is_leaf[i]), ids))
+    return out
+
+
+def test_quad_empty_and_prune_known_answers(orc):
+    """Root cell (0, 0, 100).  Eight points in the lower-left quarter and one in the upper-right: the ninth insert subdivides
+    the root into two leaves (child codes 0 and 3)."""
+    ll = np.array([[5 + 5 * k, 10 + 3 * k] for k in range(8)], F32)          # x, y < 50: child 0
+    pos = np.vstack([ll, [[80, 90]]]).astype(F32)                            # child 3
+    w = np.ones(9, np.uint32)
+    q = orc.Quad(pos, w, root=(0.0, 0.0, 100.0))
+    f = q.flat()
+    assert list(f.is_leaf) == [0, 1, 1] and list(f.child_code) == [0, 0, 3] and list(f.count) == [9, 8, 1]
+    assert q.empty() == 3                  # the root and its two leaves (:66-89)
+    assert q.empty() == 1                  # a root without mass is not entered (:77-79)
+    # the same points again: the kept cells take them back, nothing to prune
+    assert q.reuse(pos, w) == (1, 0)       # (empty() found the root still without mass: one cell)
+    assert _quad_cells(q.flat()) == _quad_cells(f)
+    # the ninth point joins the others: child 0 is full and subdivides, child 3 is an empty leaf and is pruned
+    moved = pos.copy()
+    moved[8] = (12.0, 40.0)
+    emptied, pruned = q.reuse(moved, w)
+    assert emptied == 3 and pruned == 1
+    g = q.flat()
+    assert g.is_leaf[0] == 0 and g.is_leaf[1] == 0 and g.mass[0] == 9 and g.mass[1] == 9
+    assert 3 not in list(g.child_code[g.depth == 1])           # the flag bit of the pruned child is flipped: no cell 3 any more
+    # everything moves to the upper right: child 0, a ROOT by now, ends without mass and is dropped as one child (:118-124)
+    ur = (pos * F32(0.2) + F32(70.0)).astype(F32)
+    emptied, pruned = q.reuse(ur, w)
+    assert pruned == 1 and emptied == len(g.skip)
+    k = q.flat()
+    assert list(k.child_code[k.depth == 1]) == [3] and k.mass[0] == 9
+    # a fresh build over the same points has fewer cells where the kept tree stays subdivided, never more points per leaf
+    assert len(orc.Quad(ur, w, root=(0.0, 0.0, 100.0)).flat().skip) <= len(k.skip)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_kept_quad_tree_agrees_with_python_restatement(orc, nb, dtype):
+    """Three steps of a tree that is kept (empty, insert, calculate_gravity, prune): the counts the two calls return, every
+    cell with its points in order, and the walk, against the independent Python reading of quad_tree.rs:66-137."""
+    n = 700
+    pos, _, _ = nb.scenes.plummer(n, seed=104, dtype=dtype)
+    w = (np.arange(n) % 4 + 1).astype(np.uint32)
+    py = npr.PyQuad(pos, w, dtype=dtype)
+    q = orc.Quad(pos, w)
+    rng = np.random.default_rng(17)
+    for step in range(3):
+        pos = (pos + rng.standard_normal(pos.shape) * (300.0 * (step + 1))).astype(dtype)
+        if step == 2:
+            pos[: n // 2] = (pos[: n // 2] * 0.25 + 60000.0).astype(dtype)      # half of the points leave their cells for one corner
+        assert q.reuse(pos, w) == py.reuse(pos, w)
+        assert _quad_cells(q.flat()) == py.cells()
+        tg = pos[::29]
+        got = np.array([py.walk(p, 0.5) for p in tg], dtype=dtype)
+        assert np.array_equal(got, q.walk(tg, theta=0.5))
+
+
+def test_kept_quad_tree_over_unmoved_points_is_the_fresh_build(orc, nb):
+    n = 3000
+    pos, _, _ = nb.scenes.plummer(n, seed=105)
+    w = np.ones(n, np.uint32)
+    q = orc.Quad(pos, w)
+    f = q.flat()
+    emptied, pruned = q.reuse(pos, w)
+    assert emptied == len(f.skip) and pruned == 0
+    g = q.flat()
+    for k in ("mass", "is_leaf", "first", "count", "skip", "order", "path"):
+        assert np.array_equal(getattr(f, k), getattr(g, k)), k
+    assert np.array_equal(f.geom, g.geom, equal_nan=True)
