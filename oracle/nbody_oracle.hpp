@@ -8,7 +8,7 @@
 // exists in this image, so this restatement could not be checked against the reference's own
 // outputs.  It is pinned only by hand-derived known-answer tests (tests/test_oracle_kat.py) and by a second,
 // independently written reading of the same reference text in Python (tests/_np_restatement.py: force law, BVH
-// build + upward pass + walk, quad insert + upward pass + walk) that agrees with this file bit for bit.
+// build + upward pass + walk, quad insert + upward pass + walk + empty / prune) that agrees with this file bit for bit.
 //
 // Third-party arithmetic that is NOT under /root/reference and is restated from the crates'
 // published behaviour (Cargo.lock pins):
