@@ -1,4 +1,4 @@
-"""world_size-2 (and 4) test of the target sharding + per-step position all-gather, on CPU with gloo.
+"""world_size-2 (and 3, 4, 8: the node the driver scales to) test of the target sharding + per-step position all-gather, on CPU with gloo.
 
 The compute engine injected here is the CPU oracle (test infrastructure); what is under test is
 nbody_simulation_amd/sharding.py: block partition, replicated sources, in-place velocity ownership and the
@@ -75,7 +75,7 @@ def _worker(rank, world, port, n, steps, ret, chunks=0):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n,chunks", [(2, 512, 0), (4, 512, 0), (2, 700, 3), (4, 333, 2), (3, 50, 1)])
+@pytest.mark.parametrize("world,n,chunks", [(2, 512, 0), (4, 512, 0), (2, 700, 3), (4, 333, 2), (3, 50, 1), (8, 1000, 2)])
 def test_sharded_steps_equal_single_rank(world, n, chunks, orc, nb):
     """Block layout {c*G + r}, ragged sizes (short and empty blocks) and several chunks per step included."""
     steps = 3
