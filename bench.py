@@ -31,6 +31,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# one rank per GPU shares device buffers between processes (RCCL): the host driver of this pool supports dmabuf IPC only.  Set before
+# anything initialises HIP; a value the launcher exported wins.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 N_BODIES = 1 << 20          # BASELINE.json configs[2]
 FLOPS_PER_PAIR = 14         # SURVEY §8d / DESIGN.md: algorithmic flops of one force-law evaluation
