@@ -851,3 +851,22 @@ def test_f64_walks_take_theta_as_the_f32_parameter_it_is(nb, orc, ctx):
     quad = orc.Quad(pos, w)
     assert np.array_equal(acc, quad.walk(pos, theta=0.7, nthreads=16))
     ctx.set_params(theta=50.0, order=C.ORDER_AS_WRITTEN)
+
+
+def test_two_hundred_reference_scene_steps_equal_the_oracle(nb, orc):
+    """The reference's own workload end to end (World::new's scene, 151 405 bodies, BVH, theta 50, dt 0.1, as written:
+    main.rs:276-425), 200 steps in four calls on the default path — device builds, the one-pass walk cut by the previous walk's term
+    counts, steps enqueued ahead of the host — against the oracle's World::update: rows, velocities, weights and the permutation bit
+    for bit after every call.  (tools/soak_ref_scene.py is the same over thousands of steps: profiles/r04_soak_ref_scene_bvh.txt.)"""
+    C = nb._capi
+    pos, vel, w = nb.scenes.galaxy()
+    o_pos, o_vel, o_w, o_ids = pos, vel, w, np.arange(pos.shape[0], dtype=np.uint32)
+    with C.Context(0) as c:
+        c.upload(pos, vel, w)
+        for k in (1, 49, 50, 100):
+            c.update_tree(C.TREE_BVH, 0.1, k)
+            o_pos, o_vel, o_w, o_ids, _ = orc.update_bvh(o_pos, o_vel, o_w, nsteps=k, nthreads=16, ids=o_ids)
+            p, v, w2, ids = c.download()
+            assert np.array_equal(ids, o_ids) and np.array_equal(w2, o_w)
+            assert np.array_equal(p.view(np.uint32), o_pos.view(np.uint32)) and np.array_equal(v.view(np.uint32), o_vel.view(np.uint32))
+            assert c.last_build_on_device()
