@@ -852,6 +852,7 @@ __global__ __launch_bounds__(256) void walk_tile_fast(const WalkArgs<T> a, const
   const int n_tgt = (int)a.n_tgt;  // (the scan, hence the walk, is 32 bits wide)
   int t0, lo;
   wave_targets(off, n_tgt, wave, qmul, lane, t0, lo);
+  const long long log_t1 = LOG ? wall_clock64() : 0;  // the search is over (its ballots waited for its loads)
   if (lo == t0) return;
   const int64_t t = (int64_t)t0 + lane;
   const bool live = t < lo;
@@ -1067,10 +1068,16 @@ __global__ __launch_bounds__(256) void walk_tile_fast(const WalkArgs<T> a, const
     }
     return __builtin_amdgcn_readfirstlane(next);
   };
+  long long log_t2 = 0;
   while (i < n_nodes) {
     const Rec r = fetch(i);
+    if (LOG && i == 0) {
+      asm volatile("" : : "s"(r.l.x), "v"(p.x));  // the root's record and the targets have arrived
+      log_t2 = wall_clock64();
+    }
     i = step(r, i);
   }
+  const long long log_t3 = LOG ? wall_clock64() : 0;  // the walk is over: what follows is the wave's epilogue
   ax = ax + bx;
   ay = ay + by;
   if (live) {
@@ -1084,8 +1091,8 @@ __global__ __launch_bounds__(256) void walk_tile_fast(const WalkArgs<T> a, const
   if (LOG && lane == 0) {
     unsigned long long* o = a.wave_log + 4 * wave;
     o[0] = (((unsigned long long)log_t0 & 0xFFFFFFFFFFull) << 24) | ((unsigned long long)(wall_clock64() - log_t0) & 0xFFFFFFull);  // start (absolute, 40 bits) | duration
-    o[1] = log_nodes;
-    o[2] = log_leaves;
+    o[1] = (unsigned long long)log_nodes | ((unsigned long long)((log_t1 - log_t0) & 0xFFFF) << 32) | ((unsigned long long)((log_t2 - log_t0) & 0xFFFF) << 48);  // + ticks to the end of the search | to the first record
+    o[2] = (unsigned long long)log_leaves | ((unsigned long long)((wall_clock64() - log_t3) & 0xFFFF) << 32);  // + ticks of the epilogue
     o[3] = ((unsigned long long)(unsigned)(lo - t0) << 32) | log_rounds;
   }
 }

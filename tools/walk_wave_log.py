@@ -25,23 +25,28 @@ with C.Context(0) as ctx:
 log = np.fromfile("/tmp/nbody_wave_log.bin", dtype=np.uint64).reshape(-1, 4)
 start = (log[:, 0] >> np.uint64(24)).astype(np.int64)
 us = (log[:, 0] & np.uint64(0xFFFFFF)) * 0.01
-nodes, leaves = log[:, 1].astype(np.int64), log[:, 2].astype(np.int64)
+nodes, leaves = (log[:, 1] & np.uint64(0xFFFFFFFF)).astype(np.int64), (log[:, 2] & np.uint64(0xFFFFFFFF)).astype(np.int64)
+t_search = ((log[:, 1] >> np.uint64(32)) & np.uint64(0xFFFF)) * 0.01    # us from the wave's start to the end of its target search
+t_first = ((log[:, 1] >> np.uint64(48)) & np.uint64(0xFFFF)) * 0.01     # ... to the arrival of the root's record and the targets
+t_tail = ((log[:, 2] >> np.uint64(32)) & np.uint64(0xFFFF)) * 0.01      # us of the epilogue (history, total, the log itself)
 targets, rounds = (log[:, 3] >> np.uint64(32)).astype(np.int64), (log[:, 3] & np.uint64(0xFFFFFFFF)).astype(np.int64)
 live = targets > 0
 print(f"{scene} after {warm} steps, NBODY_WALK_TILE_WAVES={os.environ.get('NBODY_WALK_TILE_WAVES', 'default')}: walk kernel {ms:.3f} ms (with the log's overhead); {live.sum()} of {len(us)} waves have targets")
 print(f"per live wave: {us[live].mean():.1f} us mean, {np.percentile(us[live], 99):.1f} p99, {us[live].max():.1f} max; steps {nodes[live].mean():.0f} node + "
       f"{leaves[live].mean():.0f} leaf, {rounds[live].mean():.0f} rounds, {targets[live].mean():.1f} targets")
+print(f"a wave's fixed part: search {t_search[live].mean():.1f} us mean ({np.percentile(t_search[live], 99):.1f} p99), root record and targets there after "
+      f"{t_first[live].mean():.1f} us ({np.percentile(t_first[live], 99):.1f} p99), epilogue {t_tail[live].mean():.1f} us")
 steps = nodes + leaves
 ok = live & (steps > 0)
 print(f"us per step (node + leaf): mean {(us[ok] / steps[ok]).mean():.2f}; sum of wave times {us[live].sum() / 1e3:.1f} ms")
 A = np.stack([nodes[ok], leaves[ok], rounds[ok], np.ones(ok.sum())], axis=1).astype(np.float64)
 coef, *_ = np.linalg.lstsq(A, us[ok], rcond=None)
 print("least squares: %.3f us per node step + %.3f us per leaf step + %.3f us per round + %.1f us per wave" % tuple(coef))
-t_first = start[live].min()
+t_begin = start[live].min()
 end = start + (us * 100).astype(np.int64)
-print(f"waves start between 0 and {(start[live].max() - t_first) * 0.01:.1f} us after the first; the last one ends at {(end[live].max() - t_first) * 0.01:.1f} us")
+print(f"waves start between 0 and {(start[live].max() - t_begin) * 0.01:.1f} us after the first; the last one ends at {(end[live].max() - t_begin) * 0.01:.1f} us")
 for k in np.argsort(-end * live)[:5]:
-    print(f"  ends last: wave {k}: starts at {(start[k] - t_first) * 0.01:.1f} us, runs {us[k]:.1f} us, {targets[k]} targets, {nodes[k]} node steps, {leaves[k]} leaf steps")
+    print(f"  ends last: wave {k}: starts at {(start[k] - t_begin) * 0.01:.1f} us, runs {us[k]:.1f} us, {targets[k]} targets, {nodes[k]} node steps, {leaves[k]} leaf steps")
 h = np.histogram(us[live], bins=[0, 25, 50, 75, 100, 125, 150, 175, 200, 250, 300, 400, 1000])[0]
 print("waves by run time (us) <25 <50 <75 <100 <125 <150 <175 <200 <250 <300 <400 more:", " ".join(str(x) for x in h))
 big = live & (targets >= 48)
