@@ -153,3 +153,41 @@ def test_a_kept_quad_tree_is_walked_as_the_host_keeps_it(nb, orc, ctx, dtype):
     ctx.upload(moved, vel, w)
     assert np.array_equal(ctx.walk_tree(tree), q.walk(moved, theta=0.5, nthreads=8))
     assert not np.array_equal(ctx.accel_tree(C.TREE_QUAD), q.walk(moved, theta=0.5, nthreads=8))   # the library's own (fresh) tree differs
+
+
+@pytest.mark.parametrize("n", [1, 2, 64, 65])
+def test_the_smallest_trees_walk_too(nb, orc, ctx, n):
+    """BVHTree::from always makes a Root (main.rs:400 calls it unconditionally), so even one body comes as a root with two
+    leaves, one of them empty (offset MAX, size -MAX, NaN centre of gravity: bvh_tree.rs:40-54)."""
+    C = nb._capi
+    pos = np.array([[10.0 + 3 * k, 20.0 + 7 * (k % 5)] for k in range(n)], F32)
+    vel = np.zeros_like(pos)
+    w = np.arange(1, n + 1, dtype=np.uint32)
+    h, tree = _oracle_tree(nb, orc, C.TREE_BVH, pos, w)
+    ok, why = C.tree_validate(tree, n)
+    assert ok, why
+    ctx.set_params(theta=0.5, leaf_size=64, arith=C.ARITH_AUTO)
+    ctx.upload(pos, vel, w)
+    tg = np.array([[0.0, 0.0], [11.0, 21.0], [1e4, -3.0]], F32)
+    assert np.array_equal(ctx.walk_tree(tree, tg), h.walk(tg, theta=0.5))
+
+
+def test_a_callers_tree_behind_a_sharded_handle(nb, orc):
+    """The same call on a context that fronts several devices (here: the one device three times, peer copies): the first
+    replica walks, the others are brought up to its rows, and the steps that follow equal the plain context's."""
+    C = nb._capi
+    n = 20000
+    pos, vel, _ = nb.scenes.plummer(n, seed=65)
+    w = (np.arange(n) % 5 + 1).astype(np.uint32)
+    h, tree = _oracle_tree(nb, orc, C.TREE_BVH, pos, w)
+    want = h.walk(pos[::5], theta=0.5, nthreads=8)
+    prm = dict(theta=0.5, leaf_size=64, arith=C.ARITH_AUTO)
+    with C.Context(0) as s, C.MultiContext([0, 0, 0], C.EXCHANGE_PEER, 2) as m:
+        for c in (s, m):
+            c.set_params(**prm)
+            c.upload(pos, vel, w)
+            assert np.array_equal(c.walk_tree(tree, pos[::5]), want)
+            c.update_tree(C.TREE_BVH, 0.1, 2)
+            c.update_direct(0.1, 1)
+        for x, y in zip(s.download(), m.download()):
+            assert np.array_equal(x, y)
