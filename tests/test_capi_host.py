@@ -376,3 +376,49 @@ def test_chunked_exact_sum_reproduces_the_sequential_chain(nb, chunk):
         assert _bits(got) == _bits(want) or (np.isnan(got) and np.isnan(want)), (name, got, want)
         if name == "uniform151405" and chunk == 2048:
             assert used >= 70      # every chunk but the first, and both halves of the chunks a power of two falls into
+
+
+def test_header_is_c99_and_a_c_program_links_the_library(tmp_path):
+    """The boundary is a C ABI: the header compiles as pedantic C99 and as C++17, and a plain C caller — what a Rust `extern "C"`
+    block amounts to — links the product library and runs its host-only entry points (no device is touched)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    inc, libdir = os.path.join(root, "include"), os.path.join(root, "nbody-simulation_amd", "lib")
+    src = tmp_path / "caller.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include <string.h>
+#include "nbody_hip.h"
+int main(void) {
+  nbody_params p;
+  if (nbody_abi_version() < 2 || nbody_default_params(&p) != NBODY_OK) return 1;
+  if (p.theta != 50.0f || p.clamp != 0.001f || p.leaf_size != 64) return 2;       /* main.rs:35, :247-248, bvh_tree.rs:37 */
+  /* a root with two leaves over three particles ... */
+  int32_t is_leaf[3] = {0, 1, 1};
+  int64_t first[3] = {0, 0, 2}, count[3] = {3, 2, 1}, skip[3] = {3, 2, 3};
+  uint32_t order[3] = {2, 0, 1};
+  char why[128];
+  if (nbody_tree_validate(NBODY_TREE_BVH, 3, is_leaf, first, count, skip, 3, order, why, sizeof why) != NBODY_OK) return 3;
+  skip[1] = 1;                                                                     /* ... and with a skip link that points at itself */
+  if (nbody_tree_validate(NBODY_TREE_BVH, 3, is_leaf, first, count, skip, 3, order, why, sizeof why) != NBODY_ERR_INVALID) return 4;
+  if (!strstr(why, "skip")) return 5;
+  /* the host builder needs no device either (bvh_tree.rs:56-96 is host code upstream) */
+  float pos[8] = {1, 1, 2, 5, 7, 3, 9, 9};
+  uint32_t w[4] = {1, 2, 3, 4};
+  nbody_host_tree* t = NULL;
+  nbody_tree_view v;
+  if (nbody_host_tree_build_f32(NBODY_TREE_BVH, 4, pos, w, NULL, &t) != NBODY_OK || nbody_host_tree_info(t, &v) != NBODY_OK) return 6;
+  if (v.n_nodes != 3 || v.kind != NBODY_TREE_BVH) return 7;
+  nbody_host_tree_free(t);
+  puts("ok");
+  return 0;
+}
+''')
+    subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", inc, "-fsyntax-only", str(src)], check=True)
+    hdr_cc = tmp_path / "hdr.cc"
+    hdr_cc.write_text('#include "nbody_hip.h"\nint main() { return 0; }\n')
+    subprocess.run(["g++", "-std=c++17", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", inc, "-fsyntax-only", str(hdr_cc)], check=True)
+    exe = tmp_path / "caller"
+    subprocess.run(["gcc", "-std=c99", "-I", inc, str(src), "-o", str(exe), "-L", libdir, "-lnbody_hip", f"-Wl,-rpath,{libdir}"], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.strip() == "ok", (out.returncode, out.stdout, out.stderr)
