@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 namespace nbody {
+template <class T> struct GatherArgs;  // tree_kernels.h
 
 constexpr int kBvhLevels = 64;    // level counters kept on the device
 constexpr int kBvhKeyDepth = 56;  // deepest level the device build follows; deeper (degenerate input) -> host builder
@@ -50,7 +51,9 @@ hipError_t bvh_build_levels(hipStream_t s, int n, int leaf_size, int level_begin
 hipError_t bvh_build_finish(hipStream_t s, const uint32_t* weight, int n, int leaf_size, int sub_start, char* scratch,
                             const BvhBuildLayout& L,
                             uint32_t* order_out, void* geom0, void* geom1, void* link, int* depth_out, uint32_t* mass_out,
-                            float2* size_out);
+                            float2* size_out, const GatherArgs<float>* gather = nullptr);
+// gather: the row gather of the step (tree_kernels.h; perm = bvh_build_order, perm_copy = where the caller wants the permutation)
+// done by the numbering's launch instead of one of its own.
 // The permutation where the build leaves it (n words inside `scratch`): with order_out == nullptr bvh_build_finish does not
 // copy it out, the caller's gather reads it here.
 const uint32_t* bvh_build_order(const char* scratch, const BvhBuildLayout& L);

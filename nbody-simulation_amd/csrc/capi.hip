@@ -706,10 +706,9 @@ template <class T> int bvh_build_device(nbody_ctx* c, State<T>& s) {
     if (lv_end > kBvhKeyDepth + 1) lv_end = kBvhKeyDepth + 1;
     int hostf[kBvhFlagWords + kBvhLevels];
     auto tail = [&](int sub_start) -> int {
-      HIPCHK(c, bvh_build_finish(c->stream, in.weight, n, leaf, sub_start, s.bb_scratch, L, s.order_dev, s.geom0, s.geom1, s.link,
-                                 s.node_depth, s.node_mass, s.node_size));
       GatherArgs<T> g{};  // rows into tree order, as the in-place partition leaves `self.particles` (bvh_tree.rs:73-77)
-      g.perm = s.order_dev;
+      g.perm = bvh_build_order(s.bb_scratch, L);  // read where the build left it, and copied out on the way
+      g.perm_copy = s.order_dev;
       g.n = n;
       g.pos_in = in.pos; g.pos_out = out.pos;
       g.weight_in = in.weight;
@@ -717,7 +716,8 @@ template <class T> int bvh_build_device(nbody_ctx* c, State<T>& s) {
       g.vel_in = in.vel; g.vel_out = out.vel;
       g.weight_out = out.weight;
       g.ids_in = in.ids; g.ids_out = out.ids;
-      HIPCHK(c, launch_gather<T>(c->stream, g));
+      HIPCHK(c, bvh_build_finish(c->stream, in.weight, n, leaf, sub_start, s.bb_scratch, L, nullptr, s.geom0, s.geom1, s.link,
+                                 s.node_depth, s.node_mass, s.node_size, &g));  // (numbering and row gather in one launch)
       return NBODY_OK;
     };
     auto ask = [&]() -> int {
@@ -1288,8 +1288,6 @@ template <class T> int bvh_step_ahead(nbody_ctx* c, State<T>& s, T delta, PhaseE
     s.bb_flags_clean = false;
     HIPCHK(c, bvh_build_begin(c->stream, in.pos, n, s.bb_scratch, L, flags_clean, stamp, stamp_prev_end));
     if (lv_end > 0) HIPCHK(c, bvh_build_levels(c->stream, n, leaf, 0, lv_end, s.bb_scratch, L));
-    HIPCHK(c, bvh_build_finish(c->stream, in.weight, n, leaf, 0, s.bb_scratch, L, nullptr, s.geom0, s.geom1, s.link, s.node_depth,
-                               s.node_mass, s.node_size));
     int* walk_info = (int*)(s.ws_scratch + WL.info);
     GatherArgs<T> g{};
     g.perm = bvh_build_order(s.bb_scratch, L);  // read where the build left it, and copied out on the way
@@ -1302,7 +1300,9 @@ template <class T> int bvh_step_ahead(nbody_ctx* c, State<T>& s, T delta, PhaseE
     g.vel_in = in.vel; g.vel_out = out.vel;
     g.weight_out = out.weight;
     g.ids_in = in.ids; g.ids_out = out.ids;
-    HIPCHK(c, launch_gather<T>(c->stream, g));
+    // (the numbering's launch gathers the rows too: bvh_emit_gather)
+    HIPCHK(c, bvh_build_finish(c->stream, in.weight, n, leaf, 0, s.bb_scratch, L, nullptr, s.geom0, s.geom1, s.link, s.node_depth,
+                               s.node_mass, s.node_size, &g));
     if (!stamps) rc = phase_mark(c, ph, 1);
     if (rc) return rc;
     // ---- walk (rows as after the build: `out` is the permuted set, `in` the snapshot)

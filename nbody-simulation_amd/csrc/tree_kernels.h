@@ -101,6 +101,22 @@ template <class T> struct GatherArgs {
   int* zero8 = nullptr;           // 8 words set to zero by the first thread (counters of a kernel further down the stream)
 };
 
+// one row of the gather (gather_particles, and the tail of bvh_emit_gather)
+template <class T> __device__ __forceinline__ void gather_row(const GatherArgs<T>& a, const int64_t i) {
+  using T2 = typename NodeVec2<T>::type;
+  if (i == 0 && a.zero8)
+    for (int k = 0; k < 8; ++k) a.zero8[k] = 0;
+  if (i >= a.n) return;
+  int64_t s = (int64_t)a.perm[i];
+  if (a.perm_copy) a.perm_copy[i] = (uint32_t)s;
+  if (s >= a.n) s = i;  // a build that failed leaves no permutation behind; the rows it produces are never used
+  if (a.pos_out) reinterpret_cast<T2*>(a.pos_out)[i] = reinterpret_cast<const T2*>(a.pos_in)[s];
+  if (a.vel_out) reinterpret_cast<T2*>(a.vel_out)[i] = reinterpret_cast<const T2*>(a.vel_in)[s];
+  if (a.weight_out) a.weight_out[i] = a.weight_in[s];
+  if (a.ids_out) a.ids_out[i] = a.ids_in[s];
+  if (a.mass_out) a.mass_out[i] = (T)a.weight_in[s];  // `weight as f32`, main.rs:360
+}
+
 template <class T> hipError_t launch_tree_walk(hipStream_t s, const WalkArgs<T>& a, bool wave_uniform);
 hipError_t launch_div_pair_selftest(hipStream_t s, const float* nx, const float* ny, const float* den, int64_t n, float* qx, float* qy);
 template <class T> hipError_t launch_gather(hipStream_t s, const GatherArgs<T>& a);

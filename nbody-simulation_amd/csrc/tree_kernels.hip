@@ -427,19 +427,7 @@ __global__ __launch_bounds__(256) void tree_walk_small(const WalkArgs<T> a, cons
 
 template <class T>
 __global__ __launch_bounds__(256) void gather_particles(const GatherArgs<T> a) {
-  using T2 = typename V2<T>::type;
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i == 0 && a.zero8)
-    for (int k = 0; k < 8; ++k) a.zero8[k] = 0;
-  if (i >= a.n) return;
-  int64_t s = (int64_t)a.perm[i];
-  if (a.perm_copy) a.perm_copy[i] = (uint32_t)s;
-  if (s >= a.n) s = i;  // a build that failed leaves no permutation behind; the rows it produces are never used
-  if (a.pos_out) reinterpret_cast<T2*>(a.pos_out)[i] = reinterpret_cast<const T2*>(a.pos_in)[s];
-  if (a.vel_out) reinterpret_cast<T2*>(a.vel_out)[i] = reinterpret_cast<const T2*>(a.vel_in)[s];
-  if (a.weight_out) a.weight_out[i] = a.weight_in[s];
-  if (a.ids_out) a.ids_out[i] = a.ids_in[s];
-  if (a.mass_out) a.mass_out[i] = (T)a.weight_in[s];  // `weight as f32`, main.rs:360
+  gather_row<T>(a, (int64_t)blockIdx.x * 256 + threadIdx.x);
 }
 
 // main.rs:419-423: v += a*dt ; x += v*dt, multiply then add, in place.
