@@ -1,7 +1,7 @@
 """Soak of the reference's own workload against the oracle: World::new's scene (151 405 bodies), BVH, theta 50, dt 0.1, AS WRITTEN
 (main.rs:388-425), stepped on the device (product library, steps enqueued ahead of the host) and by the CPU restatement, compared
 bit for bit — positions, velocities, weights and the row permutation — every `every` steps.
-    python tools/soak_ref_scene.py [steps=2000] [every=250] [bvh|quad]
+    python tools/soak_ref_scene.py [steps=2000] [every=250] [bvh|quad] [f32|f64] [written|consistent]
 A long run exercises what single steps do not: the walk's estimate from the previous walk's history, the device build's level
 count learnt from the step before, the decoupled look-back scan's epochs, the speculation of the step enqueued ahead."""
 import json, os, sys, time
@@ -13,14 +13,20 @@ C = nb._capi
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 every = int(sys.argv[2]) if len(sys.argv) > 2 else 250
 tree = sys.argv[3] if len(sys.argv) > 3 else "bvh"   # quad: the quad tree in World::update's place (quad_tree.rs:153-270; theta 0.5)
+dtype = np.float64 if len(sys.argv) > 4 and sys.argv[4] == "f64" else np.float32
+consistent = len(sys.argv) > 5 and sys.argv[5] == "consistent"   # every acceleration applied to the row it was computed for
 pos, vel, w = nb.scenes.galaxy()
+pos, vel = pos.astype(dtype), vel.astype(dtype)
 n = pos.shape[0]
 ids = np.arange(n, dtype=np.uint32)
 o_pos, o_vel, o_w, o_ids = pos, vel, w, ids
-out = {"scene": "World::new (seeded)", "n": int(n), "steps": steps, "compared_every": every, "tree": tree, "order": "as written", "checks": []}
+out = {"scene": "World::new (seeded)", "n": int(n), "steps": steps, "compared_every": every, "tree": tree, "dtype": "f64" if dtype == np.float64 else "f32",
+       "order": "consistent" if consistent else "as written", "checks": []}
 with C.Context(0) as c:
     if tree == "quad":
         c.set_params(theta=0.5)
+    if consistent:
+        c.set_params(order=C.ORDER_CONSISTENT)
     c.upload(pos, vel, w)
     done = 0
     gpu_s = cpu_s = 0.0
@@ -40,7 +46,8 @@ with C.Context(0) as c:
             if tree == "quad":
                 o_pos, o_vel, _ = orc.update_quad(o_pos, o_vel, o_w, theta=0.5, nsteps=k, nthreads=16)   # (the quad build leaves the rows in place)
             else:
-                o_pos, o_vel, o_w, o_ids, _ = orc.update_bvh(o_pos, o_vel, o_w, nsteps=k, nthreads=16, ids=o_ids)
+                o_pos, o_vel, o_w, o_ids, _ = orc.update_bvh(o_pos, o_vel, o_w, nsteps=k, nthreads=16, ids=o_ids,
+                                                                 mode=orc.CONSISTENT if consistent else orc.AS_WRITTEN)
         except RuntimeError:
             cpu_degenerate = True
         cpu_s += time.perf_counter() - t0
@@ -54,7 +61,7 @@ with C.Context(0) as c:
             break
         done += k
         p, v, w2, i2 = c.download()
-        same = bool(np.array_equal(p.view(np.uint32), o_pos.view(np.uint32)) and np.array_equal(v.view(np.uint32), o_vel.view(np.uint32))
+        same = bool(np.array_equal(p.view(np.uint8), o_pos.view(np.uint8)) and np.array_equal(v.view(np.uint8), o_vel.view(np.uint8))
                     and np.array_equal(w2, o_w) and np.array_equal(i2, o_ids))
         out["checks"].append({"step": done, "bit_identical": same, "device_build": bool(c.last_build_on_device())})
         print(f"step {done}: bit identical to the oracle: {same}", flush=True)
